@@ -1,0 +1,91 @@
+"""ctypes binding of ``csrc/libf5hip.so`` (C ABI declared in ``include/f5hip.h``).
+
+This is the stub a reference maintainer would add next to ``src/f5_tts/infer/utils_infer.py`` to
+call the engine.  There is NO fallback: if the shared library is missing or
+fails to load, importing the engine raises — the product path never routes through CPU code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
+
+PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
+
+
+class DitConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim", "conv_layers",
+        "text_mask_padding", "pe_attn_head", "attn_mask_enabled", "conv_pos_kernel", "conv_pos_groups")]
+
+
+class VocosConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_channels", "dim", "intermediate_dim", "num_layers", "n_fft", "hop_length")]
+
+
+# every symbol include/f5hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "f5hip_abi_version": (C.c_int, []),
+    "f5hip_create": (C.c_int, [C.POINTER(DitConfigC), C.POINTER(VocosConfigC), C.c_int, C.POINTER(_P)]),
+    "f5hip_destroy": (C.c_int, [_P]),
+    "f5hip_last_error": (C.c_char_p, [_P]),
+    "f5hip_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "f5hip_num_tensors": (C.c_int, [_P]),
+    "f5hip_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "f5hip_weight_blob": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "f5hip_mark_all_loaded": (C.c_int, [_P]),
+    "f5hip_finalize_weights": (C.c_int, [_P]),
+    "f5hip_mel": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int, _P]),
+    "f5hip_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int,
+                               _P, _P, _P]),
+    "f5hip_debug_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
+    "f5hip_vocos_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "f5hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "f5hip_num_kernel_stats": (C.c_int, [_P]),
+    "f5hip_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "f5hip_reset_kernel_stats": (C.c_int, [_P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class F5HipError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen libf5hip.so and type every entry point.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path == LIB_PATH:
+        return _lib
+    if not os.path.isfile(path):
+        raise F5HipError(f"{path} not found — build it with `python __graft_entry__.py` (or `make -C f5-tts_amd/csrc`); "
+                         "there is no CPU fallback")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    if lib.f5hip_abi_version() != 1:
+        raise F5HipError("libf5hip ABI version mismatch")
+    if path == LIB_PATH:
+        _lib = lib
+    return lib
+
+
+def check(lib: C.CDLL, ctx, status: int) -> None:
+    if status == 0:
+        return
+    msg = lib.f5hip_last_error(ctx)
+    text = msg.decode("utf-8", "replace") if msg else "unknown error"
+    # mirror the reference's error behaviour: bad shapes/arguments are ValueError (asserts in cfm.py:109,124),
+    # everything else RuntimeError
+    if status in (1, 4):
+        raise ValueError(f"f5hip: {text}")
+    raise F5HipError(f"f5hip (status {status}): {text}")

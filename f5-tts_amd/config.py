@@ -1,0 +1,80 @@
+"""Architecture constants of the hot path (host side).
+
+Mirrors the ``model.arch`` / ``model.mel_spec`` blocks of the reference's Hydra configs
+(reference ``src/f5_tts/configs/F5TTS_v1_Base.yaml:20-47``, ``F5TTS_Base.yaml:20-46``,
+``E2TTS_Base.yaml:20-41``) and the keyword arguments of ``DiT.__init__``
+(reference ``src/f5_tts/model/backbones/dit.py:171-192``).
+"""
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass, replace
+from typing import Optional
+
+# mel front-end constants: reference src/f5_tts/infer/utils_infer.py:52-58
+TARGET_SAMPLE_RATE = 24000
+N_MEL_CHANNELS = 100
+HOP_LENGTH = 256
+WIN_LENGTH = 1024
+N_FFT = 1024
+
+
+@dataclass(frozen=True)
+class DiTConfig:
+    dim: int = 1024
+    depth: int = 22
+    heads: int = 16
+    dim_head: int = 64
+    ff_mult: int = 2
+    mel_dim: int = N_MEL_CHANNELS
+    text_num_embeds: int = 2545
+    text_dim: int = 512
+    text_mask_padding: bool = True
+    conv_layers: int = 4
+    pe_attn_head: Optional[int] = None  # None = rope on all heads, k = first k heads only
+    attn_mask_enabled: bool = False
+    conv_pos_kernel: int = 31
+    conv_pos_groups: int = 16
+    backbone: str = "DiT"
+
+    @property
+    def ff_inner(self) -> int:
+        return int(self.dim * self.ff_mult)
+
+    def arch_kwargs(self) -> dict:
+        """kwargs accepted by the reference ``DiT(**model_cfg, text_num_embeds=..., mel_dim=...)``."""
+        return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head,
+                    ff_mult=self.ff_mult, text_dim=self.text_dim, text_mask_padding=self.text_mask_padding,
+                    conv_layers=self.conv_layers, pe_attn_head=self.pe_attn_head,
+                    attn_mask_enabled=self.attn_mask_enabled, mel_dim=self.mel_dim,
+                    text_num_embeds=self.text_num_embeds)
+
+    def to_dict(self) -> dict:
+        return asdict(self)
+
+
+@dataclass(frozen=True)
+class VocosConfig:
+    """charactr/vocos-mel-24khz ``config.yaml`` (loader: reference src/f5_tts/infer/utils_infer.py:106-129)."""
+    input_channels: int = N_MEL_CHANNELS
+    dim: int = 512
+    intermediate_dim: int = 1536
+    num_layers: int = 8
+    n_fft: int = N_FFT
+    hop_length: int = HOP_LENGTH
+
+
+F5TTS_V1_BASE = DiTConfig()  # api/cli default (reference src/f5_tts/api.py:26)
+F5TTS_BASE = replace(F5TTS_V1_BASE, text_mask_padding=False, pe_attn_head=1)
+# reduced sizes used by the parity tests (same code path, seconds on the CPU oracle)
+DIT_TINY = DiTConfig(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, text_dim=128, conv_layers=2,
+                     text_num_embeds=255)
+DIT_TINY_V0 = replace(DIT_TINY, text_mask_padding=False, pe_attn_head=1)
+VOCOS_MEL_24K = VocosConfig()
+VOCOS_TINY = VocosConfig(dim=128, intermediate_dim=384, num_layers=2)
+
+PRESETS = {
+    "F5TTS_v1_Base": F5TTS_V1_BASE,
+    "F5TTS_Base": F5TTS_BASE,
+    "tiny": DIT_TINY,
+    "tiny_v0": DIT_TINY_V0,
+}

@@ -1,0 +1,979 @@
+// api.cpp — C-ABI entry points of libf5hip (include/f5hip.h): context, weight blob, and the
+// enqueue logic of the sampler / mel / vocoder pipelines.  No torch types, no CPU fallback: every
+// numeric step is a launch of a kernel from gemm/elementwise/convpos/attention/audio.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "engine.h"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      char _b[512];                                                                                    \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      ctx->err = _b;                                                                                   \
+      return F5HIP_ERR_HIP;                                                                            \
+    }                                                                                                  \
+  } while (0)
+
+#define FAIL(code, ...)                          \
+  do {                                           \
+    char _b[512];                                \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);       \
+    ctx->err = _b;                               \
+    return code;                                 \
+  } while (0)
+
+#define CHK(expr)                   \
+  do {                              \
+    int _r = (expr);                \
+    if (_r != F5HIP_OK) return _r;  \
+  } while (0)
+
+int add_slot(f5hip_ctx* ctx, const std::string& name, int64_t numel, bool optional = false) {
+  Slot s;
+  s.name = name;
+  s.numel = numel;
+  s.offset = ctx->blob_elems;
+  s.optional = optional;
+  ctx->index[name] = (int)ctx->slots.size();
+  ctx->slots.push_back(s);
+  ctx->blob_elems += (numel + 3) & ~int64_t(3);  // keep every tensor 16-byte aligned
+  return (int)ctx->slots.size() - 1;
+}
+
+const float* W(const f5hip_ctx* ctx, const std::string& name) {
+  auto it = ctx->index.find(name);
+  if (it == ctx->index.end()) return nullptr;
+  return ctx->blob + ctx->slots[it->second].offset;
+}
+
+// Blob order is chosen so that fused operands are contiguous: [to_q|to_k|to_v] per block, and the
+// AdaLN linears of ALL blocks back to back (one GEMM computes every block's modulation for every step).
+void build_slots(f5hip_ctx* ctx) {
+  const auto& c = ctx->cfg;
+  const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
+  const std::string p = "transformer.";
+  add_slot(ctx, p + "time_embed.time_mlp.0.weight", D * 256);
+  add_slot(ctx, p + "time_embed.time_mlp.0.bias", D);
+  add_slot(ctx, p + "time_embed.time_mlp.2.weight", D * D);
+  add_slot(ctx, p + "time_embed.time_mlp.2.bias", D);
+  add_slot(ctx, p + "text_embed.text_embed.weight", (int64_t)(c.text_num_embeds + 1) * T);
+  for (int i = 0; i < c.conv_layers; ++i) {
+    const std::string b = p + "text_embed.text_blocks." + std::to_string(i) + ".";
+    add_slot(ctx, b + "dwconv.weight", T * 7);
+    add_slot(ctx, b + "dwconv.bias", T);
+    add_slot(ctx, b + "norm.weight", T);
+    add_slot(ctx, b + "norm.bias", T);
+    add_slot(ctx, b + "pwconv1.weight", 2 * T * T);
+    add_slot(ctx, b + "pwconv1.bias", 2 * T);
+    add_slot(ctx, b + "grn.gamma", 2 * T);
+    add_slot(ctx, b + "grn.beta", 2 * T);
+    add_slot(ctx, b + "pwconv2.weight", 2 * T * T);
+    add_slot(ctx, b + "pwconv2.bias", T);
+  }
+  add_slot(ctx, p + "input_embed.proj.weight", D * (2 * mel + T));
+  add_slot(ctx, p + "input_embed.proj.bias", D);
+  const int64_t cpg = D / c.conv_pos_groups;
+  for (int j = 0; j < 2; ++j) {
+    const std::string b = p + "input_embed.conv_pos_embed.conv1d." + std::to_string(2 * j) + ".";
+    add_slot(ctx, b + "weight", D * cpg * c.conv_pos_kernel);
+    add_slot(ctx, b + "bias", D);
+  }
+  add_slot(ctx, p + "rotary_embed.inv_freq", c.dim_head / 2, /*optional=*/true);
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.weight", 6 * D * D);
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.bias", 6 * D);
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = p + "transformer_blocks." + std::to_string(i) + ".";
+    add_slot(ctx, b + "attn.to_q.weight", inner * D);
+    add_slot(ctx, b + "attn.to_k.weight", inner * D);
+    add_slot(ctx, b + "attn.to_v.weight", inner * D);
+    add_slot(ctx, b + "attn.to_q.bias", inner);
+    add_slot(ctx, b + "attn.to_k.bias", inner);
+    add_slot(ctx, b + "attn.to_v.bias", inner);
+    add_slot(ctx, b + "attn.to_out.0.weight", D * inner);
+    add_slot(ctx, b + "attn.to_out.0.bias", D);
+    add_slot(ctx, b + "ff.ff.0.0.weight", F * D);
+    add_slot(ctx, b + "ff.ff.0.0.bias", F);
+    add_slot(ctx, b + "ff.ff.2.weight", D * F);
+    add_slot(ctx, b + "ff.ff.2.bias", D);
+  }
+  add_slot(ctx, p + "norm_out.linear.weight", 2 * D * D);
+  add_slot(ctx, p + "norm_out.linear.bias", 2 * D);
+  add_slot(ctx, p + "proj_out.weight", mel * D);
+  add_slot(ctx, p + "proj_out.bias", mel);
+  add_slot(ctx, p + "text_embed.freqs_cis", 8192 * T, /*optional=*/true);  // non-persistent buffer (dit.py:48)
+  ctx->dit_elems = ctx->blob_elems;
+  if (ctx->has_vocos) {
+    const auto& v = ctx->vcfg;
+    const int64_t C = v.dim, I = v.intermediate_dim;
+    add_slot(ctx, "backbone.embed.weight", C * v.input_channels * 7);
+    add_slot(ctx, "backbone.embed.bias", C);
+    add_slot(ctx, "backbone.norm.weight", C);
+    add_slot(ctx, "backbone.norm.bias", C);
+    for (int i = 0; i < v.num_layers; ++i) {
+      const std::string b = "backbone.convnext." + std::to_string(i) + ".";
+      add_slot(ctx, b + "dwconv.weight", C * 7);
+      add_slot(ctx, b + "dwconv.bias", C);
+      add_slot(ctx, b + "norm.weight", C);
+      add_slot(ctx, b + "norm.bias", C);
+      add_slot(ctx, b + "pwconv1.weight", I * C);
+      add_slot(ctx, b + "pwconv1.bias", I);
+      add_slot(ctx, b + "pwconv2.weight", C * I);
+      add_slot(ctx, b + "pwconv2.bias", C);
+      add_slot(ctx, b + "gamma", C);
+    }
+    add_slot(ctx, "backbone.final_layer_norm.weight", C);
+    add_slot(ctx, "backbone.final_layer_norm.bias", C);
+    add_slot(ctx, "head.out.weight", (int64_t)(v.n_fft + 2) * C);
+    add_slot(ctx, "head.out.bias", v.n_fft + 2);
+    add_slot(ctx, "head.istft.window", v.n_fft, /*optional=*/true);
+  }
+}
+
+bool slot_loaded(const f5hip_ctx* ctx, const std::string& name) {
+  auto it = ctx->index.find(name);
+  return it != ctx->index.end() && ctx->slots[it->second].loaded;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+struct Prof {
+  f5hip_ctx* ctx;
+  hipStream_t s;
+  int kc;
+  double flops, bytes;
+  ProfRec rec{};
+  bool on;
+  Prof(f5hip_ctx* c, hipStream_t st, int kclass, double fl, double by) : ctx(c), s(st), kc(kclass), flops(fl), bytes(by), on(c->profile) {
+    if (on) {
+      rec.kclass = kc;
+      rec.flops = fl;
+      rec.bytes = by;
+      (void)hipEventCreate(&rec.e0);
+      (void)hipEventCreate(&rec.e1);
+      (void)hipEventRecord(rec.e0, s);
+    }
+  }
+  ~Prof() {
+    if (on) {
+      (void)hipEventRecord(rec.e1, s);
+      ctx->prof.push_back(rec);
+    }
+  }
+};
+
+void collect_prof(f5hip_ctx* ctx, hipStream_t s) {
+  if (ctx->prof.empty()) return;
+  (void)hipStreamSynchronize(s);
+  for (auto& r : ctx->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      KStat& k = ctx->stats[r.kclass];
+      k.calls += 1;
+      k.ms += ms;
+      k.flops += r.flops;
+      k.bytes += r.bytes;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  ctx->prof.clear();
+}
+
+const char* kclass_name(int k) {
+  static const char* names[KC_COUNT] = {"gemm_block", "attention", "convpos", "ln_modulate", "gemm_misc", "text_embed",
+                                        "elementwise", "mel", "vocos_gemm", "vocos_other", "istft"};
+  return names[k];
+}
+
+// ---- GEMM helpers ------------------------------------------------------------------------------
+GemmCore core(const void* A, int64_t lda, const void* Wt, int64_t ldw, int M, int N, int K) {
+  GemmCore g{};
+  g.A = A; g.A_lo = nullptr; g.W = Wt; g.W_lo = nullptr;
+  g.lda = lda; g.ldw = ldw; g.strideA = 0; g.strideW = 0;
+  g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
+  return g;
+}
+EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_NONE) {
+  EpiStore e{};
+  e.alpha = 1.f; e.act = act; e.bias = bias; e.out32 = out32; e.ldo = ldo; e.ldres = ldo;
+  return e;
+}
+
+double gemm_flops(int64_t M, int64_t N, int64_t K) { return 2.0 * (double)M * (double)N * (double)K; }
+
+int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
+
+// ---- finalize: derived layouts -------------------------------------------------------------------
+int finalize_impl(f5hip_ctx* ctx) {
+  const auto& c = ctx->cfg;
+  const int64_t D = c.dim, T = c.text_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
+  for (auto& s : ctx->slots)
+    if (!s.loaded && !s.optional) FAIL(F5HIP_ERR_STATE, "tensor '%s' was never loaded", s.name.c_str());
+  hipStream_t st = nullptr;
+  const std::string p = "transformer.";
+
+  // f16 hi/lo copies of the per-step GEMM weights
+  const int64_t per_block = 3 * inner * D + D * inner + F * D + D * F;
+  HIPCHK(ctx->half_pool.ensure((size_t)(per_block * c.depth * 2) * sizeof(f16)));
+  f16* hp = ctx->half_pool.as<f16>();
+  ctx->blocks.assign(c.depth, BlockW{});
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = p + "transformer_blocks." + std::to_string(i) + ".";
+    BlockW& bw = ctx->blocks[i];
+    bw.wqkv = W(ctx, b + "attn.to_q.weight");
+    bw.bqkv = W(ctx, b + "attn.to_q.bias");
+    bw.wo = W(ctx, b + "attn.to_out.0.weight");
+    bw.bo = W(ctx, b + "attn.to_out.0.bias");
+    bw.w1 = W(ctx, b + "ff.ff.0.0.weight");
+    bw.b1 = W(ctx, b + "ff.ff.0.0.bias");
+    bw.w2 = W(ctx, b + "ff.ff.2.weight");
+    bw.b2 = W(ctx, b + "ff.ff.2.bias");
+    auto carve = [&](const float* src, int64_t n, f16*& hi, f16*& lo) -> hipError_t {
+      hi = hp; hp += n;
+      lo = hp; hp += n;
+      return launch_split_f16(src, n, 1.0f, hi, lo, st);
+    };
+    HIPCHK(carve(bw.wqkv, 3 * inner * D, bw.wqkv_hi, bw.wqkv_lo));
+    HIPCHK(carve(bw.wo, D * inner, bw.wo_hi, bw.wo_lo));
+    HIPCHK(carve(bw.w1, F * D, bw.w1_hi, bw.w1_lo));
+    HIPCHK(carve(bw.w2, D * F, bw.w2_hi, bw.w2_lo));
+  }
+  ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm.linear.weight");
+  ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm.linear.bias");
+  {
+    const int64_t n = (int64_t)c.mel_dim * D;
+    HIPCHK(ctx->wp_hi.ensure(n * sizeof(f16)));
+    HIPCHK(ctx->wp_lo.ensure(n * sizeof(f16)));
+    HIPCHK(launch_split_f16(W(ctx, p + "proj_out.weight"), n, 1.0f, ctx->wp_hi.as<f16>(), ctx->wp_lo.as<f16>(), st));
+  }
+  // conv_pos weights -> per-tap operand tiles
+  const int cpg = (int)(D / c.conv_pos_groups);
+  for (int j = 0; j < 2; ++j) {
+    const int64_t n = D * cpg * c.conv_pos_kernel;
+    HIPCHK(ctx->conv_w32[j].ensure(n * sizeof(float)));
+    HIPCHK(ctx->conv_whi[j].ensure(n * sizeof(f16)));
+    HIPCHK(ctx->conv_wlo[j].ensure(n * sizeof(f16)));
+    HIPCHK(launch_convpos_pack(W(ctx, p + "input_embed.conv_pos_embed.conv1d." + std::to_string(2 * j) + ".weight"), (int)D, cpg,
+                               c.conv_pos_kernel, ctx->conv_w32[j].as<float>(), ctx->conv_whi[j].as<f16>(), ctx->conv_wlo[j].as<f16>(), st));
+  }
+  // depthwise weights [C,1,7] -> [7,C]
+  const int64_t vC = ctx->has_vocos ? ctx->vcfg.dim : 0;
+  HIPCHK(ctx->dwpack.ensure((size_t)(7 * (T * c.conv_layers + vC * (ctx->has_vocos ? ctx->vcfg.num_layers : 0)) + 4) * sizeof(float)));
+  float* dwp = ctx->dwpack.as<float>();
+  ctx->tblocks.assign(c.conv_layers, TextBlockW{});
+  for (int i = 0; i < c.conv_layers; ++i) {
+    const std::string b = p + "text_embed.text_blocks." + std::to_string(i) + ".";
+    TextBlockW& tb = ctx->tblocks[i];
+    tb.dw_b = W(ctx, b + "dwconv.bias"); tb.ln_w = W(ctx, b + "norm.weight"); tb.ln_b = W(ctx, b + "norm.bias");
+    tb.pw1_w = W(ctx, b + "pwconv1.weight"); tb.pw1_b = W(ctx, b + "pwconv1.bias");
+    tb.gamma = W(ctx, b + "grn.gamma"); tb.beta = W(ctx, b + "grn.beta");
+    tb.pw2_w = W(ctx, b + "pwconv2.weight"); tb.pw2_b = W(ctx, b + "pwconv2.bias");
+    tb.dw7 = dwp; dwp += 7 * T;
+    HIPCHK(launch_dw_pack(W(ctx, b + "dwconv.weight"), (int)T, tb.dw7, st));
+  }
+  // absolute sinusoid position table of the text encoder (reference model/modules.py:207-218), fp32 op order as torch
+  if (c.conv_layers > 0) {
+    const int64_t n = (int64_t)8192 * T;
+    HIPCHK(ctx->freqs_cis.ensure(n * sizeof(float)));
+    if (slot_loaded(ctx, p + "text_embed.freqs_cis")) {
+      HIPCHK(hipMemcpy(ctx->freqs_cis.p, W(ctx, p + "text_embed.freqs_cis"), n * sizeof(float), hipMemcpyDeviceToDevice));
+    } else {
+      std::vector<float> tab(n);
+      const int half = (int)T / 2;
+      for (int k = 0; k < half; ++k) {
+        const float e = (float)(2 * k) / (float)T;
+        const float f = 1.0f / powf(10000.0f, e);
+        for (int pos = 0; pos < 8192; ++pos) {
+          const float a = (float)pos * f;
+          tab[(int64_t)pos * T + k] = cosf(a);
+          tab[(int64_t)pos * T + half + k] = sinf(a);
+        }
+      }
+      HIPCHK(hipMemcpy(ctx->freqs_cis.p, tab.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  {
+    const int half = c.dim_head / 2;
+    HIPCHK(ctx->inv_freq.ensure(half * sizeof(float)));
+    if (slot_loaded(ctx, p + "rotary_embed.inv_freq")) {
+      HIPCHK(hipMemcpy(ctx->inv_freq.p, W(ctx, p + "rotary_embed.inv_freq"), half * sizeof(float), hipMemcpyDeviceToDevice));
+    } else {
+      std::vector<float> f(half);
+      for (int k = 0; k < half; ++k) f[k] = 1.0f / powf(10000.0f, (float)(2 * k) / (float)c.dim_head);
+      HIPCHK(hipMemcpy(ctx->inv_freq.p, f.data(), half * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  // audio tables: twiddles, periodic hann window, HTK mel filterbank (torchaudio melscale_fbanks, norm=None)
+  {
+    const int nfft = 1024, nbin = 513, nmel = c.mel_dim;
+    std::vector<float> tw(nfft), win(nfft), fb((size_t)nbin * nmel);
+    for (int k = 0; k < nfft / 2; ++k) {
+      const double a = 2.0 * M_PI * (double)k / (double)nfft;
+      tw[2 * k] = (float)cos(a);
+      tw[2 * k + 1] = (float)sin(a);
+    }
+    for (int i = 0; i < nfft; ++i) win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)nfft));
+    const double sr = 24000.0, fmin = 0.0, fmax = sr / 2;
+    auto hz2mel = [](double f) { return 2595.0 * log10(1.0 + f / 700.0); };
+    const double mmin = hz2mel(fmin), mmax = hz2mel(fmax);
+    std::vector<double> fpts(nmel + 2);
+    for (int i = 0; i < nmel + 2; ++i) {
+      const double m = mmin + (mmax - mmin) * (double)i / (double)(nmel + 1);
+      fpts[i] = 700.0 * (pow(10.0, m / 2595.0) - 1.0);
+    }
+    for (int k = 0; k < nbin; ++k) {
+      const double fr = (sr / 2) * (double)k / (double)(nbin - 1);
+      for (int m = 0; m < nmel; ++m) {
+        const double down = (fr - fpts[m]) / (fpts[m + 1] - fpts[m]);
+        const double up = (fpts[m + 2] - fr) / (fpts[m + 2] - fpts[m + 1]);
+        const double v = std::max(0.0, std::min(down, up));
+        fb[(size_t)k * nmel + m] = (float)v;
+      }
+    }
+    HIPCHK(ctx->twiddle.ensure(tw.size() * sizeof(float)));
+    HIPCHK(ctx->window.ensure(win.size() * sizeof(float)));
+    HIPCHK(ctx->melfb.ensure(fb.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(ctx->twiddle.p, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->window.p, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->melfb.p, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (ctx->has_vocos) {
+    const auto& v = ctx->vcfg;
+    if (v.n_fft != 1024 || v.hop_length != 256) FAIL(F5HIP_ERR_UNSUPPORTED, "vocos head: only n_fft=1024 / hop=256 is built");
+    const int64_t C = v.dim;
+    ctx->vlayers.assign(v.num_layers, VocosLayerW{});
+    for (int i = 0; i < v.num_layers; ++i) {
+      const std::string b = "backbone.convnext." + std::to_string(i) + ".";
+      VocosLayerW& l = ctx->vlayers[i];
+      l.dw_b = W(ctx, b + "dwconv.bias"); l.ln_w = W(ctx, b + "norm.weight"); l.ln_b = W(ctx, b + "norm.bias");
+      l.pw1_w = W(ctx, b + "pwconv1.weight"); l.pw1_b = W(ctx, b + "pwconv1.bias");
+      l.pw2_w = W(ctx, b + "pwconv2.weight"); l.pw2_b = W(ctx, b + "pwconv2.bias");
+      l.gamma = W(ctx, b + "gamma");
+      l.dw7 = dwp; dwp += 7 * C;
+      HIPCHK(launch_dw_pack(W(ctx, b + "dwconv.weight"), (int)C, l.dw7, st));
+    }
+    // head padded to a multiple of 4 output rows (1026 -> 1028)
+    const int nout = v.n_fft + 2, npad = (nout + 3) & ~3;
+    HIPCHK(ctx->vhead_w.ensure((size_t)npad * C * sizeof(float), nullptr, true));
+    HIPCHK(ctx->vhead_b.ensure((size_t)npad * sizeof(float), nullptr, true));
+    HIPCHK(hipMemcpy(ctx->vhead_w.p, W(ctx, "head.out.weight"), (size_t)nout * C * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(ctx->vhead_b.p, W(ctx, "head.out.bias"), (size_t)nout * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  HIPCHK(init_gemm_kernels());
+  HIPCHK(init_convpos_kernels());
+  HIPCHK(hipDeviceSynchronize());
+  ctx->finalized = true;
+  return F5HIP_OK;
+}
+
+// ---- time-grid tables: every step's time embedding and AdaLN modulation in 4 GEMMs -------------------
+int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int64_t D = c.dim;
+  const std::string p = "transformer.";
+  std::vector<float> dt(steps);
+  for (int i = 0; i < steps; ++i) dt[i] = t[i + 1] - t[i];
+  HIPCHK(ctx->dt_dev.ensure(std::max(steps, 64) * sizeof(float)));
+  HIPCHK(ctx->cfg_dev.ensure(16));
+  HIPCHK(hipMemcpyAsync(ctx->dt_dev.p, dt.data(), steps * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->cfg_dev.p, &cfg_strength, sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // dt / cfg are stack temporaries
+  const bool same = (int)ctx->t_host.size() == steps + 1 && memcmp(ctx->t_host.data(), t, (steps + 1) * sizeof(float)) == 0;
+  if (same) return F5HIP_OK;
+  bool moved = false;
+  HIPCHK(ctx->t_dev.ensure((steps + 1) * sizeof(float), &moved));
+  HIPCHK(ctx->tsin.ensure((size_t)steps * 256 * sizeof(float), &moved));
+  HIPCHK(ctx->th1.ensure((size_t)steps * D * sizeof(float), &moved));
+  HIPCHK(ctx->tsilu.ensure((size_t)steps * D * sizeof(float), &moved));
+  HIPCHK(ctx->mods.ensure((size_t)steps * c.depth * 6 * D * sizeof(float), &moved));
+  HIPCHK(ctx->fmods.ensure((size_t)steps * 2 * D * sizeof(float), &moved));
+  if (moved) ctx->ws_epoch++;
+  ctx->t_host.assign(t, t + steps + 1);
+  HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ctx->t_host.data(), (steps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
+  {
+    Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
+    HIPCHK(launch_time_sinus(ctx->t_dev.as<float>(), steps, 256, ctx->tsin.as<float>(), st));
+    // TimestepEmbedding (reference model/modules.py:852-862) then SiLU (input of every AdaLN linear, :322,343)
+    GemmCore g = core(ctx->tsin.p, 256, W(ctx, p + "time_embed.time_mlp.0.weight"), 256, steps, (int)D, 256);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->th1.as<float>(), D, W(ctx, p + "time_embed.time_mlp.0.bias"), ACT_SILU), 1, st));
+    g = core(ctx->th1.p, D, W(ctx, p + "time_embed.time_mlp.2.weight"), D, steps, (int)D, (int)D);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->tsilu.as<float>(), D, W(ctx, p + "time_embed.time_mlp.2.bias"), ACT_SILU), 1, st));
+    const int nm = c.depth * 6 * (int)D;
+    g = core(ctx->tsilu.p, D, ctx->adaln_w, D, steps, nm, (int)D);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->mods.as<float>(), nm, ctx->adaln_b), 1, st));
+    g = core(ctx->tsilu.p, D, W(ctx, p + "norm_out.linear.weight"), D, steps, 2 * (int)D, (int)D);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->fmods.as<float>(), 2 * D, W(ctx, p + "norm_out.linear.bias")), 1, st));
+  }
+  return F5HIP_OK;
+}
+
+// ---- workspace -----------------------------------------------------------------------------------
+int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
+  const auto& c = ctx->cfg;
+  const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
+  const int64_t BN = (int64_t)B * n, M = 2 * BN;
+  bool moved = false;
+#define ENS(buf, bytes) HIPCHK(ctx->buf.ensure((size_t)(bytes), &moved))
+  ENS(tok, BN * 4); ENS(valid, BN); ENS(textkeep, M); ENS(rowvalid, M); ENS(condmask, BN); ENS(kvlen, 2 * B * 4);
+  ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, 2 * B * 2 * T * 4);
+  ENS(step_cond, BN * mel * 4); ENS(cconst, M * D * 4); ENS(y, BN * mel * 4);
+  ENS(h, M * D * 4); ENS(c1, M * D * 4); ENS(x, M * D * 4);
+  ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)n * c.dim_head * 4);
+  if (op == OP_F32) {
+    ENS(a32, M * D * 4); ENS(o32, M * inner * 4); ENS(f32, M * F * 4);
+  } else {
+    ENS(a_hi, M * D * 2); ENS(o_hi, M * inner * 2); ENS(f_hi, M * F * 2);
+    if (op == OP_F16X3) { ENS(a_lo, M * D * 2); ENS(o_lo, M * inner * 2); ENS(f_lo, M * F * 2); }
+  }
+  if (exact_attn) {
+    const int64_t np = (n + 3) & ~3;
+    ENS(q32, M * inner * 4); ENS(k32, M * inner * 4);
+    if ((size_t)(2 * B * c.heads * c.dim_head * np * 4) > ctx->vt32.cap) {
+      HIPCHK(ctx->vt32.ensure((size_t)(2 * B * c.heads * c.dim_head * np * 4), &moved, /*zero=*/true));
+    } else if (ctx->ws_n != n) {
+      HIPCHK(hipMemset(ctx->vt32.p, 0, ctx->vt32.cap));  // padding columns must be zero for the new row stride
+    }
+    ENS(scores, (int64_t)2 * B * c.heads * n * np * 4);
+  } else {
+    ENS(q16, M * inner * 2); ENS(k16, M * inner * 2); ENS(v16, M * inner * 2);
+  }
+#undef ENS
+  if (moved) ctx->ws_epoch++;
+  ctx->ws_B = B;
+  ctx->ws_n = n;
+  return F5HIP_OK;
+}
+
+// ---- text embedding (once per utterance; reference dit.py:86-139, cached across steps :294-310) -----
+int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, const int64_t* duration, int use_mask, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int T = c.text_dim;
+  const int64_t BN = (int64_t)B * n, M = 2 * BN;
+  std::vector<int32_t> tok(BN);
+  std::vector<uint8_t> valid(BN), keep(M);
+  for (int b = 0; b < B; ++b) {
+    const int64_t sl = use_mask ? std::min<int64_t>(duration[b], n) : n;
+    for (int pos = 0; pos < n; ++pos) {
+      int64_t id = pos < nt ? text[(int64_t)b * nt + pos] + 1 : 0;  // +1, 0 = filler (dit.py:87,95-96)
+      const bool ok = pos < sl;
+      if (!ok) id = 0;
+      if (id < 0 || id > c.text_num_embeds) FAIL(F5HIP_ERR_INVALID, "text id %lld out of range at [%d,%d]", (long long)(id - 1), b, pos);
+      tok[(int64_t)b * n + pos] = (int32_t)id;
+      valid[(int64_t)b * n + pos] = ok ? 1 : 0;
+      const uint8_t k = (c.text_mask_padding && id == 0) ? 0 : 1;
+      keep[(int64_t)b * n + pos] = k;
+      keep[BN + (int64_t)b * n + pos] = k;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok.data(), BN * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BN, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->textkeep.p, keep.data(), M, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  Prof pr(ctx, st, KC_TEXT, 0, 0);
+  float* tx = ctx->tx.as<float>();
+  HIPCHK(launch_text_embed(ctx->tok.as<int32_t>(), ctx->valid.as<uint8_t>(), W(ctx, "transformer.text_embed.text_embed.weight"),
+                           ctx->freqs_cis.as<float>(), B, n, T, c.text_mask_padding, c.conv_layers > 0, tx, st));
+  const uint8_t* keepd = c.text_mask_padding ? ctx->textkeep.as<uint8_t>() : nullptr;
+  for (int i = 0; i < c.conv_layers; ++i) {
+    const TextBlockW& tb = ctx->tblocks[i];
+    // ConvNeXtV2Block (reference model/modules.py:270-280)
+    HIPCHK(launch_dwconv7_ln(tx, 2 * B, n, T, tb.dw7, tb.dw_b, tb.ln_w, tb.ln_b, 1e-6f, ctx->ta.as<float>(), st));
+    GemmCore g = core(ctx->ta.p, T, tb.pw1_w, T, (int)M, 2 * T, T);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->th.as<float>(), 2 * T, tb.pw1_b, ACT_GELU_ERF), 1, st));
+    HIPCHK(launch_grn_sumsq(ctx->th.as<float>(), 2 * B, n, 2 * T, ctx->sumsq.as<float>(), st));
+    HIPCHK(launch_grn_apply(ctx->th.as<float>(), ctx->sumsq.as<float>(), tb.gamma, tb.beta, 2 * B, n, 2 * T, ctx->tg.as<float>(), st));
+    g = core(ctx->tg.p, 2 * T, tb.pw2_w, 2 * T, (int)M, T, 2 * T);
+    EpiStore e = epi_store(tx, T, tb.pw2_b);
+    e.res = tx; e.ldres = T;
+    e.rowmask = keepd; e.mask_mode = 2;  // masked_fill after the residual add (dit.py:127)
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  return F5HIP_OK;
+}
+
+// ---- one ODE function evaluation + Euler update ---------------------------------------------------
+int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
+  const int64_t BN = (int64_t)B * n;
+  const int M = (int)(2 * BN);
+  const std::string p = "transformer.";
+  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;
+  float* x = ctx->x.as<float>();
+  float* h = ctx->h.as<float>();
+  const int wbytes = op == OP_F32 ? 4 : 2;
+  const int npl = op == OP_F16X3 ? 3 : 1;
+
+  {  // InputEmbedding.proj: only the x columns are per-step (dit.py:162); cond/text part is in cconst
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
+    GemmCore g = core(ctx->y.p, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
+    EpiStore e = epi_store(h, D, nullptr);
+    e.res = ctx->cconst.as<float>(); e.ldres = D;
+    e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D;
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  {  // ConvPositionEmbedding + residual (dit.py:163, modules.py:187-201)
+    const int cpg = D / c.conv_pos_groups;
+    Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops(M, D, (int64_t)cpg * c.conv_pos_kernel) * (npl == 3 ? 1 : 1), 0);
+    HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, 2 * B, n, D, c.conv_pos_groups,
+                          c.conv_pos_kernel, ctx->c1.as<float>(), st));
+    HIPCHK(launch_convpos(op, ctx->c1.as<float>(), ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, 2 * B, n, D, c.conv_pos_groups,
+                          c.conv_pos_kernel, x, st));
+  }
+  const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
+  float* a32 = op == OP_F32 ? ctx->a32.as<float>() : nullptr;
+  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() : nullptr;
+  f16* a_lo = op == OP_F16X3 ? ctx->a_lo.as<f16>() : nullptr;
+  const void* A = op == OP_F32 ? (const void*)a32 : (const void*)a_hi;
+  float* o32 = op == OP_F32 ? ctx->o32.as<float>() : nullptr;
+  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() : nullptr;
+  f16* o_lo = op == OP_F16X3 ? ctx->o_lo.as<f16>() : nullptr;
+  float* f32 = op == OP_F32 ? ctx->f32.as<float>() : nullptr;
+  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() : nullptr;
+  f16* f_lo = op == OP_F16X3 ? ctx->f_lo.as<f16>() : nullptr;
+  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() : nullptr;
+  const double ln_bytes = (double)M * D * (4 + wbytes * (op == OP_F16X3 ? 2 : 1));
+
+  for (int i = 0; i < c.depth; ++i) {
+    const BlockW& bw = ctx->blocks[i];
+    const float* md = mods_step + (int64_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:323)
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st));
+    }
+    {  // fused to_q|to_k|to_v + rope + 1/sqrt(dh) (modules.py:481-509; SDPA default scale)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
+      GemmCore g = core(A, D, op == OP_F32 ? (const void*)bw.wqkv : (const void*)bw.wqkv_hi, D, M, 3 * inner, D);
+      g.A_lo = a_lo; g.W_lo = bw.wqkv_lo;
+      EpiQKV e{};
+      e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = n; e.heads = H; e.dh = dh;
+      e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
+      if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (n + 3) & ~3; }
+      else { e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.v16 = ctx->v16.as<f16>(); }
+      HIPCHK(launch_gemm_qkv(op, g, e, st));
+    }
+    {
+      Prof pr(ctx, st, KC_ATTN, 4.0 * (double)(2 * B) * H * (double)n * n * dh, 0);
+      if (exact_attn) {
+        // materialised-score attention in fp32: S = QK^T (batched GEMM), row softmax, O = PV (batched GEMM)
+        const int np = (n + 3) & ~3;
+        GemmCore g = core(ctx->q32.p, dh, ctx->k32.p, dh, n, np, dh);
+        g.w_rows = n; g.strideA = (int64_t)n * dh; g.strideW = (int64_t)n * dh;
+        EpiStore e = epi_store(ctx->scores.as<float>(), np, nullptr);
+        e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
+        HIPCHK(launch_gemm_store(OP_F32, g, e, 2 * B * H, st));
+        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)2 * B * H * n, np, n, H, kvlen, n, st));
+        g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
+        g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
+        EpiStore e2 = epi_store(o32, inner, nullptr);
+        e2.out16 = o_hi; e2.out16_lo = o_lo;
+        e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
+        HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
+      } else {
+        HIPCHK(launch_flash_attn(ctx->q16.as<f16>(), ctx->k16.as<f16>(), ctx->v16.as<f16>(), 2 * B, H, n, kvlen, o_hi, o_lo, st));
+      }
+    }
+    {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, inner, op == OP_F32 ? (const void*)bw.wo : (const void*)bw.wo_hi,
+                        inner, M, D, inner);
+      g.A_lo = o_lo; g.W_lo = bw.wo_lo;
+      EpiStore e = epi_store(x, D, bw.bo);
+      e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, a32, a_hi, a_lo, D, st));
+    }
+    {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
+      GemmCore g = core(A, D, op == OP_F32 ? (const void*)bw.w1 : (const void*)bw.w1_hi, D, M, F, D);
+      g.A_lo = a_lo; g.W_lo = bw.w1_lo;
+      EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
+      e.out16 = f_hi; e.out16_lo = f_lo;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {  // x += gate_mlp * ff (modules.py:755)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, F, op == OP_F32 ? (const void*)bw.w2 : (const void*)bw.w2_hi, F, M, D, F);
+      g.A_lo = f_lo; g.W_lo = bw.w2_lo;
+      EpiStore e = epi_store(x, D, bw.b2);
+      e.colscale = md + 5 * D; e.res = x; e.ldres = D;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+  }
+  {  // AdaLayerNorm_Final: chunk order is (scale, shift) (modules.py:344) + proj_out (dit.py:367-368)
+    const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, fm, fm + D, a32, a_hi, a_lo, D, st));
+    }
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, mel, D), 0);
+    GemmCore g = core(A, D, op == OP_F32 ? (const void*)W(ctx, p + "proj_out.weight") : (const void*)ctx->wp_hi.p, D, M, mel, D);
+    g.A_lo = a_lo; g.W_lo = ctx->wp_lo.p;
+    HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias")), 1, st));
+  }
+  {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
+    HIPCHK(launch_cfg_euler(ctx->y.as<float>(), ctx->vel.as<float>(), BN * mel, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            traj ? traj + (int64_t)(step + 1) * BN * mel : nullptr, ctx->dbg_vel.as<float>(), st));
+  }
+  return F5HIP_OK;
+}
+
+int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+  for (int s = 0; s < steps; ++s) CHK(run_step(ctx, B, n, s, op, exact_attn, use_mask, traj, st));
+  return F5HIP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int f5hip_abi_version(void) { return F5HIP_ABI_VERSION; }
+
+const char* f5hip_last_error(const f5hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int device, f5hip_ctx** out) {
+  if (!dc || !out) { g_create_err = "null argument"; return F5HIP_ERR_INVALID; }
+  const auto bad = [&](const char* m) { g_create_err = m; return F5HIP_ERR_INVALID; };
+  if (dc->dim <= 0 || dc->depth <= 0 || dc->heads * dc->dim_head != dc->dim) return bad("dim must equal heads*dim_head and be > 0");
+  if (dc->dim_head != 64) return bad("dim_head must be 64 (attention kernels are built for dh=64)");
+  if (dc->dim % 4 || dc->text_dim % 4 || dc->mel_dim % 4 || dc->ff_inner % 8 || dc->dim % 8) return bad("dim/text_dim/mel_dim/ff_inner alignment");
+  if (dc->conv_pos_groups <= 0 || dc->dim % dc->conv_pos_groups) return bad("conv_pos_groups must divide dim");
+  const int cpg = dc->dim / dc->conv_pos_groups;
+  if (cpg != 16 && cpg != 32 && cpg != 64) return bad("dim/conv_pos_groups must be 16, 32 or 64");
+  if (!(dc->conv_pos_kernel & 1)) return bad("conv_pos_kernel must be odd");
+  if (dc->mel_dim > 256) return bad("mel_dim must be <= 256");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    g_create_err = "no such HIP device (libf5hip has no CPU fallback)";
+    return F5HIP_ERR_HIP;
+  }
+  if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return F5HIP_ERR_HIP; }
+  f5hip_ctx* ctx = new f5hip_ctx();
+  ctx->cfg = *dc;
+  ctx->device = device;
+  if (vc) { ctx->vcfg = *vc; ctx->has_vocos = true; }
+  build_slots(ctx);
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->blob), ctx->blob_elems * sizeof(float)) != hipSuccess) {
+    g_create_err = "hipMalloc of the weight blob failed";
+    delete ctx;
+    return F5HIP_ERR_HIP;
+  }
+  (void)hipMemset(ctx->blob, 0, ctx->blob_elems * sizeof(float));
+  *out = ctx;
+  return F5HIP_OK;
+}
+
+int f5hip_destroy(f5hip_ctx* ctx) {
+  if (!ctx) return F5HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+  if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+  DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
+                    &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_lo, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
+                    &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
+                    &ctx->mods, &ctx->fmods, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
+                    &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
+                    &ctx->a_hi, &ctx->a_lo, &ctx->o32, &ctx->o_hi, &ctx->o_lo, &ctx->f32, &ctx->f_hi, &ctx->f_lo, &ctx->q32, &ctx->k32,
+                    &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->v16, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes};
+  for (DevBuf* b : bufs) b->release();
+  if (ctx->blob) (void)hipFree(ctx->blob);
+  delete ctx;
+  return F5HIP_OK;
+}
+
+int f5hip_num_tensors(const f5hip_ctx* ctx) { return ctx ? (int)ctx->slots.size() : 0; }
+
+int f5hip_tensor_info(const f5hip_ctx* ctx, int i, const char** name, int64_t* numel, int64_t* off) {
+  if (!ctx || i < 0 || i >= (int)ctx->slots.size()) return F5HIP_ERR_INVALID;
+  if (name) *name = ctx->slots[i].name.c_str();
+  if (numel) *numel = ctx->slots[i].numel;
+  if (off) *off = ctx->slots[i].offset;
+  return F5HIP_OK;
+}
+
+int f5hip_load_tensor(f5hip_ctx* ctx, const char* name, const float* data, int64_t numel) {
+  if (!ctx || !name || !data) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->index.find(name);
+  if (it == ctx->index.end()) FAIL(F5HIP_ERR_INVALID, "unexpected tensor '%s'", name);
+  Slot& s = ctx->slots[it->second];
+  if (s.numel != numel) FAIL(F5HIP_ERR_INVALID, "tensor '%s': expected %lld elements, got %lld", name, (long long)s.numel, (long long)numel);
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy(ctx->blob + s.offset, data, numel * sizeof(float), hipMemcpyHostToDevice));
+  s.loaded = true;
+  ctx->finalized = false;
+  return F5HIP_OK;
+}
+
+int f5hip_weight_blob(f5hip_ctx* ctx, void** p, int64_t* bytes) {
+  if (!ctx || !p || !bytes) return F5HIP_ERR_INVALID;
+  *p = ctx->blob;
+  *bytes = ctx->blob_elems * (int64_t)sizeof(float);
+  return F5HIP_OK;
+}
+
+int f5hip_mark_all_loaded(f5hip_ctx* ctx) {
+  if (!ctx) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (auto& s : ctx->slots)
+    if (!s.optional) s.loaded = true;
+  ctx->finalized = false;
+  return F5HIP_OK;
+}
+
+int f5hip_finalize_weights(f5hip_ctx* ctx) {
+  if (!ctx) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(hipSetDevice(ctx->device));
+  return finalize_impl(ctx);
+}
+
+int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const std::string k = key;
+  if (k == "use_graph") ctx->use_graph = value != 0;
+  else if (k == "profile") ctx->profile = value != 0;
+  else if (k == "attn_impl") ctx->attn_impl = (int)value;
+  else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
+  return F5HIP_OK;
+}
+
+int f5hip_num_kernel_stats(const f5hip_ctx*) { return KC_COUNT; }
+int f5hip_kernel_stat(const f5hip_ctx* ctx, int i, const char** name, int64_t* calls, double* ms, double* flops, double* bytes) {
+  if (!ctx || i < 0 || i >= KC_COUNT) return F5HIP_ERR_INVALID;
+  if (name) *name = kclass_name(i);
+  if (calls) *calls = ctx->stats[i].calls;
+  if (ms) *ms = ctx->stats[i].ms;
+  if (flops) *flops = ctx->stats[i].flops;
+  if (bytes) *bytes = ctx->stats[i].bytes;
+  return F5HIP_OK;
+}
+int f5hip_reset_kernel_stats(f5hip_ctx* ctx) {
+  if (!ctx) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (auto& s : ctx->stats) s = KStat{};
+  return F5HIP_OK;
+}
+
+// ---- mel -----------------------------------------------------------------------------------------
+int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float* out, int frame_major, void* stream) {
+  if (!ctx || !wav || !out || batch <= 0) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
+  if (nsamp < 513) FAIL(F5HIP_ERR_INVALID, "reflect padding needs more than n_fft/2 samples (got %lld)", (long long)nsamp);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int frames = 1 + (int)(nsamp / 256);
+  {
+    Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
+    HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->melfb.as<float>(), ctx->cfg.mel_dim,
+                      frame_major, out, st));
+  }
+  collect_prof(ctx, st);
+  return F5HIP_OK;
+}
+
+// ---- sampler -------------------------------------------------------------------------------------
+int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t* cond_mask, const int64_t* text, int nt,
+                 const int64_t* duration, int use_mask, const float* y0, const float* t, int steps, float cfg_strength, int precision,
+                 float* out, float* trajectory, void* stream) {
+  if (!ctx) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
+  if (!cond || !cond_mask || !text || !duration || !y0 || !t || !out) FAIL(F5HIP_ERR_INVALID, "null argument");
+  if (B <= 0 || n <= 0 || steps <= 0 || nt <= 0) FAIL(F5HIP_ERR_INVALID, "batch, n, nt and steps must be positive");
+  if (n > 8192 && ctx->cfg.conv_layers > 0) FAIL(F5HIP_ERR_INVALID, "n=%d exceeds the 8192-frame text position table (dit.py:47)", n);
+  if (cfg_strength < 1e-5f) FAIL(F5HIP_ERR_UNSUPPORTED, "cfg_strength < 1e-5 (single-branch forward) is not built");
+  if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
+  for (int b = 0; b < B; ++b)
+    if (duration[b] <= 0 || duration[b] > n) FAIL(F5HIP_ERR_INVALID, "duration[%d]=%lld outside (0, n=%d]", b, (long long)duration[b], n);
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const auto& c = ctx->cfg;
+  const int op = op_of(precision);
+  const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
+  if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
+  const int mel = c.mel_dim, D = c.dim;
+  const int64_t BN = (int64_t)B * n;
+
+  CHK(ensure_workspace(ctx, B, n, op, exact_attn));
+  CHK(prepare_time(ctx, t, steps, cfg_strength, st));
+
+  // masks (cfm.py:128-158)
+  {
+    std::vector<uint8_t> rv(2 * BN);
+    std::vector<int32_t> kv(2 * B);
+    for (int b = 0; b < B; ++b) {
+      for (int pos = 0; pos < n; ++pos) rv[(int64_t)b * n + pos] = rv[BN + (int64_t)b * n + pos] = pos < duration[b] ? 1 : 0;
+      kv[b] = kv[B + b] = (int32_t)duration[b];
+    }
+    HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv.data(), 2 * BN, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->kvlen.p, kv.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->condmask.p, cond_mask, BN, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
+    HIPCHK(launch_mask_select(cond, ctx->condmask.as<uint8_t>(), BN, mel, ctx->step_cond.as<float>(), st));  // cfm.py:151-153
+    HIPCHK(hipMemcpyAsync(ctx->y.p, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (trajectory) HIPCHK(hipMemcpyAsync(trajectory, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(launch_rope_table(ctx->inv_freq.as<float>(), n, c.dim_head / 2, ctx->rope.as<float>(), st));
+  }
+  CHK(run_text_embed(ctx, B, n, text, nt, duration, use_mask, st));
+  {  // step-invariant part of InputEmbedding.proj: W_c.cond + W_t.text + b  (cond branch), W_t.text_uncond + b (uncond, cond=0)
+    Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
+    const float* Wp = W(ctx, "transformer.input_embed.proj.weight");
+    const float* bp = W(ctx, "transformer.input_embed.proj.bias");
+    const int ldw = 2 * mel + c.text_dim;
+    float* cc = ctx->cconst.as<float>();
+    GemmCore g = core(ctx->step_cond.p, mel, Wp + mel, ldw, (int)BN, D, mel);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(cc, D, bp), 1, st));
+    g = core(ctx->tx.p, c.text_dim, Wp + 2 * mel, ldw, (int)BN, D, c.text_dim);
+    EpiStore e = epi_store(cc, D, nullptr);
+    e.res = cc; e.ldres = D;
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+    g = core(ctx->tx.as<float>() + BN * c.text_dim, c.text_dim, Wp + 2 * mel, ldw, (int)BN, D, c.text_dim);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(cc + BN * D, D, bp), 1, st));
+  }
+
+  // ---- the NFE loop: eager, or one hipGraph replay ------------------------------------------------
+  bool done = false;
+  if (ctx->use_graph && !ctx->profile) {
+    auto& k = ctx->graph_key;
+    const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
+                     k.traj == trajectory && k.ws_epoch == ctx->ws_epoch;
+    if (!hit) {
+      if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+      if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
+      int r = enqueue_steps(ctx, B, n, steps, op, exact_attn, use_mask, trajectory, ctx->cap_stream);
+      hipError_t ce = hipStreamEndCapture(ctx->cap_stream, &graph);
+      if (r != F5HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
+      HIPCHK(ce);
+      HIPCHK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.traj = trajectory; k.ws_epoch = ctx->ws_epoch;
+    }
+    HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
+    done = true;
+  }
+  if (!done) CHK(enqueue_steps(ctx, B, n, steps, op, exact_attn, use_mask, trajectory, st));
+
+  {  // out = where(cond_mask, cond, y_final) (cfm.py:221-223)
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
+    HIPCHK(launch_where_rows(ctx->condmask.as<uint8_t>(), cond, ctx->y.as<float>(), BN, mel, out, st));
+  }
+  ctx->last_B = B;
+  ctx->last_n = n;
+  collect_prof(ctx, st);
+  return F5HIP_OK;
+}
+
+int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, void* stream) {
+  if (!ctx || !dst) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const auto& c = ctx->cfg;
+  const int64_t BN = (int64_t)ctx->last_B * ctx->last_n;
+  if (BN == 0) FAIL(F5HIP_ERR_STATE, "no sample call yet");
+  const float* src = nullptr;
+  int64_t want = 0;
+  switch (which) {
+    case 0: src = ctx->tx.as<float>(); want = BN * c.text_dim; break;
+    case 1: src = ctx->tx.as<float>() + BN * c.text_dim; want = BN * c.text_dim; break;
+    case 2: src = ctx->dbg_vel.as<float>(); want = BN * c.mel_dim; break;
+    case 3: src = ctx->h.as<float>(); want = 2 * BN * c.dim; break;
+    default: FAIL(F5HIP_ERR_INVALID, "unknown debug tensor %d", which);
+  }
+  if (numel != want) FAIL(F5HIP_ERR_INVALID, "debug tensor %d has %lld elements, caller asked for %lld", which, (long long)want, (long long)numel);
+  HIPCHK(hipMemcpyAsync(dst, src, want * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return F5HIP_OK;
+}
+
+// ---- vocoder -------------------------------------------------------------------------------------
+int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int channel_major, float* out, void* stream) {
+  if (!ctx || !melp || !out) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->has_vocos) FAIL(F5HIP_ERR_STATE, "context was created without a vocoder config");
+  if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
+  if (B <= 0 || T < 2) FAIL(F5HIP_ERR_INVALID, "vocos decode needs batch > 0 and frames >= 2");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const auto& v = ctx->vcfg;
+  const int C = v.dim, I = v.intermediate_dim, Cin = v.input_channels;
+  const int64_t R = (int64_t)B * T;
+  const int kcol = Cin * 7, ldc = (kcol + 3) & ~3;
+  const int nout = v.n_fft + 2, npad = (nout + 3) & ~3;
+  HIPCHK(ctx->vcol.ensure((size_t)R * ldc * 4));
+  HIPCHK(ctx->vx.ensure((size_t)R * C * 4));
+  HIPCHK(ctx->va.ensure((size_t)R * C * 4));
+  HIPCHK(ctx->vh.ensure((size_t)R * I * 4));
+  HIPCHK(ctx->vlogits.ensure((size_t)R * npad * 4));
+  HIPCHK(ctx->vframes.ensure((size_t)R * v.n_fft * 4));
+  float* vx = ctx->vx.as<float>();
+  {  // embed Conv1d(100 -> C, k=7, pad 3) as im2col + GEMM, then LayerNorm
+    Prof pr(ctx, st, KC_VOCOS_OTHER, 0, 0);
+    HIPCHK(launch_im2col7(melp, B, T, Cin, channel_major, ctx->vcol.as<float>(), ldc, st));
+  }
+  {
+    Prof pr(ctx, st, KC_VOCOS_GEMM, gemm_flops(R, C, kcol), 0);
+    GemmCore g = core(ctx->vcol.p, ldc, W(ctx, "backbone.embed.weight"), kcol, (int)R, C, kcol);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(vx, C, W(ctx, "backbone.embed.bias")), 1, st));
+  }
+  {
+    Prof pr(ctx, st, KC_VOCOS_OTHER, 0, 0);
+    HIPCHK(launch_layernorm(vx, C, (int)R, C, 1e-6f, W(ctx, "backbone.norm.weight"), W(ctx, "backbone.norm.bias"), nullptr, nullptr, vx, nullptr,
+                            nullptr, C, st));
+  }
+  for (int i = 0; i < v.num_layers; ++i) {
+    const VocosLayerW& l = ctx->vlayers[i];
+    {
+      Prof pr(ctx, st, KC_VOCOS_OTHER, 0, 2.0 * R * C * 4);
+      HIPCHK(launch_dwconv7_ln(vx, B, T, C, l.dw7, l.dw_b, l.ln_w, l.ln_b, 1e-6f, ctx->va.as<float>(), st));
+    }
+    Prof pr(ctx, st, KC_VOCOS_GEMM, 2 * gemm_flops(R, I, C), 0);
+    GemmCore g = core(ctx->va.p, C, l.pw1_w, C, (int)R, I, C);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->vh.as<float>(), I, l.pw1_b, ACT_GELU_ERF), 1, st));
+    g = core(ctx->vh.p, I, l.pw2_w, I, (int)R, C, I);
+    EpiStore e = epi_store(vx, C, l.pw2_b);
+    e.colscale = l.gamma; e.res = vx; e.ldres = C;
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  {
+    Prof pr(ctx, st, KC_VOCOS_OTHER, 0, 0);
+    HIPCHK(launch_layernorm(vx, C, (int)R, C, 1e-6f, W(ctx, "backbone.final_layer_norm.weight"), W(ctx, "backbone.final_layer_norm.bias"), nullptr,
+                            nullptr, ctx->va.as<float>(), nullptr, nullptr, C, st));
+  }
+  {
+    Prof pr(ctx, st, KC_VOCOS_GEMM, gemm_flops(R, nout, C), 0);
+    GemmCore g = core(ctx->va.p, C, ctx->vhead_w.p, C, (int)R, npad, C);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->vlogits.as<float>(), npad, ctx->vhead_b.as<float>()), 1, st));
+  }
+  {
+    Prof pr(ctx, st, KC_ISTFT, 0, (double)R * npad * 4 + 2.0 * R * v.n_fft * 4 + (double)B * 256.0 * (T - 1) * 4);
+    HIPCHK(launch_istft_frames(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
+    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
+  }
+  collect_prof(ctx, st);
+  return F5HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// convpos.hip — ConvPositionEmbedding's grouped Conv1d(dim, dim, k=31, groups=16) as an implicit GEMM
+// on MFMA (reference model/modules.py:175-201).  One block = (sequence, group, 128 frames):
+//   out[m, co] = mish( mask( bias[co] + sum_{tap, ci} x[m + tap - K/2, ci] * W[co, ci, tap] ) ) (+ residual)
+// The haloed input tile (128 + K - 1 frames x cpg channels) is staged ONCE in LDS (converted to the
+// operand type on the way); the 31 shifted GEMMs of depth cpg read it at a row offset of `tap`, while
+// the per-tap weight tile [cpg(co)][cpg(ci)] streams through a double-buffered LDS slot.
+// The weight axis is the MFMA "A" operand (accumulator rows) exactly as in gemm.h.
+#include "kernels.h"
+
+namespace {
+
+template <typename T, int NPL, int CPG>
+struct ConvCfg {
+  static constexpr int BMR = 128;                                // frames per block
+  static constexpr int COT = (CPG + 31) / 32;                    // 32-row co tiles
+  static constexpr int ROWB = CPG * (int)sizeof(T) + 16;         // LDS row bytes (padded)
+  static constexpr int KSTEPS = CPG * (int)sizeof(T) / 32;       // 32-byte k-steps per tap
+  static constexpr int WROWS = COT * 32;
+  static constexpr int WPLANE = WROWS * ROWB;
+  static constexpr int WSTAGE = NPL * WPLANE;
+};
+
+template <typename T, int NPL, int CPG>
+__global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ x, const T* __restrict__ w, const T* __restrict__ w_lo,
+                                                      const float* __restrict__ bias, const uint8_t* __restrict__ rowvalid,
+                                                      const float* __restrict__ residual, int n, int D, int K, float* out) {
+  using C = ConvCfg<T, NPL, CPG>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * C::BMR, g = blockIdx.y, s = blockIdx.z;
+  const int halo = K / 2;
+  const int xrows = C::BMR + K - 1;
+  const int xplane = xrows * C::ROWB;
+  char* sX = smem;                       // [NPL][xrows][ROWB]
+  char* sW = smem + NPL * xplane;        // [2 stages][NPL][WROWS][ROWB]
+
+  // ---- stage the haloed input tile (fp32 -> T [hi, lo]) -------------------------------------
+  constexpr int C4 = CPG / 4;  // float4 chunks per row
+  for (int c = tid; c < xrows * C4; c += 256) {
+    const int r = c / C4, c4 = c - r * C4;
+    const int pos = m0 + r - halo;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos >= 0 && pos < n) {
+      const int64_t grow = (int64_t)s * n + pos;
+      if (!rowvalid || rowvalid[grow]) v = *reinterpret_cast<const float4*>(x + grow * D + g * CPG + c4 * 4);
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(sX + r * C::ROWB + c4 * 16) = v;
+    } else {
+      f16x4 hi, lo;
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(xv[e], h, l); hi[e] = h; lo[e] = l; }
+      *reinterpret_cast<f16x4*>(sX + r * C::ROWB + c4 * 8) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<f16x4*>(sX + xplane + r * C::ROWB + c4 * 8) = lo;
+    }
+  }
+  // zero the co-padding rows of both weight stages once (CPG < 32 only)
+  if constexpr (C::WROWS > CPG) {
+    for (int c = tid; c < 2 * C::WSTAGE / 16; c += 256) *reinterpret_cast<uint4*>(sW + c * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+  }
+
+  // ---- weight tile streaming -------------------------------------------------------------------
+  constexpr int WCH = CPG * CPG * (int)sizeof(T) / 16;    // 16-byte chunks per tap tile
+  constexpr int CPR = CPG * (int)sizeof(T) / 16;          // chunks per row
+  constexpr int WPT = (WCH + 255) / 256;
+  uint4 rw[NPL][WPT];
+  const int64_t wtile = (int64_t)CPG * CPG;
+  auto load_w = [&](int tap) {
+    const T* src = w + ((int64_t)g * K + tap) * wtile;
+    const T* src_lo = NPL == 2 ? w_lo + ((int64_t)g * K + tap) * wtile : nullptr;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = tid + i * 256;
+      if (c < WCH) {
+        rw[0][i] = reinterpret_cast<const uint4*>(src)[c];
+        if constexpr (NPL == 2) rw[1][i] = reinterpret_cast<const uint4*>(src_lo)[c];
+      }
+    }
+  };
+  auto store_w = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = tid + i * 256;
+      if (c < WCH) {
+        const int r = c / CPR, cc = c - r * CPR;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          *reinterpret_cast<uint4*>(sW + stage * C::WSTAGE + p * C::WPLANE + r * C::ROWB + cc * 16) = rw[p][i];
+      }
+    }
+  };
+
+  f32x16 acc[C::COT];
+#pragma unroll
+  for (int i = 0; i < C::COT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+
+  const int koff = (lane >> 5) * 16;
+  for (int tap = 0; tap < K; ++tap) {
+    if (tap + 1 < K) load_w(tap + 1);
+    const char* wbase = sW + (tap & 1) * C::WSTAGE + (lane & 31) * C::ROWB + koff;
+    const char* xbase = sX + (wave * 32 + (lane & 31) + tap) * C::ROWB + koff;
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      Frag fx[NPL], fw[NPL][C::COT];
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        fx[p].u = *reinterpret_cast<const uint4*>(xbase + p * xplane + ks * 32);
+#pragma unroll
+        for (int i = 0; i < C::COT; ++i)
+          fw[p][i].u = *reinterpret_cast<const uint4*>(wbase + p * C::WPLANE + i * 32 * C::ROWB + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < C::COT; ++i) {
+        Mma32<T>::mma(acc[i], fw[0][i], fx[0]);
+        if constexpr (NPL == 2) {
+          Mma32<T>::mma(acc[i], fw[0][i], fx[1]);
+          Mma32<T>::mma(acc[i], fw[1][i], fx[0]);
+        }
+      }
+    }
+    if (tap + 1 < K) store_w((tap + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+  const int m = m0 + wave * 32 + (lane & 31);
+  if (m >= n) return;
+  const int64_t grow = (int64_t)s * n + m;
+  const bool dead = rowvalid && !rowvalid[grow];
+#pragma unroll
+  for (int i = 0; i < C::COT; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = i * 32 + 8 * q + 4 * (lane >> 5);
+      if (co >= CPG) continue;
+      const int ch = g * CPG + co;
+      const float4 b = *reinterpret_cast<const float4*>(bias + ch);
+      float v[4] = {acc[i][4 * q] + b.x, acc[i][4 * q + 1] + b.y, acc[i][4 * q + 2] + b.z, acc[i][4 * q + 3] + b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = dead ? 0.f : act_mish(v[e]);
+      if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + grow * D + ch);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      *reinterpret_cast<float4*>(out + grow * D + ch) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <typename T, int NPL, int CPG>
+hipError_t launch_cfg(const float* x, const T* w, const T* w_lo, const float* bias, const uint8_t* rowvalid, const float* residual,
+                      int S, int n, int D, int groups, int K, float* out, hipStream_t s) {
+  using C = ConvCfg<T, NPL, CPG>;
+  const int lds = NPL * (C::BMR + K - 1) * C::ROWB + 2 * C::WSTAGE;
+  auto kern = convpos_kernel<T, NPL, CPG>;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  dim3 grid((n + C::BMR - 1) / C::BMR, groups, S);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, w, w_lo, bias, rowvalid, residual, n, D, K, out);
+  return hipGetLastError();
+}
+
+template <int CPG>
+hipError_t launch_cpg(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
+                      const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out, hipStream_t s) {
+  switch (op) {
+    case OP_F32: return launch_cfg<float, 1, CPG>(x, w32, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case OP_F16: return launch_cfg<f16, 1, CPG>(x, whi, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case OP_F16X3: return launch_cfg<f16, 2, CPG>(x, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
+                          const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out,
+                          hipStream_t s) {
+  const int cpg = D / groups;
+  if (cpg * groups != D || (K & 1) == 0) return hipErrorInvalidValue;
+  switch (cpg) {
+    case 16: return launch_cpg<16>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case 32: return launch_cpg<32>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case 64: return launch_cpg<64>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+namespace {
+template <int CPG>
+hipError_t set_attrs_cpg() {
+  hipError_t e;
+  const int lim = 160 * 1024;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_kernel<float, 1, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_kernel<f16, 1, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(convpos_kernel<f16, 2, CPG>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
+  return hipSuccess;
+}
+}  // namespace
+hipError_t init_convpos_kernels() {
+  hipError_t e;
+  if ((e = set_attrs_cpg<16>()) != hipSuccess) return e;
+  if ((e = set_attrs_cpg<32>()) != hipSuccess) return e;
+  return set_attrs_cpg<64>();
+}

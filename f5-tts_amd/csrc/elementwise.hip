@@ -1,0 +1,437 @@
+// elementwise.hip — HBM-bound kernels of the hot path: LayerNorm/AdaLN-modulate, token embedding,
+// depthwise conv + LN, GRN, masks, CFG+Euler update, tables and one-time weight repacking.
+// All are one-wave-per-row or grid-stride kernels with 16-byte accesses along the channel axis.
+#include "kernels.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm (+ affine | AdaLN modulation).  One wave per row; the row lives in registers.
+// ---------------------------------------------------------------------------------------------
+template <int VPL>  // float4 vectors per lane: D <= 64*4*VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
+                                                         const float* __restrict__ weight, const float* __restrict__ bias,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* out32, f16* out16, f16* out16_lo, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float4 v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= D) continue;
+    float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+    if (weight) {
+      const float4 w = *reinterpret_cast<const float4*>(weight + c);
+      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      y[0] = y[0] * w.x + b.x; y[1] = y[1] * w.y + b.y; y[2] = y[2] * w.z + b.z; y[3] = y[3] * w.w + b.w;
+    }
+    if (scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      y[0] = y[0] * (1.0f + sc.x) + sh.x; y[1] = y[1] * (1.0f + sc.y) + sh.y;
+      y[2] = y[2] * (1.0f + sc.z) + sh.z; y[3] = y[3] * (1.0f + sc.w) + sh.w;
+    }
+    const int64_t o = (int64_t)row * ldo + c;
+    if (out32) *reinterpret_cast<float4*>(out32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+    if (out16) {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(y[e], h, l); hi[e] = h; lo[e] = l; }
+      *reinterpret_cast<f16x4*>(out16 + o) = hi;
+      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o) = lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// text embedding (reference model/backbones/dit.py:86-127)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tok, const uint8_t* __restrict__ valid,
+                                                          const float* __restrict__ table, const float* __restrict__ freqs,
+                                                          int B, int n, int T, int mask_padding, int has_pos, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);  // over 2B*n
+  if (row >= (int64_t)2 * B * n) return;
+  const int s = (int)(row / n), pos = (int)(row - (int64_t)s * n);
+  const int b = s % B;
+  const bool uncond = s >= B;
+  const int id = tok[(int64_t)b * n + pos];
+  const bool ok = valid[(int64_t)b * n + pos] != 0;
+  const bool filler = mask_padding && id == 0;  // text_mask is computed BEFORE drop_text zeroes the ids (dit.py:103-107)
+  const float* e = table + (int64_t)(uncond ? 0 : id) * T;
+  const float* f = freqs + (int64_t)pos * T;
+  float* o = out + row * T;
+  for (int c = lane * 4; c < T; c += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && !(filler && has_pos)) {
+      v = *reinterpret_cast<const float4*>(e + c);
+      if (has_pos) {
+        const float4 p = *reinterpret_cast<const float4*>(f + c);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      }
+    }
+    *reinterpret_cast<float4*>(o + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise conv k=7 + bias + LayerNorm(affine).  One wave per (sequence, frame) row.
+// ---------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, int S, int n, int C,
+                                                          const float* __restrict__ w7, const float* __restrict__ cbias,
+                                                          const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                                                          float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= (int64_t)S * n) return;
+  const int pos = (int)(row % n);
+  float4 v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      float4 acc = *reinterpret_cast<const float4*>(cbias + c);
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int p = pos + t - 3;
+        if (p >= 0 && p < n) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + (row + (t - 3)) * C + c);
+          const float4 wv = *reinterpret_cast<const float4*>(w7 + (int64_t)t * C + c);
+          acc.x += xv.x * wv.x; acc.y += xv.y * wv.y; acc.z += xv.z * wv.z; acc.w += xv.w * wv.w;
+        }
+      }
+      v[i] = acc;
+      sum += (acc.x + acc.y) + (acc.z + acc.w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= C) continue;
+    const float4 w = *reinterpret_cast<const float4*>(ln_w + c);
+    const float4 b = *reinterpret_cast<const float4*>(ln_b + c);
+    *reinterpret_cast<float4*>(out + row * C + c) =
+        make_float4((v[i].x - mean) * rstd * w.x + b.x, (v[i].y - mean) * rstd * w.y + b.y, (v[i].z - mean) * rstd * w.z + b.z,
+                    (v[i].w - mean) * rstd * w.w + b.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRN
+// ---------------------------------------------------------------------------------------------
+// grid (C/64, S): block of 256 = 4 row-phases x 64 channels
+__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ h, int n, int C, float* sumsq) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ph = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  float acc = 0.f;
+  if (c < C) {
+    const float* p = h + (int64_t)s * n * C + c;
+    for (int r = ph; r < n; r += 4) {
+      const float v = p[(int64_t)r * C];
+      acc += v * v;
+    }
+  }
+  red[ph][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (ph == 0 && c < C) sumsq[(int64_t)s * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one wave per row; every wave first reduces mean_c(sqrt(sumsq[s,:])) (C floats, L2-resident)
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ h, const float* __restrict__ sumsq,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int S, int n,
+                                                         int C, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= (int64_t)S * n) return;
+  const int s = (int)(row / n);
+  const float* ss = sumsq + (int64_t)s * C;
+  float part = 0.f;
+  for (int c = lane; c < C; c += 64) part += sqrtf(ss[c]);
+  const float denom = wave_sum(part) / (float)C + 1e-6f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 hv = *reinterpret_cast<const float4*>(h + row * C + c);
+    const float4 sv = *reinterpret_cast<const float4*>(ss + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = g.x * (hv.x * (sqrtf(sv.x) / denom)) + b.x + hv.x;
+    o.y = g.y * (hv.y * (sqrtf(sv.y) / denom)) + b.y + hv.y;
+    o.z = g.z * (hv.z * (sqrtf(sv.z) / denom)) + b.z + hv.z;
+    o.w = g.w * (hv.w * (sqrtf(sv.w) / denom)) + b.w + hv.w;
+    *reinterpret_cast<float4*>(out + row * C + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// masks / selects  (C % 4 == 0)
+// ---------------------------------------------------------------------------------------------
+__global__ void zero_rows_kernel(float* x, const uint8_t* mask, int64_t rows, int C4) {
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (mask[i / C4]) reinterpret_cast<float4*>(x)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__global__ void where_rows_kernel(const uint8_t* mask, const float* a, const float* b, int64_t rows, int C4, float* out) {
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool m = mask[i / C4] != 0;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m) v = reinterpret_cast<const float4*>(a)[i];
+    else if (b) v = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// v [2*half]: first half cond prediction, second half uncond.  (reference cfm.py:190-191; euler step)
+__global__ void cfg_euler_kernel(float* y, const float* __restrict__ v, int64_t half4, const float* dt_ptr, const float* cfg_ptr,
+                                 float* traj_next, float* vel_dbg) {
+  const float dt = *dt_ptr, cfg = *cfg_ptr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 c = reinterpret_cast<const float4*>(v)[i];
+    const float4 u = reinterpret_cast<const float4*>(v)[half4 + i];
+    float4 yy = reinterpret_cast<float4*>(y)[i];
+    float4 g;
+    g.x = c.x + (c.x - u.x) * cfg; g.y = c.y + (c.y - u.y) * cfg; g.z = c.z + (c.z - u.z) * cfg; g.w = c.w + (c.w - u.w) * cfg;
+    yy.x += dt * g.x; yy.y += dt * g.y; yy.z += dt * g.z; yy.w += dt * g.w;
+    reinterpret_cast<float4*>(y)[i] = yy;
+    if (traj_next) reinterpret_cast<float4*>(traj_next)[i] = yy;
+    if (vel_dbg) reinterpret_cast<float4*>(vel_dbg)[i] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------------------------
+// reference model/modules.py:157-169: emb = 1000 * t * exp(-k * ln(1e4)/(half-1)); cat(sin, cos)
+__global__ void time_sinus_kernel(const float* t, int S, int dim, float* out) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * half) return;
+  const int s = i / half, k = i - s * half;
+  const float e = logf(10000.0f) / (float)(half - 1);
+  const float f = expf((float)k * -e);
+  const float a = 1000.0f * t[s] * f;
+  out[(int64_t)s * dim + k] = sinf(a);
+  out[(int64_t)s * dim + half + k] = cosf(a);
+}
+__global__ void rope_table_kernel(const float* inv_freq, int n, int half, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half) return;
+  const int pos = i / half, k = i - pos * half;
+  const float a = (float)pos * inv_freq[k];
+  out[2 * (int64_t)i] = cosf(a);
+  out[2 * (int64_t)i + 1] = sinf(a);
+}
+__global__ void split_f16_kernel(const float* src, int64_t n, float prescale, f16* hi, f16* lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    f16 h, l;
+    split_f16(src[i] * prescale, h, l);
+    hi[i] = h;
+    if (lo) lo[i] = l;
+  }
+}
+// w [D, cpg, K] (out-channel, in-channel-in-group, tap) -> [G][K][co][ci]
+__global__ void convpos_pack_kernel(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo) {
+  const int64_t total = (int64_t)D * cpg * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cpg);
+    const int co = (int)((i / cpg) % cpg);
+    const int t = (int)((i / ((int64_t)cpg * cpg)) % K);
+    const int g = (int)(i / ((int64_t)cpg * cpg * K));
+    const float v = w[((int64_t)(g * cpg + co) * cpg + ci) * K + t];
+    w32[i] = v;
+    f16 h, l;
+    split_f16(v, h, l);
+    whi[i] = h;
+    wlo[i] = l;
+  }
+}
+__global__ void dw_pack_kernel(const float* w, int C, float* w7) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 7 * C) return;
+  const int t = i / C, c = i - t * C;
+  w7[i] = w[c * 7 + t];
+}
+
+// exact attention: softmax over the first kv columns of each score row, zero the rest (incl. padding to ld)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, int64_t rows, int ld, int nseq, int heads,
+                                                            const int32_t* kvlen, int kv_default) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int bp = (int)(row / ((int64_t)heads * nseq));
+  const int kv = kvlen ? kvlen[bp] : kv_default;
+  float* p = S + row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < kv; c += 64) mx = fmaxf(mx, p[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < kv; c += 64) {
+    const float e = expf(p[c] - mx);
+    p[c] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int c = lane; c < ld; c += 64) p[c] = c < kv ? p[c] * inv : 0.f;
+}
+
+// mel [B, T, Cin] (or [B, Cin, T]) -> col [B*T, ldc], k = ci*7 + tap (matches weight [Cout, Cin, 7] flattened)
+__global__ void im2col7_kernel(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc) {
+  const int64_t total = (int64_t)B * T * ldc;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ldc);
+    const int64_t row = i / ldc;
+    float v = 0.f;
+    if (k < Cin * 7) {
+      const int ci = k / 7, tap = k - ci * 7;
+      const int b = (int)(row / T), pos = (int)(row - (int64_t)b * T) + tap - 3;
+      if (pos >= 0 && pos < T) v = channel_major ? mel[((int64_t)b * Cin + ci) * T + pos] : mel[((int64_t)b * T + pos) * Cin + ci];
+    }
+    col[i] = v;
+  }
+}
+
+inline int grid_1d(int64_t total, int block = 256, int cap = 8192) {
+  int64_t g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
+                            const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
+                            hipStream_t s) {
+  if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
+  dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
+  return hipGetLastError();
+}
+
+hipError_t launch_text_embed(const int32_t* tok, const uint8_t* valid, const float* table, const float* freqs_cis, int B, int n,
+                             int T, int mask_padding, int has_pos, float* out, hipStream_t s) {
+  if (T % 4) return hipErrorInvalidValue;
+  const int64_t rows = (int64_t)2 * B * n;
+  hipLaunchKernelGGL(text_embed_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, tok, valid, table, freqs_cis, B, n, T,
+                     mask_padding, has_pos, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w7, const float* cbias, const float* ln_w,
+                             const float* ln_b, float eps, float* out, hipStream_t s) {
+  if (C % 4 || C > 2048) return hipErrorInvalidValue;
+  const int64_t rows = (int64_t)S * n;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (C <= 256) hipLaunchKernelGGL(dwconv7_ln_kernel<1>, grid, dim3(256), 0, s, x, S, n, C, w7, cbias, ln_w, ln_b, eps, out);
+  else if (C <= 512) hipLaunchKernelGGL(dwconv7_ln_kernel<2>, grid, dim3(256), 0, s, x, S, n, C, w7, cbias, ln_w, ln_b, eps, out);
+  else if (C <= 1024) hipLaunchKernelGGL(dwconv7_ln_kernel<4>, grid, dim3(256), 0, s, x, S, n, C, w7, cbias, ln_w, ln_b, eps, out);
+  else hipLaunchKernelGGL(dwconv7_ln_kernel<8>, grid, dim3(256), 0, s, x, S, n, C, w7, cbias, ln_w, ln_b, eps, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, hipStream_t s) {
+  hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S), dim3(256), 0, s, h, n, C, sumsq);
+  return hipGetLastError();
+}
+hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,
+                            float* out, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const int64_t rows = (int64_t)S * n;
+  hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, h, sumsq, gamma, beta, S, n, C, out);
+  return hipGetLastError();
+}
+hipError_t launch_zero_rows(float* x, const uint8_t* mask, int64_t rows, int C, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_1d(rows * (C / 4))), dim3(256), 0, s, x, mask, rows, C / 4);
+  return hipGetLastError();
+}
+hipError_t launch_mask_select(const float* a, const uint8_t* mask, int64_t rows, int C, float* out, hipStream_t s) {
+  return launch_where_rows(mask, a, nullptr, rows, C, out, s);
+}
+hipError_t launch_where_rows(const uint8_t* mask, const float* a, const float* b, int64_t rows, int C, float* out, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(where_rows_kernel, dim3(grid_1d(rows * (C / 4))), dim3(256), 0, s, mask, a, b, rows, C / 4, out);
+  return hipGetLastError();
+}
+hipError_t launch_cfg_euler(float* y, const float* v, int64_t half_elems, const float* dt_ptr, const float* cfg_ptr, float* traj_next,
+                            float* vel_dbg, hipStream_t s) {
+  if (half_elems % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_1d(half_elems / 4)), dim3(256), 0, s, y, v, half_elems / 4, dt_ptr, cfg_ptr, traj_next,
+                     vel_dbg);
+  return hipGetLastError();
+}
+hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(time_sinus_kernel, dim3(grid_1d((int64_t)S * dim / 2)), dim3(256), 0, s, t, S, dim, out);
+  return hipGetLastError();
+}
+hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(rope_table_kernel, dim3(grid_1d((int64_t)n * half)), dim3(256), 0, s, inv_freq, n, half, out);
+  return hipGetLastError();
+}
+hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s) {
+  hipLaunchKernelGGL(split_f16_kernel, dim3(grid_1d(n)), dim3(256), 0, s, src, n, prescale, hi, lo);
+  return hipGetLastError();
+}
+hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo, hipStream_t s) {
+  hipLaunchKernelGGL(convpos_pack_kernel, dim3(grid_1d((int64_t)D * cpg * K)), dim3(256), 0, s, w, D, cpg, K, w32, whi, wlo);
+  return hipGetLastError();
+}
+hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s) {
+  hipLaunchKernelGGL(dw_pack_kernel, dim3(grid_1d(7 * C)), dim3(256), 0, s, w, C, w7);
+  return hipGetLastError();
+}
+hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, rows, ld, nseq, heads, kvlen_per_batch,
+                     kv_default);
+  return hipGetLastError();
+}
+hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s) {
+  hipLaunchKernelGGL(im2col7_kernel, dim3(grid_1d((int64_t)B * T * ldc)), dim3(256), 0, s, mel, B, T, Cin, channel_major, col, ldc);
+  return hipGetLastError();
+}

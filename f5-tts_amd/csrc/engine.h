@@ -1,0 +1,154 @@
+// engine.h — host-side state of libf5hip: context, packed weight blob, derived layouts, workspace.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/f5hip.h"
+#include "kernels.h"
+
+struct Slot {
+  std::string name;
+  int64_t numel = 0;
+  int64_t offset = 0;  // in floats, into the blob
+  bool loaded = false;
+  bool optional = false;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  // grow-only; returns true when the pointer changed (invalidates captured graphs)
+  hipError_t ensure(size_t bytes, bool* moved = nullptr, bool zero = false) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = (bytes + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    if (moved) *moved = true;
+    if (zero) return hipMemset(p, 0, want);
+    return hipSuccess;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct BlockW {  // per DiT block
+  const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // fp32 (blob)
+  f16 *wqkv_hi, *wqkv_lo, *wo_hi, *wo_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+};
+struct TextBlockW {
+  const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *gamma, *beta, *pw2_w, *pw2_b;
+  float* dw7;  // [7, T]
+};
+struct VocosLayerW {
+  const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *pw2_w, *pw2_b, *gamma;
+  float* dw7;
+};
+
+enum KClass {
+  KC_GEMM_BLOCK = 0,  // QKV / out / FF1 / FF2 of the DiT blocks (the dominant kernel)
+  KC_ATTN,
+  KC_CONVPOS,
+  KC_LNMOD,
+  KC_GEMM_MISC,
+  KC_TEXT,
+  KC_ELEMWISE,
+  KC_MEL,
+  KC_VOCOS_GEMM,
+  KC_VOCOS_OTHER,
+  KC_ISTFT,
+  KC_COUNT
+};
+
+struct KStat {
+  int64_t calls = 0;
+  double ms = 0, flops = 0, bytes = 0;
+};
+
+struct ProfRec {
+  int kclass;
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+
+struct f5hip_ctx {
+  f5hip_dit_config cfg{};
+  f5hip_vocos_config vcfg{};
+  bool has_vocos = false;
+  int device = 0;
+  std::mutex mu;
+  std::string err;
+
+  // weights
+  std::vector<Slot> slots;
+  std::unordered_map<std::string, int> index;
+  float* blob = nullptr;
+  int64_t blob_elems = 0;
+  int64_t dit_elems = 0;
+  bool finalized = false;
+
+  // derived layouts
+  DevBuf half_pool;  // all f16 hi/lo copies
+  std::vector<BlockW> blocks;
+  std::vector<TextBlockW> tblocks;
+  std::vector<VocosLayerW> vlayers;
+  DevBuf conv_w32[2], conv_whi[2], conv_wlo[2];
+  DevBuf wp_hi, wp_lo;                 // proj_out f16
+  DevBuf dwpack;                       // [7,C] depthwise weights (text + vocos)
+  DevBuf freqs_cis;                    // [8192, text_dim]
+  DevBuf inv_freq;                     // [dh/2]
+  DevBuf vhead_w, vhead_b;             // padded vocos head [1028, C], [1028]
+  DevBuf twiddle, window, melfb;       // audio tables
+  const float *adaln_w = nullptr, *adaln_b = nullptr;  // [depth*6D, D], [depth*6D]
+
+  // time-grid dependent tables (cached on the last grid)
+  std::vector<float> t_host;
+  DevBuf t_dev, dt_dev, cfg_dev, tsin, th1, tsilu, mods, fmods;
+
+  // workspace (grow-only)
+  int ws_B = 0, ws_n = 0;
+  DevBuf tok, valid, textkeep, rowvalid, condmask, kvlen;
+  DevBuf tx, ta, th, tg, sumsq;
+  DevBuf step_cond, cconst, y, h, c1, x;
+  DevBuf a32, a_hi, a_lo, o32, o_hi, o_lo, f32, f_hi, f_lo;
+  DevBuf q32, k32, vt32, scores, q16, k16, v16;
+  DevBuf vel, rope, dbg_vel;
+  // vocos workspace
+  DevBuf vcol, vx, va, vh, vlogits, vframes;
+
+  // options / measurement
+  bool use_graph = false;
+  bool profile = false;
+  int attn_impl = 0;  // 0 auto (flash for fp16 modes), 1 force exact(materialised), 2 force flash
+  KStat stats[KC_COUNT];
+  std::vector<ProfRec> prof;
+
+  // last sample (debug taps)
+  int last_B = 0, last_n = 0;
+
+  // graph cache
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    int B = 0, n = 0, steps = 0, prec = -1, use_mask = 0;
+    float* traj = nullptr;
+    uint64_t ws_epoch = 0;
+  } graph_key;
+  uint64_t ws_epoch = 0;
+  hipStream_t cap_stream = nullptr;
+};

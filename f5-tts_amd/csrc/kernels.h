@@ -1,0 +1,90 @@
+// kernels.h — host-callable launchers of every HIP kernel in libf5hip (internal; the public ABI is include/f5hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.h"
+
+enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2 };  // GEMM operand kind
+
+// ---- gemm.hip ---------------------------------------------------------------------------------
+// batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
+hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s);
+hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s);
+// one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
+hipError_t init_gemm_kernels();
+hipError_t init_convpos_kernels();
+
+// ---- elementwise.hip --------------------------------------------------------------------------
+// LayerNorm over the last dim D (D % 4 == 0, D <= 2048), eps inside sqrt.  Either affine (weight/bias) or
+// AdaLN modulation: y = ln(x) * (1 + scale) + shift.  Writes fp32 and/or f16 hi(/lo) planes.
+hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
+                            const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
+                            hipStream_t s);
+// text token embedding + absolute sinusoid position + masks (reference model/backbones/dit.py:86-127)
+//   tok [B, n] int32 (0 = filler), valid [B, n] u8 (pos < seq_len[b]); out [2B, n, T]: rows [0,B) cond, [B,2B) uncond (ids zeroed)
+hipError_t launch_text_embed(const int32_t* tok, const uint8_t* valid, const float* table, const float* freqs_cis,
+                             int B, int n, int T, int mask_padding, int has_pos, float* out, hipStream_t s);
+// depthwise conv k=7 (zero pad per sequence) + bias + LayerNorm(affine): x [S, n, C] -> out [S, n, C]
+//   w7 [7, C] (tap-major), C % 256 == 0 or C <= 2048 with C % 4 == 0
+hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w7, const float* cbias, const float* ln_w,
+                             const float* ln_b, float eps, float* out, hipStream_t s);
+// GRN (reference model/modules.py:242-245): sumsq[s, c] = sum_n h[s,n,c]^2 ; then
+//   out = gamma * (h * Gx / (mean_c(Gx) + 1e-6)) + beta + h
+hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, hipStream_t s);
+hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,
+                            float* out, hipStream_t s);
+// zero rows where mask[row] != 0 (masked_fill), x [rows, C]
+hipError_t launch_zero_rows(float* x, const uint8_t* mask, int64_t rows, int C, hipStream_t s);
+// step_cond = where(cond_mask, cond, 0)
+hipError_t launch_mask_select(const float* a, const uint8_t* mask, int64_t rows, int C, float* out, hipStream_t s);
+// out = where(mask, a, b)
+hipError_t launch_where_rows(const uint8_t* mask, const float* a, const float* b, int64_t rows, int C, float* out, hipStream_t s);
+// CFG + Euler (reference cfm.py:190-191 + torchdiffeq euler): y += dt * (vc + (vc - vu) * cfg); optional copies
+hipError_t launch_cfg_euler(float* y, const float* v, int64_t half_elems, const float* dt_ptr, const float* cfg_ptr,
+                            float* traj_next, float* vel_dbg, hipStream_t s);
+// sinusoidal time embedding (reference model/modules.py:157-169): t [S] -> out [S, 256]
+hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStream_t s);
+// rope table: out [n, dh/2, 2] = (cos, sin)(pos * inv_freq[i])
+hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out, hipStream_t s);
+// fp32 -> f16 hi/lo planes (weights, one-time), optional power-of-two prescale
+hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s);
+// conv_pos weights [D, cpg, K] -> per-tap operand layout [G][K][cpg(co)][cpg(ci)] (fp32 + f16 hi/lo)
+hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo, hipStream_t s);
+// [C, 1, 7] depthwise weights -> [7, C]
+hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s);
+// row softmax for the exact (materialised-score) attention: S [rows, ld], cols >= kvlen(row) get 0
+hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
+                               hipStream_t s);
+// im2col for the Vocos embed conv (k=7, pad 3): mel [B, T, Cin] (frame-major) -> col [B*T, 7*Cin] with k index = ci*7 + tap
+hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s);
+
+// ---- convpos.hip ------------------------------------------------------------------------------
+// grouped Conv1d(k, groups) as implicit GEMM on MFMA + bias + row mask + Mish (+ residual)
+//   x [S, n, D] fp32; w per-tap layout; out [S, n, D] fp32; rowvalid [S*n] u8 or null (reference
+//   model/modules.py:187-201: input and conv output zero-filled outside the mask)
+hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
+                          const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out,
+                          hipStream_t s);
+
+// ---- attention.hip ----------------------------------------------------------------------------
+// flash-style non-causal attention, fp16 operands / fp32 softmax+accumulate.
+//   q,k,v [BH, n, 64] f16 (q pre-scaled); o16(/lo) [B', n, H*64]; kvlen per batch' or null
+bool flash_attn_available();
+hipError_t launch_flash_attn(const f16* q, const f16* k, const f16* v, int Bp, int heads, int n, const int32_t* kvlen,
+                             f16* o16, f16* o16_lo, hipStream_t s);
+
+// ---- audio.hip --------------------------------------------------------------------------------
+struct AudioTables {
+  const float* twiddle;   // [512, 2] cos/sin(2*pi*k/1024)
+  const float* window;    // [1024] periodic hann
+  const float* melfb;     // [513, 100] HTK triangles
+  const float* env_inv;   // unused (envelope computed per call)
+};
+hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
+                      const float* melfb, int nmel, int frame_major, float* out, hipStream_t s);
+// head logits [B*T, ld] (log-mag | phase) -> windowed time frames [B, T, 1024]
+hipError_t launch_istft_frames(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window,
+                               float* frames, hipStream_t s);
+// overlap-add + envelope normalisation + centre trim: frames [B, T, 1024] -> wav [B, 256*(T-1)]
+hipError_t launch_istft_ola(const float* frames, const float* window, int B, int T, float* wav, hipStream_t s);

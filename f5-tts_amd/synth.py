@@ -1,0 +1,119 @@
+"""Seeded synthetic weights and inputs (no pretrained checkpoints are reachable offline).
+
+The state-dict keys follow the reference's on-disk contract exactly (reference
+``src/f5_tts/infer/utils_infer.py:190-232`` loads them with ``load_state_dict``), so a dict made
+here loads into the reference ``CFM`` with ``strict=True`` — the golden generator does exactly that.
+
+The reference zero-initialises AdaLN, the output projection (``model/backbones/dit.py:264-274``)
+and the GRN gamma/beta (``model/modules.py:239-240``); a fresh model therefore predicts zero
+velocity.  All those tensors get seeded NON-zero values here, otherwise parity would be vacuous.
+Everything is drawn from one CPU ``torch.Generator`` in a fixed order, so the same
+``(config, seed)`` gives bit-identical tensors on every box with the same torch build.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .config import DiTConfig, VocosConfig
+
+
+def _normal(g: torch.Generator, shape, std: float) -> torch.Tensor:
+    return torch.randn(shape, generator=g, dtype=torch.float32) * std
+
+
+def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init weights of the DiT backbone with the reference's key names (``transformer.*``)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000003 * seed + 17)
+    sd: Dict[str, torch.Tensor] = {}
+    D, T, mel = cfg.dim, cfg.text_dim, cfg.mel_dim
+    p = "transformer."
+
+    def linear(name, out_f, in_f, w_std=None, b_std=0.02):
+        sd[p + name + ".weight"] = _normal(g, (out_f, in_f), w_std if w_std is not None else 1.0 / math.sqrt(in_f))
+        sd[p + name + ".bias"] = _normal(g, (out_f,), b_std)
+
+    linear("time_embed.time_mlp.0", D, 256)
+    linear("time_embed.time_mlp.2", D, D)
+    sd[p + "text_embed.text_embed.weight"] = _normal(g, (cfg.text_num_embeds + 1, T), 1.0)
+    for i in range(cfg.conv_layers):
+        b = f"text_embed.text_blocks.{i}."
+        sd[p + b + "dwconv.weight"] = _normal(g, (T, 1, 7), 1.0 / math.sqrt(7))
+        sd[p + b + "dwconv.bias"] = _normal(g, (T,), 0.02)
+        sd[p + b + "norm.weight"] = 1.0 + _normal(g, (T,), 0.05)
+        sd[p + b + "norm.bias"] = _normal(g, (T,), 0.05)
+        linear(b + "pwconv1", 2 * T, T)
+        sd[p + b + "grn.gamma"] = _normal(g, (1, 1, 2 * T), 0.2)
+        sd[p + b + "grn.beta"] = _normal(g, (1, 1, 2 * T), 0.05)
+        linear(b + "pwconv2", T, 2 * T)
+    linear("input_embed.proj", D, 2 * mel + T)
+    cpg = D // cfg.conv_pos_groups
+    for j in (0, 2):
+        b = f"input_embed.conv_pos_embed.conv1d.{j}."
+        sd[p + b + "weight"] = _normal(g, (D, cpg, cfg.conv_pos_kernel), 1.0 / math.sqrt(cpg * cfg.conv_pos_kernel))
+        sd[p + b + "bias"] = _normal(g, (D,), 0.02)
+    sd[p + "rotary_embed.inv_freq"] = 1.0 / (10000.0 ** (torch.arange(0, cfg.dim_head, 2).float() / cfg.dim_head))
+    inner = cfg.heads * cfg.dim_head
+    for i in range(cfg.depth):
+        b = f"transformer_blocks.{i}."
+        linear(b + "attn_norm.linear", 6 * D, D, w_std=0.02, b_std=0.05)  # zero-init in the reference
+        linear(b + "attn.to_q", inner, D)
+        linear(b + "attn.to_k", inner, D)
+        linear(b + "attn.to_v", inner, D)
+        linear(b + "attn.to_out.0", D, inner)
+        linear(b + "ff.ff.0.0", cfg.ff_inner, D)
+        linear(b + "ff.ff.2", D, cfg.ff_inner)
+    linear("norm_out.linear", 2 * D, D, w_std=0.02, b_std=0.05)  # zero-init in the reference
+    linear("proj_out", mel, D, w_std=0.04, b_std=0.02)  # zero-init in the reference
+    return sd
+
+
+def synth_vocos_state_dict(cfg: VocosConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Random-init Vocos (mel -> iSTFT head) weights with the ``vocos`` package's key names."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7000003 * seed + 29)
+    sd: Dict[str, torch.Tensor] = {}
+    C, I, inp = cfg.dim, cfg.intermediate_dim, cfg.input_channels
+    sd["backbone.embed.weight"] = _normal(g, (C, inp, 7), 1.0 / math.sqrt(inp * 7))
+    sd["backbone.embed.bias"] = _normal(g, (C,), 0.02)
+    sd["backbone.norm.weight"] = 1.0 + _normal(g, (C,), 0.05)
+    sd["backbone.norm.bias"] = _normal(g, (C,), 0.05)
+    for i in range(cfg.num_layers):
+        b = f"backbone.convnext.{i}."
+        sd[b + "dwconv.weight"] = _normal(g, (C, 1, 7), 1.0 / math.sqrt(7))
+        sd[b + "dwconv.bias"] = _normal(g, (C,), 0.02)
+        sd[b + "norm.weight"] = 1.0 + _normal(g, (C,), 0.05)
+        sd[b + "norm.bias"] = _normal(g, (C,), 0.05)
+        sd[b + "pwconv1.weight"] = _normal(g, (I, C), 1.0 / math.sqrt(C))
+        sd[b + "pwconv1.bias"] = _normal(g, (I,), 0.02)
+        sd[b + "pwconv2.weight"] = _normal(g, (C, I), 1.0 / math.sqrt(I))
+        sd[b + "pwconv2.bias"] = _normal(g, (C,), 0.02)
+        sd[b + "gamma"] = 1.0 / cfg.num_layers + _normal(g, (C,), 0.02)
+    sd["backbone.final_layer_norm.weight"] = 1.0 + _normal(g, (C,), 0.05)
+    sd["backbone.final_layer_norm.bias"] = _normal(g, (C,), 0.05)
+    # head: keep log-magnitudes modest so exp() stays well below the 1e2 clip on most bins
+    sd["head.out.weight"] = _normal(g, (cfg.n_fft + 2, C), 0.5 / math.sqrt(C))
+    sd["head.out.bias"] = _normal(g, (cfg.n_fft + 2,), 0.1)
+    sd["head.istft.window"] = torch.hann_window(cfg.n_fft)
+    return sd
+
+
+def synth_wave(n_samples: int, seed: int = 0, batch: int = 1) -> torch.Tensor:
+    """``0.1 * N(0,1)`` clipped to +-1: rms ~= 0.1, so the RMS-normalise branch
+    (reference ``src/f5_tts/infer/utils_infer.py:463-465``) is a no-op."""
+    g = torch.Generator(device="cpu")
+    out = []
+    for b in range(batch):
+        g.manual_seed(424243 * (seed + b) + 5)
+        out.append((0.1 * torch.randn(n_samples, generator=g)).clamp(-1.0, 1.0))
+    return torch.stack(out, 0)
+
+
+def synth_text_ids(batch: int, nt: int, vocab: int, seed: int = 0) -> torch.Tensor:
+    """int64 ``[batch, nt]`` ids uniform in ``[1, vocab-1]`` (0 is "space"/unknown, -1 is batch padding)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(99991 * seed + 3)
+    return torch.randint(1, vocab, (batch, nt), generator=g, dtype=torch.int64)

@@ -1,0 +1,156 @@
+/*
+ * f5hip.h — C ABI of libf5hip.so: the MI355X (gfx950) engine for the F5-TTS inference hot path.
+ *
+ * The reference (SWivid/F5-TTS) has no FFI on this path: its seam is the duck-typed Python objects
+ * returned by load_model()/load_vocoder() (reference src/f5_tts/infer/utils_infer.py:238-276, :106-145)
+ * and consumed by infer_batch_process() (:440-593).  The closest thing to an operator ABI in the tree
+ * is the TensorRT-LLM engine call (reference
+ * src/f5_tts/runtime/triton_trtllm/model_repo_f5_tts/f5_tts/1/f5_tts_trtllm.py:268-277,338-364:
+ * caller-allocated device buffers, a raw stream handle, boolean status).  This header follows that
+ * precedent: plain pointers and sizes, caller-owned I/O device buffers, library-owned weights and
+ * workspace, int status codes (0 = ok) + f5hip_last_error().  No torch types cross this boundary.
+ *
+ * Each entry point names the reference interface it replaces.  The Python binding that a reference
+ * maintainer would add is f5-tts_amd/binding.py (ctypes) — shown in INTEGRATION.md.
+ *
+ * All "device" pointers are HIP device pointers valid on the context's device; all launches go to
+ * the `stream` argument (a hipStream_t passed as void*; NULL = the legacy default stream).  Calls
+ * return after enqueueing unless stated otherwise; outputs are complete when the stream reaches the
+ * end of the enqueued work.  A context is internally serialised (one mutex): concurrent
+ * f5hip_sample() calls from a thread pool (reference utils_infer.py:540-543) are safe.
+ */
+#ifndef F5HIP_H
+#define F5HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F5HIP_ABI_VERSION 1
+
+/* status codes */
+enum {
+  F5HIP_OK = 0,
+  F5HIP_ERR_INVALID = 1,   /* bad argument / shape (mirrors the reference's asserts, cfm.py:109,124) */
+  F5HIP_ERR_HIP = 2,       /* a HIP runtime call failed */
+  F5HIP_ERR_STATE = 3,     /* call order (weights not finalised, ...) */
+  F5HIP_ERR_UNSUPPORTED = 4
+};
+
+/* GEMM operand precision of the per-step DiT path (everything else is always fp32):
+ *   FP32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                     — parity mode
+ *   FP16X3  fp16 hi/lo split operands, 3 MFMAs per product, fp32 accum    — ~fp32 accuracy
+ *   FP16    fp16 operands, fp32 accumulate (what the reference runs on GPU: utils_infer.py:191-199) */
+enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2 };
+
+/* Architecture of the DiT backbone: the keyword arguments of reference
+ * src/f5_tts/model/backbones/dit.py:171-192 that change inference arithmetic. */
+typedef struct f5hip_dit_config {
+  int32_t dim, depth, heads, dim_head, ff_inner;
+  int32_t mel_dim, text_num_embeds, text_dim, conv_layers;
+  int32_t text_mask_padding;   /* bool */
+  int32_t pe_attn_head;        /* -1 = rope on all heads (None), k>0 = first k heads */
+  int32_t attn_mask_enabled;   /* bool: key-padding mask inside attention */
+  int32_t conv_pos_kernel, conv_pos_groups;
+} f5hip_dit_config;
+
+/* Vocos (charactr/vocos-mel-24khz config.yaml; loader reference utils_infer.py:106-129). */
+typedef struct f5hip_vocos_config {
+  int32_t input_channels, dim, intermediate_dim, num_layers, n_fft, hop_length;
+} f5hip_vocos_config;
+
+typedef struct f5hip_ctx f5hip_ctx;
+
+int f5hip_abi_version(void);
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* replaces: CFM(transformer=DiT(**cfg)).to(device) in load_model (utils_infer.py:258-271).
+ * vocos_cfg may be NULL (no vocoder).  device = HIP device ordinal. */
+int f5hip_create(const f5hip_dit_config* dit_cfg, const f5hip_vocos_config* vocos_cfg, int device, f5hip_ctx** out);
+int f5hip_destroy(f5hip_ctx* ctx);
+/* last error text of this context (or of the failed f5hip_create when ctx == NULL); never NULL */
+const char* f5hip_last_error(const f5hip_ctx* ctx);
+
+/* ---- weights --------------------------------------------------------------------------------- */
+/* replaces: model.load_state_dict(...) in load_checkpoint (utils_infer.py:190-232) and
+ * vocoder.load_state_dict (utils_infer.py:127).  `name` is the reference state-dict key after the
+ * EMA prefix strip ("transformer.transformer_blocks.0.attn.to_q.weight", "backbone.embed.weight", ...).
+ * `data` is fp32, contiguous, HOST memory, `numel` elements; it is copied synchronously into the
+ * context's packed device blob.  Unknown names return F5HIP_ERR_INVALID (the adapter drops the keys
+ * the reference drops: "initted", "step", legacy mel_stft buffers, rotary inv_freq is accepted and ignored). */
+int f5hip_load_tensor(f5hip_ctx* ctx, const char* name, const float* data, int64_t numel);
+/* number of named tensors the context expects / i-th name and element count (for loaders and tests) */
+int f5hip_num_tensors(const f5hip_ctx* ctx);
+int f5hip_tensor_info(const f5hip_ctx* ctx, int index, const char** name, int64_t* numel, int64_t* blob_offset);
+/* The packed fp32 weight blob on the device (DiT then Vocos), for the one-time RCCL broadcast from
+ * rank 0 — the reference instead lets every rank read the checkpoint
+ * (src/f5_tts/eval/eval_infer_batch.py:140-172). */
+int f5hip_weight_blob(f5hip_ctx* ctx, void** device_ptr, int64_t* bytes);
+/* Mark every tensor as loaded (used after the blob was filled by a broadcast instead of load_tensor). */
+int f5hip_mark_all_loaded(f5hip_ctx* ctx);
+/* Build derived device layouts (fp16 hi/lo operand copies, fused QKV, per-tap conv weights, FFT/mel
+ * tables).  Must be called after all tensors are loaded and before any compute call.  Synchronous. */
+int f5hip_finalize_weights(f5hip_ctx* ctx);
+
+/* ---- mel front-end ---------------------------------------------------------------------------- */
+/* replaces: MelSpec.forward -> get_vocos_mel_spectrogram (reference src/f5_tts/model/modules.py:80-109,138-151):
+ * reflect-pad n_fft/2, STFT(1024, hop 256, periodic hann), |.|, HTK mel filterbank [513->100], log(clamp 1e-5).
+ * wav: device fp32 [batch, n_samples]; out: device fp32, frames = 1 + n_samples/256;
+ * frame_major != 0 -> out[batch, frames, 100] (what CFM.sample consumes after its permute, cfm.py:107-108),
+ * else out[batch, 100, frames] (what MelSpec.forward returns). */
+int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t n_samples, float* out, int frame_major, void* stream);
+
+/* ---- sampler ----------------------------------------------------------------------------------- */
+/* replaces: CFM.sample from "duration" onwards (reference src/f5_tts/model/cfm.py:128-223) including the
+ * odeint euler loop (cfm.py:218), DiT.forward(cfg_infer=True, cache=True) (dit.py:319-370), the CFG combine
+ * (cfm.py:190-191) and the prompt restore (cfm.py:221-223).  The host adapter keeps the reference's cheap
+ * host logic (tokenise, duration clamp, seeded torch-CPU noise, time grid) and passes its results in.
+ *
+ *   batch, n        number of utterances, padded frame count (= duration.amax())
+ *   cond            device fp32 [batch, n, mel]: prompt mel padded with zeros to n frames (cfm.py:145)
+ *   cond_mask       host uint8 [batch, n]: lens_to_mask(lens) & edit_mask, padded False (cfm.py:128-130,149)
+ *   text            host int64 [batch, nt]: token ids, -1 = batch padding (utils.py:99-106)
+ *   duration        host int64 [batch]: per-utterance frame count; rows >= duration[b] are padding.
+ *                   use_mask != 0 <=> the reference passes mask = lens_to_mask(duration) (batch > 1, cfm.py:155-158)
+ *   y0              device fp32 [batch, n, mel]: initial noise (cfm.py:196-201), zero on padding rows
+ *   t               host fp32 [steps + 1]: the time grid (cfm.py:211-216)
+ *   cfg_strength    classifier-free guidance strength (>= 1e-5; the no-CFG branch is F5HIP_ERR_UNSUPPORTED)
+ *   precision       F5HIP_PREC_*
+ *   out             device fp32 [batch, n, mel]: where(cond_mask, cond, y_final)
+ *   trajectory      device fp32 [steps + 1, batch, n, mel] or NULL: every ODE state (cfm.py:218 return value)
+ */
+int f5hip_sample(f5hip_ctx* ctx, int batch, int n, const float* cond, const uint8_t* cond_mask, const int64_t* text,
+                 int nt, const int64_t* duration, int use_mask, const float* y0, const float* t, int steps,
+                 float cfg_strength, int precision, float* out, float* trajectory, void* stream);
+
+/* Debug/parity taps (tests only): copies of internal tensors of the LAST f5hip_sample call.
+ *   which = 0: text_embed cond [batch, n, text_dim]   1: text_embed uncond
+ *           2: velocity of the last step [batch, n, mel] (after CFG)
+ *           3: packed hidden state after input embedding of the last step [2*batch, n, dim]
+ * dst: device fp32 buffer of `numel` elements. */
+int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, void* stream);
+
+/* ---- vocoder ------------------------------------------------------------------------------------ */
+/* replaces: vocoder.decode(mel) (reference utils_infer.py:510-511; `vocos` package: backbone + ISTFTHead,
+ * head restated in-repo at runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:45-59).
+ * mel: device fp32; channel_major != 0 -> [batch, 100, frames] (the reference's call layout), else [batch, frames, 100].
+ * out: device fp32 [batch, 256 * (frames - 1)] (torch.istft(center=True) length). */
+int f5hip_vocos_decode(f5hip_ctx* ctx, const float* mel, int batch, int frames, int channel_major, float* out, void* stream);
+
+/* ---- engine options / measurement ---------------------------------------------------------------- */
+/* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel
+ * class with hipEvents on the launch stream; forces eager launches). */
+int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
+/* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
+ * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */
+int f5hip_num_kernel_stats(const f5hip_ctx* ctx);
+int f5hip_kernel_stat(const f5hip_ctx* ctx, int index, const char** name, int64_t* calls, double* total_ms,
+                      double* flops, double* bytes);
+int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F5HIP_H */

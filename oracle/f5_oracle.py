@@ -1,0 +1,422 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the F5-TTS inference hot path.  NOT product code.
+
+A self-contained restatement (plain torch fp32 on CPU, functional style over a flat
+state-dict) of the reference's algorithm for the path named by BASELINE.json's north_star:
+``CFM.sample`` + ``DiT.forward`` + Vocos mel front-end + Vocos decode.  Each function cites the
+reference file:line it follows (paths relative to ``/root/reference/``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the CHECKER / the timed CPU baseline — the product path
+(``f5-tts_amd``) never routes through it and fails loudly when the HIP library is missing.
+
+Pinning status.  The reference has no tests and no golden vectors.  This
+restatement is pinned against OUTPUTS OF THE REFERENCE ITSELF, run in the build container by
+``oracle/make_golden.py`` (reference classes imported verbatim through ``oracle/ref_shims.py``)
+and committed as fixtures under ``tests/golden/``; ``tests/test_oracle.py`` re-checks it against
+the live reference whenever ``/root/reference`` exists.  The arithmetic that lives in
+un-vendored third-party packages (torchdiffeq, x_transformers, torchaudio mel, the ``vocos``
+package) is restated from the published algorithms — for those pieces the pin is the reference's
+own call sites plus the in-repo cross-checks (rope: ``runtime/triton_trtllm/.../f5_tts_trtllm.py:232-237``;
+STFT/iSTFT: ``runtime/triton_trtllm/scripts/conv_stft.py``, runnable, agreement checked by
+``make_golden.py``); the Vocos *backbone* has no in-repo check: parity for it is "unpinned by the
+reference" and anchored on the upstream definition cited in ``vocos_decode``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ---------------------------------------------------------------------------------------------
+# model/utils.py
+# ---------------------------------------------------------------------------------------------
+def lens_to_mask(t: Tensor, length: Optional[int] = None) -> Tensor:
+    """src/f5_tts/model/utils.py:53-58"""
+    if length is None:
+        length = int(t.amax())
+    seq = torch.arange(length)
+    return seq[None, :] < t[:, None]
+
+
+_EPSS = {  # src/f5_tts/model/utils.py:205-218
+    5: [0, 2, 4, 8, 16, 32],
+    6: [0, 2, 4, 6, 8, 16, 32],
+    7: [0, 2, 4, 6, 8, 16, 24, 32],
+    10: [0, 2, 4, 6, 8, 12, 16, 20, 24, 28, 32],
+    12: [0, 2, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32],
+    16: [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32],
+}
+
+
+def time_grid(steps: int, sway_sampling_coef: Optional[float], use_epss: bool = True, t_start: float = 0.0) -> Tensor:
+    """src/f5_tts/model/cfm.py:211-216 (+ utils.py:205-218)."""
+    if t_start == 0 and use_epss and steps in _EPSS:
+        t = (1 / 32) * torch.tensor(_EPSS[steps], dtype=torch.float32)
+    else:
+        t = torch.linspace(t_start, 1, steps + 1, dtype=torch.float32)
+    if sway_sampling_coef is not None:
+        t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# mel front-end  (model/modules.py:80-109 -> torchaudio.transforms.MelSpectrogram)
+# ---------------------------------------------------------------------------------------------
+def htk_fbanks(n_freqs=513, f_min=0.0, f_max=12000.0, n_mels=100, sample_rate=24000) -> Tensor:
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+def vocos_mel(wav: Tensor, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000) -> Tensor:
+    """src/f5_tts/model/modules.py:80-109: MelSpectrogram(power=1, center=True, norm=None) ->
+    clamp(1e-5).log().  wav [b, nw] -> [b, n_mels, 1 + nw // hop]."""
+    spec = torch.stft(wav, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()
+    fb = htk_fbanks(n_fft // 2 + 1, 0.0, float(sr // 2), n_mels, sr)
+    mel = torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
+    return mel.clamp(min=1e-5).log()
+
+
+# ---------------------------------------------------------------------------------------------
+# modules
+# ---------------------------------------------------------------------------------------------
+def precompute_freqs_cis(dim: int, end: int, theta: float = 10000.0) -> Tensor:
+    """src/f5_tts/model/modules.py:207-218 -> [end, dim] = cat(cos, sin)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].float() / dim))
+    t = torch.arange(end)
+    freqs = torch.outer(t, freqs).float()
+    return torch.cat([torch.cos(freqs), torch.sin(freqs)], dim=-1)
+
+
+def sinus_time_embedding(t: Tensor, dim: int = 256, scale: float = 1000.0) -> Tensor:
+    """src/f5_tts/model/modules.py:157-169 (divides by half_dim-1, cat(sin, cos))."""
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    emb = torch.exp(torch.arange(half).float() * -emb)
+    emb = scale * t.unsqueeze(1) * emb.unsqueeze(0)
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
+
+
+def timestep_embedding(sd: SD, t: Tensor) -> Tensor:
+    """src/f5_tts/model/modules.py:852-862."""
+    h = sinus_time_embedding(t)
+    h = F.linear(h, sd["transformer.time_embed.time_mlp.0.weight"], sd["transformer.time_embed.time_mlp.0.bias"])
+    h = F.silu(h)
+    return F.linear(h, sd["transformer.time_embed.time_mlp.2.weight"], sd["transformer.time_embed.time_mlp.2.bias"])
+
+
+def grn(x: Tensor, gamma: Tensor, beta: Tensor) -> Tensor:
+    """src/f5_tts/model/modules.py:242-245 — L2 norm over the SEQUENCE axis (dim=1)."""
+    gx = torch.norm(x, p=2, dim=1, keepdim=True)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    return gamma * (x * nx) + beta + x
+
+
+def convnext_v2_block(sd: SD, pfx: str, x: Tensor) -> Tensor:
+    """src/f5_tts/model/modules.py:270-280."""
+    res = x
+    h = F.conv1d(x.transpose(1, 2), sd[pfx + "dwconv.weight"], sd[pfx + "dwconv.bias"], padding=3, groups=x.shape[-1])
+    h = h.transpose(1, 2)
+    h = F.layer_norm(h, (h.shape[-1],), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], eps=1e-6)
+    h = F.linear(h, sd[pfx + "pwconv1.weight"], sd[pfx + "pwconv1.bias"])
+    h = F.gelu(h)
+    h = grn(h, sd[pfx + "grn.gamma"], sd[pfx + "grn.beta"])
+    h = F.linear(h, sd[pfx + "pwconv2.weight"], sd[pfx + "pwconv2.bias"])
+    return res + h
+
+
+def text_embedding(sd: SD, cfg, text: Tensor, seq_len, drop_text: bool) -> Tensor:
+    """src/f5_tts/model/backbones/dit.py:86-139 (average_upsampling=False).
+    ``seq_len``: int (no mask, batch==1) or int64 [b] (per-sample valid length)."""
+    text = text + 1
+    valid = None
+    if torch.is_tensor(seq_len):
+        max_len = int(seq_len.max())
+    else:
+        max_len = int(seq_len)
+    text = text[:, :max_len]
+    text = F.pad(text, (0, max_len - text.shape[1]), value=0)
+    if torch.is_tensor(seq_len):
+        valid = torch.arange(max_len).unsqueeze(0) < seq_len.unsqueeze(1)
+        text = text.masked_fill(~valid, 0)
+    text_mask = (text == 0) if cfg.text_mask_padding else None
+    if drop_text:
+        text = torch.zeros_like(text)
+    h = F.embedding(text, sd["transformer.text_embed.text_embed.weight"])
+    if valid is not None:
+        h = h.masked_fill(~valid.unsqueeze(-1), 0.0)
+    if cfg.conv_layers > 0:
+        freqs = precompute_freqs_cis(cfg.text_dim, 8192)[:max_len, :]
+        if valid is not None:
+            freqs = freqs.unsqueeze(0) * valid.unsqueeze(-1).to(freqs.dtype)
+        h = h + freqs
+        if cfg.text_mask_padding:
+            m = text_mask.unsqueeze(-1)
+            h = h.masked_fill(m, 0.0)
+            for i in range(cfg.conv_layers):
+                h = convnext_v2_block(sd, f"transformer.text_embed.text_blocks.{i}.", h)
+                h = h.masked_fill(m, 0.0)
+        else:
+            for i in range(cfg.conv_layers):
+                h = convnext_v2_block(sd, f"transformer.text_embed.text_blocks.{i}.", h)
+    return h
+
+
+def mish(x: Tensor) -> Tensor:
+    return x * torch.tanh(F.softplus(x))
+
+
+def conv_position_embedding(sd: SD, cfg, x: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """src/f5_tts/model/modules.py:187-201."""
+    pfx = "transformer.input_embed.conv_pos_embed.conv1d."
+    k, g = cfg.conv_pos_kernel, cfg.conv_pos_groups
+    m = mask.unsqueeze(1) if mask is not None else None
+    h = x.permute(0, 2, 1)
+    if m is not None:
+        h = h.masked_fill(~m, 0.0)
+    for j in (0, 2):
+        h = F.conv1d(h, sd[pfx + f"{j}.weight"], sd[pfx + f"{j}.bias"], padding=k // 2, groups=g)
+        if m is not None:
+            h = h.masked_fill(~m, 0.0)
+        h = mish(h)
+    return h.permute(0, 2, 1)
+
+
+def input_embedding(sd: SD, cfg, x: Tensor, cond: Tensor, text_embed: Tensor, drop_audio_cond: bool,
+                    mask: Optional[Tensor]) -> Tensor:
+    """src/f5_tts/model/backbones/dit.py:151-164."""
+    if drop_audio_cond:
+        cond = torch.zeros_like(cond)
+    h = F.linear(torch.cat((x, cond, text_embed), dim=-1), sd["transformer.input_embed.proj.weight"],
+                 sd["transformer.input_embed.proj.bias"])
+    return conv_position_embedding(sd, cfg, h, mask) + h
+
+
+def rotary_freqs(dim_head: int, n: int) -> Tensor:
+    """x_transformers RotaryEmbedding.forward_from_seq_len (call: dit.py:352): [1, n, dim_head],
+    every frequency duplicated into adjacent lanes [f0,f0,f1,f1,...]."""
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, dim_head, 2).float() / dim_head))
+    freqs = torch.einsum("i,j->ij", torch.arange(n).float(), inv_freq)
+    return torch.stack((freqs, freqs), dim=-1).reshape(1, n, dim_head)
+
+
+def apply_rope(t: Tensor, freqs: Tensor) -> Tensor:
+    """x_transformers apply_rotary_pos_emb (calls: modules.py:503-509): interleaved pairs
+    (x0,x1)->(x0 cos - x1 sin, x1 cos + x0 sin).  t [b,h,n,d], freqs [1,n,d]."""
+    f = freqs[:, None]
+    tp = t.reshape(*t.shape[:-1], t.shape[-1] // 2, 2)
+    x1, x2 = tp.unbind(dim=-1)
+    rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)
+    return t * f.cos() + rot * f.sin()
+
+
+def attention(sd: SD, cfg, pfx: str, x: Tensor, mask: Optional[Tensor], freqs: Tensor) -> Tensor:
+    """src/f5_tts/model/modules.py:471-556 (torch backend, qk_norm=None)."""
+    b, n, _ = x.shape
+    hds, dh = cfg.heads, cfg.dim_head
+    q = F.linear(x, sd[pfx + "to_q.weight"], sd[pfx + "to_q.bias"]).view(b, n, hds, dh).transpose(1, 2)
+    k = F.linear(x, sd[pfx + "to_k.weight"], sd[pfx + "to_k.bias"]).view(b, n, hds, dh).transpose(1, 2)
+    v = F.linear(x, sd[pfx + "to_v.weight"], sd[pfx + "to_v.bias"]).view(b, n, hds, dh).transpose(1, 2)
+    if cfg.pe_attn_head is not None:
+        pn = cfg.pe_attn_head
+        q = torch.cat((apply_rope(q[:, :pn], freqs), q[:, pn:]), dim=1)
+        k = torch.cat((apply_rope(k[:, :pn], freqs), k[:, pn:]), dim=1)
+    else:
+        q = apply_rope(q, freqs)
+        k = apply_rope(k, freqs)
+    attn_mask = None
+    if cfg.attn_mask_enabled and mask is not None:
+        attn_mask = mask[:, None, None, :].expand(b, hds, n, n)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(b, n, hds * dh)
+    o = F.linear(o, sd[pfx + "to_out.0.weight"], sd[pfx + "to_out.0.bias"])
+    if mask is not None:
+        o = o.masked_fill(~mask.unsqueeze(-1), 0.0)
+    return o
+
+
+def dit_block(sd: SD, cfg, i: int, x: Tensor, t: Tensor, mask: Optional[Tensor], freqs: Tensor) -> Tensor:
+    """src/f5_tts/model/modules.py:743-757 (+ AdaLayerNorm :321-326, FeedForward :353-364)."""
+    pfx = f"transformer.transformer_blocks.{i}."
+    d = x.shape[-1]
+    emb = F.linear(F.silu(t), sd[pfx + "attn_norm.linear.weight"], sd[pfx + "attn_norm.linear.bias"])
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = torch.chunk(emb, 6, dim=1)
+    norm = F.layer_norm(x, (d,), eps=1e-6) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    x = x + gate_msa.unsqueeze(1) * attention(sd, cfg, pfx + "attn.", norm, mask, freqs)
+    norm = F.layer_norm(x, (d,), eps=1e-6) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    h = F.linear(norm, sd[pfx + "ff.ff.0.0.weight"], sd[pfx + "ff.ff.0.0.bias"])
+    h = F.gelu(h, approximate="tanh")
+    h = F.linear(h, sd[pfx + "ff.ff.2.weight"], sd[pfx + "ff.ff.2.bias"])
+    return x + gate_mlp.unsqueeze(1) * h
+
+
+def dit_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, text_uncond: Tensor, time: Tensor,
+                    mask: Optional[Tensor], return_hidden: bool = False):
+    """src/f5_tts/model/backbones/dit.py:319-370 with cfg_infer=True, cache=True -> [2b, n, mel]."""
+    b, n = x.shape[0], x.shape[1]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = timestep_embedding(sd, time)
+    x_c = input_embedding(sd, cfg, x, cond, text_cond, False, mask)
+    x_u = input_embedding(sd, cfg, x, cond, text_uncond, True, mask)
+    h = torch.cat((x_c, x_u), dim=0)
+    t = torch.cat((t, t), dim=0)
+    m2 = torch.cat((mask, mask), dim=0) if mask is not None else None
+    freqs = rotary_freqs(cfg.dim_head, n)
+    hidden = [h]
+    for i in range(cfg.depth):
+        h = dit_block(sd, cfg, i, h, t, m2, freqs)
+        if return_hidden:
+            hidden.append(h)
+    emb = F.linear(F.silu(t), sd["transformer.norm_out.linear.weight"], sd["transformer.norm_out.linear.bias"])
+    scale, shift = torch.chunk(emb, 2, dim=1)  # NOTE (scale, shift) order: modules.py:344
+    h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    out = F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+    return (out, hidden) if return_hidden else out
+
+
+# ---------------------------------------------------------------------------------------------
+# sampler
+# ---------------------------------------------------------------------------------------------
+def make_noise(duration: Tensor, mel_dim: int, seed: Optional[int]) -> Tensor:
+    """src/f5_tts/model/cfm.py:196-201 — per-sample reseed of torch's CPU generator, pad with 0."""
+    y0 = []
+    for dur in duration:
+        if seed is not None:
+            torch.manual_seed(seed)
+        y0.append(torch.randn(int(dur), mel_dim, dtype=torch.float32))
+    return torch.nn.utils.rnn.pad_sequence(y0, padding_value=0, batch_first=True)
+
+
+@torch.no_grad()
+def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optional[Tensor] = None, steps: int = 32,
+               cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None, seed: Optional[int] = None,
+               max_duration: int = 65536, use_epss: bool = True, edit_mask: Optional[Tensor] = None,
+               return_steps: bool = False):
+    """src/f5_tts/model/cfm.py:83-229 with a DiT backbone, CFG on (cfg_strength >= 1e-5), euler.
+    cond: wave [b, nw] or mel [b, n, mel]; text: int64 [b, nt] (already tokenised, -1 padded)."""
+    if cond.ndim == 2:
+        cond = vocos_mel(cond).permute(0, 2, 1)
+        assert cond.shape[-1] == cfg.mel_dim
+    cond = cond.float()
+    batch, cond_seq_len = cond.shape[:2]
+    if lens is None:
+        lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
+    cond_mask = lens_to_mask(lens)
+    if edit_mask is not None:
+        cond_mask = cond_mask & edit_mask
+    if isinstance(duration, int):
+        duration = torch.full((batch,), duration, dtype=torch.long)
+    duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)
+    duration = duration.clamp(max=max_duration)
+    n = int(duration.amax())
+    cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+    cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False).unsqueeze(-1)
+    step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
+    mask = lens_to_mask(duration) if batch > 1 else None
+
+    seq_len = n if mask is None else mask.sum(dim=1)  # dit.py:295-298
+    text_cond = text_embedding(sd, cfg, text, seq_len, drop_text=False)
+    text_uncond = text_embedding(sd, cfg, text, seq_len, drop_text=True)
+
+    y = make_noise(duration, cfg.mel_dim, seed)
+    t = time_grid(steps, sway_sampling_coef, use_epss)
+    traj = [y]
+    vel = []
+    for i in range(steps):  # torchdiffeq euler on the supplied grid (cfm.py:218)
+        pred_cfg = dit_forward_cfg(sd, cfg, y, step_cond, text_cond, text_uncond, t[i], mask)
+        pred, null = torch.chunk(pred_cfg, 2, dim=0)
+        v = pred + (pred - null) * cfg_strength  # cfm.py:190-191
+        y = y + (t[i + 1] - t[i]) * v
+        traj.append(y)
+        if return_steps:
+            vel.append(v)
+    trajectory = torch.stack(traj, 0)
+    out = torch.where(cond_mask, cond, trajectory[-1])  # cfm.py:221-223
+    if return_steps:
+        return out, trajectory, dict(text_cond=text_cond, text_uncond=text_uncond, velocity=torch.stack(vel, 0), t=t,
+                                     step_cond=step_cond, y0=traj[0])
+    return out, trajectory
+
+
+# ---------------------------------------------------------------------------------------------
+# Vocos (third-party ``vocos`` package, absent here — restated from upstream
+# vocos/models.py::VocosBackbone, vocos/modules.py::ConvNeXtBlock, vocos/heads.py::ISTFTHead,
+# vocos/spectral_ops.py::ISTFT(padding="center"); head math cross-checked in-repo by
+# src/f5_tts/runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:45-59)
+# ---------------------------------------------------------------------------------------------
+def vocos_backbone(sd: SD, mel: Tensor, num_layers: int) -> Tensor:
+    """mel [b, 100, T] -> [b, T, dim]."""
+    x = F.conv1d(mel, sd["backbone.embed.weight"], sd["backbone.embed.bias"], padding=3)
+    c = x.shape[1]
+    x = F.layer_norm(x.transpose(1, 2), (c,), sd["backbone.norm.weight"], sd["backbone.norm.bias"], eps=1e-6).transpose(1, 2)
+    for i in range(num_layers):
+        p = f"backbone.convnext.{i}."
+        res = x
+        h = F.conv1d(x, sd[p + "dwconv.weight"], sd[p + "dwconv.bias"], padding=3, groups=c).transpose(1, 2)
+        h = F.layer_norm(h, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-6)
+        h = F.linear(h, sd[p + "pwconv1.weight"], sd[p + "pwconv1.bias"])
+        h = F.gelu(h)
+        h = F.linear(h, sd[p + "pwconv2.weight"], sd[p + "pwconv2.bias"])
+        h = sd[p + "gamma"] * h
+        x = res + h.transpose(1, 2)
+    return F.layer_norm(x.transpose(1, 2), (c,), sd["backbone.final_layer_norm.weight"],
+                        sd["backbone.final_layer_norm.bias"], eps=1e-6)
+
+
+def vocos_head_spectrum(sd: SD, x: Tensor) -> Tensor:
+    """ISTFTHead up to the complex spectrum: [b, T, dim] -> complex [b, n_fft/2+1, T]."""
+    x = F.linear(x, sd["head.out.weight"], sd["head.out.bias"]).transpose(1, 2)
+    mag, p = x.chunk(2, dim=1)
+    mag = torch.exp(mag)
+    mag = torch.clip(mag, max=1e2)
+    return mag * (torch.cos(p) + 1j * torch.sin(p))
+
+
+def vocos_decode(sd: SD, mel: Tensor, num_layers: int = 8, n_fft: int = 1024, hop: int = 256) -> Tensor:
+    """``Vocos.decode`` (call site src/f5_tts/infer/utils_infer.py:510-511): mel [b,100,T] -> wav [b, hop*(T-1)]."""
+    x = vocos_backbone(sd, mel, num_layers)
+    spec = vocos_head_spectrum(sd, x)
+    return torch.istft(spec, n_fft, hop_length=hop, win_length=n_fft, window=sd["head.istft.window"], center=True)
+
+
+def istft_manual(spec: Tensor, n_fft: int = 1024, hop: int = 256) -> Tensor:
+    """torch.istft(center=True) spelled out: irfft -> x window -> overlap-add -> / sum(window^2) ->
+    trim n_fft/2 each side.  Used to pin the semantics the HIP kernel implements."""
+    win = torch.hann_window(n_fft)
+    frames = torch.fft.irfft(spec, n=n_fft, dim=1) * win[None, :, None]  # [b, n_fft, T]
+    b, _, T = frames.shape
+    total = n_fft + hop * (T - 1)
+    y = F.fold(frames, output_size=(1, total), kernel_size=(1, n_fft), stride=(1, hop))[:, 0, 0, :]
+    env = F.fold((win * win)[None, :, None].expand(1, n_fft, T), output_size=(1, total), kernel_size=(1, n_fft),
+                 stride=(1, hop))[:, 0, 0, :]
+    s = n_fft // 2
+    return y[:, s:total - s] / env[:, s:total - s]
+
+
+# ---------------------------------------------------------------------------------------------
+# L4 call-site glue around the path (src/f5_tts/infer/utils_infer.py:477-520), fixed-duration form
+# ---------------------------------------------------------------------------------------------
+def infer_basic(sd_dit: SD, cfg, sd_vocos: SD, vocos_layers: int, audio: Tensor, text: Tensor, duration: int, *,
+                steps: int, cfg_strength: float, sway_sampling_coef: Optional[float], seed: Optional[int]):
+    ref_audio_len = audio.shape[-1] // 256  # :486  (one less than the mel frame count)
+    out, _ = cfm_sample(sd_dit, cfg, audio, text, duration, steps=steps, cfg_strength=cfg_strength,
+                        sway_sampling_coef=sway_sampling_coef, seed=seed)
+    gen = out[:, ref_audio_len:, :].permute(0, 2, 1)  # :507-509
+    wav = vocos_decode(sd_vocos, gen, vocos_layers)  # :510-511
+    return wav, out
