@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py — the driver's benchmark contract for the F5-TTS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic utterances on every rank:
+mel front-end of the 5 s prompt -> CFM.sample (text embed + NFE-step ODE loop, CFG) -> slice -> Vocos decode.
+Default workload = BASELINE.json configs[1]: F5-TTS Base + Vocos, batch 1, NFE 16, sway sampling (N=1406 frames:
+469 prompt + 937 generated -> 938 vocoded frames, 9.995 s of audio).  Weak scaling: every rank runs the same
+per-GPU batch on its own utterances; weights are broadcast once from rank 0 over RCCL; no collective inside a step.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).  `roofline` is measured live for the dominant
+kernel (the DiT block GEMM) with HIP events on the launch stream in an extra, untimed, eager pass; `cpu_baseline` is
+the oracle (a restatement of the reference's CPU path) timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import f5_tts_amd  # noqa: E402,F401
+from f5_tts_amd import config, synth  # noqa: E402
+from f5_tts_amd import dist as fdist  # noqa: E402
+
+PEAK_TFLOPS_FP16_DENSE = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
+HOP, SR = 256, 24000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[2] uses 32)")
+    ap.add_argument("--nfe", type=int, default=16)
+    ap.add_argument("--precision", default="fp16x3", choices=["fp32", "fp16x3", "fp16"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", default="F5TTS_v1_Base")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen):
+    """Oracle (port of the reference CPU path) on the host cores, bounded sample: mel + text-embed + `probe` ODE steps
+    + vocoder at full size, per-step time extrapolated to `nfe` steps (every step does identical work)."""
+    from oracle import f5_oracle as O
+
+    probe = 2
+    torch.set_num_threads(os.cpu_count() or 1)
+    kw = dict(cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, use_epss=False)
+    t0 = time.perf_counter()
+    O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1, **kw)
+    t1 = time.perf_counter()
+    out, _ = O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1 + probe, **kw)
+    t2 = time.perf_counter()
+    gen = out[:, wav.shape[-1] // HOP:, :].permute(0, 2, 1)
+    O.vocos_decode(vsd, gen, vcfg.num_layers)
+    t3 = time.perf_counter()
+    per_step = ((t2 - t1) - (t1 - t0)) / probe
+    setup = max((t1 - t0) - per_step, 0.0)
+    total = setup + nfe * per_step + (t3 - t2)
+    return {"value": t_gen / total, "unit": "gen_mel_frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "rtf": total / (HOP * (t_gen - 1) / SR), "seconds_per_utterance_extrapolated": total,
+            "sample": f"full-size model, 1 utterance: mel + text-embed + {probe + 2} ODE steps + vocoder measured "
+                      f"({t3 - t0:.1f} s of CPU), per-step time extrapolated to NFE={nfe}"}
+
+
+def main():
+    a = parse()
+    rank, local, world = fdist.init_distributed()
+    assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine, F5HipVocos
+
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg, vcfg = config.PRESETS[a.model], config.VOCOS_MEL_24K
+    eng = F5HipEngine(cfg, vcfg, device=dev)
+    sd = vsd = None
+    if rank == 0:  # rank 0 "reads the checkpoint"; the packed blob travels over RCCL/xGMI
+        sd, vsd = synth.synth_dit_state_dict(cfg, seed=0), synth.synth_vocos_state_dict(vcfg, seed=0)
+        eng.load_state_dict({**sd, **vsd}, finalize=False)
+    fdist.broadcast_engine_weights(eng, src=0)
+    if not a.no_graph:
+        eng.set_option("use_graph", 1)
+    model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
+
+    B, nw, nt, duration = a.batch, 120000, 220, 1406
+    wav = synth.synth_wave(nw, seed=1000 * rank, batch=B).to(dev)  # resident in HBM before the timed region
+    text = synth.synth_text_ids(B, nt, cfg.text_num_embeds, seed=rank)
+    ref_len = nw // HOP  # 468 (utils_infer.py:486)
+    t_gen = duration - ref_len  # 938 vocoded frames per utterance
+    kw = dict(steps=a.nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
+
+    def one_pass():
+        out, _ = model.sample(wav, text, duration, **kw)
+        gen = out[:, ref_len:, :]  # [B, 938, 100] view; the engine takes frame-major directly
+        return eng.vocos_decode(gen.contiguous(), channel_major=False)
+
+    for _ in range(a.warmup):
+        one_pass()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wave = one_pass()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()
+    dt = fdist.barrier_max_seconds(time.perf_counter() - t0, dev)
+    assert wave.shape == (B, HOP * (t_gen - 1)) and bool(torch.isfinite(wave).all())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+        return
+    ms_per_step = 1e3 * dt / a.steps
+    frames = world * B * t_gen
+    audio_s = world * B * HOP * (t_gen - 1) / SR
+    res = {
+        "metric": "gen_mel_frames_per_s", "value": frames / (dt / a.steps), "unit": "frames/s",
+        "rtf": (dt / a.steps) / audio_s, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp16x3": "fp16x3 (fp16 hi/lo split MFMA operands, fp32 accumulate/state)", "fp16": "fp16 (fp32 accumulate/state)",
+                  "fp32": "fp32"}[a.precision],
+        "data": "synthetic (seeded 0.1*N(0,1) prompts, uniform token ids, random-init weights of the named architecture)",
+        "config": {"workload": f"{a.model} + Vocos, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
+                               f"sway -1, CFG 2.0, euler (BASELINE.json configs[{1 if B == 1 else 2}])",
+                   "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
+                   "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective"},
+    }
+    # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager pass -------
+    eng.set_option("profile", 1)
+    eng.reset_kernel_stats()
+    one_pass()
+    torch.cuda.synchronize(dev)
+    stats = eng.kernel_stats()
+    eng.set_option("profile", 0)
+    g = stats["gemm_block"]
+    if g["calls"]:
+        avg_s = 1e-3 * g["ms"] / g["calls"]
+        ach = g["flops"] / g["calls"] / avg_s / 1e12
+        res["roofline"] = {"kernel": "gemm_kernel (DiT block QKV/out/FF1/FF2)", "bound": "mfma", "achieved": ach,
+                           "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE, "traffic": None,
+                           "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
+                           "note": "achieved = algorithmic FLOPs (2MNK) / avg launch duration; fp16x3 issues 3 MFMAs per product"}
+    res["kernel_classes_ms"] = {k: round(v["ms"], 3) for k, v in stats.items() if v["calls"]}
+    if not a.no_cpu_baseline and world == 1:
+        try:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen)
+        except Exception as e:  # pragma: no cover
+            res["cpu_baseline"] = {"error": repr(e)}
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""Multi-GPU layer: utterances shard by rank, weights travel once over RCCL, nothing inside a step.
+
+The reference's only multi-GPU inference pattern is one process per GPU, each processing a disjoint
+slice of the utterance list with barriers around the loop (reference
+``src/f5_tts/eval/eval_infer_batch.py:178-214`` via ``accelerator.split_between_processes``;
+``src/f5_tts/runtime/triton_trtllm/benchmark.py:199-212,340-344`` via ``DistributedSampler``), every rank
+reading the checkpoint from disk itself.  Here rank 0 owns the checkpoint and the packed fp32 weight
+blob is broadcast once (torch.distributed backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env (torch.distributed.run contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_contiguous(n_items: int, rank: int, world: int) -> range:
+    """Contiguous slice per rank, sizes differing by at most one (accelerate's split_between_processes)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def shard_balanced(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Ragged utterances: longest-first greedy deal so every rank gets a similar frame budget
+    (the reference shuffles buckets "not only leave easy work for last workers", eval/utils_eval.py:201-203)."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += costs[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def broadcast_blob(blob: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20) -> None:
+    """Broadcast the packed weight blob in <=256 MiB chunks (few, large collectives; xGMI links are
+    point-to-point so a ring/tree broadcast is per-link bound — ~1.4 GB fp32 takes ~10 ms)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    flat = blob.view(-1)
+    for s in range(0, flat.numel(), chunk_elems):
+        dist.broadcast(flat[s:s + chunk_elems], src=src)
+
+
+def broadcast_engine_weights(engine, src: int = 0) -> None:
+    """Rank `src` has loaded the state dict; everyone else receives the blob and finalises."""
+    blob = engine.weight_blob()
+    broadcast_blob(blob, src=src)
+    if dist.is_initialized() and dist.get_rank() != src:
+        engine.mark_all_loaded()
+    engine.finalize()
+
+
+def barrier_max_seconds(seconds: float, device: torch.device | None = None) -> float:
+    """MAX over ranks of a per-rank wall time (the bench contract)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,168 @@
+"""TEST INFRASTRUCTURE — mint golden fixtures by running the REFERENCE ITSELF on CPU.
+
+The reference ships no golden vectors, so the pin for this build is: outputs of the
+reference's own ``CFM.sample`` / ``DiT`` code (imported verbatim from ``/root/reference/src`` through
+``oracle/ref_shims.py``) on seeded synthetic weights and inputs, stored under ``tests/golden/``.
+Weights/inputs are NOT stored: they are regenerated bit-identically from seeds by
+``f5-tts_amd/synth.py`` (same torch build on every box).
+
+Run in the build container only (``/root/reference`` does not exist on the GPU box):
+
+    python oracle/make_golden.py [--full]
+
+Also cross-checks, and records in ``tests/golden/pins.json``:
+  * the standalone restatement ``oracle/f5_oracle.py`` against the live reference (max-abs),
+  * torch.stft / torch.istft against the reference's own runnable conv-STFT
+    (``src/f5_tts/runtime/triton_trtllm/scripts/conv_stft.py``) — the only in-repo pin for the
+    STFT/iSTFT stage of the Vocos mel front-end / vocoder head.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import f5_tts_amd  # noqa: E402,F401
+from f5_tts_amd import config, synth  # noqa: E402
+from oracle import f5_oracle as O  # noqa: E402
+from oracle import ref_shims  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+MEL_KW = dict(n_fft=1024, hop_length=256, win_length=1024, n_mel_channels=100, target_sample_rate=24000, mel_spec_type="vocos")
+
+# name -> (preset, weight seed, wave samples, wave seed, batch, nt, text seed, duration, lens, sample kwargs)
+CASES = {
+    "tiny_v1_nfe16": dict(preset="tiny", wseed=1, nw=256 * 60, wavseed=3, batch=1, nt=40, tseed=2, duration=200, lens=None,
+                          kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    "tiny_v0_nfe16": dict(preset="tiny_v0", wseed=2, nw=256 * 60, wavseed=3, batch=1, nt=40, tseed=2, duration=200, lens=None,
+                          kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    "tiny_v1_nfe32_nosway": dict(preset="tiny", wseed=1, nw=256 * 50 + 77, wavseed=4, batch=1, nt=25, tseed=5, duration=150, lens=None,
+                                 kw=dict(steps=32, cfg_strength=1.5, sway_sampling_coef=None, seed=11)),
+    "tiny_v1_ragged_b2": dict(preset="tiny", wseed=1, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
+                              pad_from=30, kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    "tiny_v1_b3_fixed": dict(preset="tiny", wseed=1, nw=256 * 30, wavseed=9, batch=3, nt=20, tseed=6, duration=96, lens=None,
+                             kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+}
+FULL_CASES = {
+    # BASELINE.json configs[0]/[1]: F5-TTS Base, 5 s ref + 10 s gen, NFE 16, sway, CFG 2
+    "base_v1_cfg1": dict(preset="F5TTS_v1_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
+                         kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+}
+
+
+def case_inputs(c):
+    cfg = config.PRESETS[c["preset"]]
+    wav = synth.synth_wave(c["nw"], seed=c["wavseed"], batch=c["batch"])
+    text = synth.synth_text_ids(c["batch"], c["nt"], cfg.text_num_embeds, seed=c["tseed"])
+    if "pad_from" in c:
+        text[1, c["pad_from"]:] = -1
+    duration = c["duration"] if isinstance(c["duration"], int) else torch.tensor(c["duration"])
+    lens = torch.tensor(c["lens"]) if c["lens"] is not None else None
+    return cfg, wav, text, duration, lens
+
+
+def build_reference(cfg, sd):
+    CFM, DiT, _ = ref_shims.reference_classes()
+    model = CFM(transformer=DiT(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method="euler"))
+    model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
+    return model.eval()
+
+
+def run_case(name, c, pins):
+    cfg, wav, text, duration, lens = case_inputs(c)
+    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
+    model = build_reference(cfg, sd)
+    t0 = time.time()
+    with torch.no_grad():
+        out, traj = model.sample(wav, text, duration, lens=lens, **c["kw"])
+    t_ref = time.time() - t0
+    out_o, traj_o = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+    d = (out - out_o).abs().max().item()
+    dt = (traj - traj_o).abs().max().item()
+    print(f"{name}: reference {t_ref:.1f}s  out {tuple(out.shape)}  oracle-vs-reference out {d:.2e} traj {dt:.2e}")
+    steps = c["kw"]["steps"]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=out.numpy(), traj_1=traj[1].numpy(),
+                        traj_mid=traj[steps // 2].numpy(), traj_last=traj[-1].numpy())
+    pins[name] = dict(case={k: v for k, v in c.items()}, oracle_vs_reference_out=d, oracle_vs_reference_traj=dt,
+                      reference_seconds=t_ref, out_absmax=out.abs().max().item())
+
+
+def pin_stft(pins):
+    m = ref_shims.reference_conv_stft()
+    stft = m.STFT(fft_len=1024, win_hop=256, win_len=1024)
+    wav = synth.synth_wave(256 * 40, seed=21)
+    re, im = stft.transform(wav, return_type="realimag")
+    spec = torch.stft(wav, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True, pad_mode="reflect",
+                      return_complex=True)
+    d_fwd = max((re - spec.real).abs().max().item(), (im - spec.imag).abs().max().item())
+    T = spec.shape[-1]
+    inv_ref = stft.inverse(spec.real.contiguous(), spec.imag.contiguous(), "realimag")  # 256*T samples
+    inv_t = torch.istft(spec, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True)
+    d_inv = (inv_ref[:, : 256 * (T - 1)] - inv_t).abs().max().item()
+    d_man = (O.istft_manual(spec) - inv_t).abs().max().item()
+    print(f"conv_stft pin: transform vs torch.stft {d_fwd:.2e}; inverse vs torch.istft {d_inv:.2e}; istft_manual vs torch.istft {d_man:.2e}")
+    # a golden for the iSTFT stage produced by the REFERENCE's conv-iSTFT
+    g = torch.Generator().manual_seed(5)
+    sp = torch.complex(torch.randn(1, 513, 24, generator=g), torch.randn(1, 513, 24, generator=g))
+    sp[:, 0].imag.zero_()
+    sp[:, -1].imag.zero_()
+    ref_wav = stft.inverse(sp.real.contiguous(), sp.imag.contiguous(), "realimag")[:, : 256 * 23]
+    np.savez_compressed(os.path.join(GOLD, "istft_conv_reference.npz"), spec_re=sp.real.numpy(), spec_im=sp.imag.numpy(),
+                        wav=ref_wav.numpy())
+    pins["conv_stft"] = dict(transform_vs_torch_stft=d_fwd, inverse_vs_torch_istft=d_inv, istft_manual_vs_torch_istft=d_man)
+
+
+def pin_mel(pins):
+    """MelSpec.forward of the reference (through the torchaudio shim) vs the oracle; store a golden."""
+    ref_shims.install()
+    from f5_tts.model.modules import MelSpec
+
+    wav = synth.synth_wave(256 * 37 + 100, seed=13, batch=2)
+    ref = MelSpec(**MEL_KW)(wav)
+    d = (ref - O.vocos_mel(wav)).abs().max().item()
+    print(f"mel: reference MelSpec (torchaudio shim) vs oracle {d:.2e}")
+    np.savez_compressed(os.path.join(GOLD, "mel_b2.npz"), mel=ref.numpy())
+    pins["mel_b2"] = dict(nw=256 * 37 + 100, wavseed=13, batch=2, oracle_vs_reference=d)
+
+
+def golden_vocos(pins):
+    """Vocos has no source in the reference tree: the golden comes from the ORACLE restatement (parity unpinned)."""
+    vcfg = config.VOCOS_TINY
+    vsd = synth.synth_vocos_state_dict(vcfg, seed=1)
+    mel = O.vocos_mel(synth.synth_wave(256 * 80, seed=5))
+    wav = O.vocos_decode(vsd, mel, vcfg.num_layers)
+    np.savez_compressed(os.path.join(GOLD, "vocos_tiny.npz"), wav=wav.numpy())
+    pins["vocos_tiny"] = dict(source="oracle restatement (vocos package absent) — parity unpinned by the reference", wseed=1, wavseed=5,
+                              nw=256 * 80, absmax=wav.abs().max().item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also mint the full-size F5-TTS Base golden (~1 min of CPU)")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    pins_path = os.path.join(GOLD, "pins.json")
+    pins = json.load(open(pins_path)) if os.path.exists(pins_path) else {}
+    torch.manual_seed(0)
+    pin_stft(pins)
+    pin_mel(pins)
+    golden_vocos(pins)
+    for name, c in CASES.items():
+        run_case(name, c, pins)
+    if args.full:
+        for name, c in FULL_CASES.items():
+            run_case(name, c, pins)
+    pins["_meta"] = dict(torch=torch.__version__, reference="/root/reference (SWivid/F5-TTS v1.1.20)", generated_by="oracle/make_golden.py")
+    json.dump(pins, open(pins_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/f5hip.h declares; the binding types them all; no compute happens without a GPU and the
+product path fails loudly (no CPU fallback)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from f5_tts_amd import binding, config  # noqa: E402
+
+HEADER = os.path.join(ROOT, "include", "f5hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(f5hip_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(binding.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.isfile(binding.LIB_PATH), "build first: python __graft_entry__.py"
+    lib = binding.load_library()
+    for name in header_symbols():
+        assert hasattr(lib, name)
+    assert lib.f5hip_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (f5hip_[a-z_0-9]+)", out))
+    assert set(header_symbols()) <= exported
+
+
+def test_header_cites_reference_interfaces():
+    src = open(HEADER).read()
+    for cite in ("utils_infer.py:238-276", "cfm.py:128-223", "modules.py:80-109", "utils_infer.py:510-511", "utils_infer.py:190-232"):
+        assert cite in src
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(binding.F5HipError):
+        binding.load_library(str(tmp_path / "nope.so"))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback():
+    from f5_tts_amd.engine import F5HipEngine
+
+    with pytest.raises((binding.F5HipError, RuntimeError, AssertionError, ValueError)):
+        F5HipEngine(config.DIT_TINY, None, device="cpu")
+    lib = binding.load_library()
+    import ctypes as C
+
+    c = binding.DitConfigC(dim=256, depth=2, heads=4, dim_head=64, ff_inner=512, mel_dim=100, text_num_embeds=255, text_dim=128,
+                           conv_layers=2, text_mask_padding=1, pe_attn_head=-1, attn_mask_enabled=0, conv_pos_kernel=31, conv_pos_groups=16)
+    ctx = C.c_void_p()
+    st = lib.f5hip_create(C.byref(c), None, 0, C.byref(ctx))
+    assert st != 0 and not ctx.value
+    assert b"CPU fallback" in lib.f5hip_last_error(None) or b"device" in lib.f5hip_last_error(None)
+
+
+def test_create_rejects_bad_config():
+    lib = binding.load_library()
+    import ctypes as C
+
+    c = binding.DitConfigC(dim=250, depth=2, heads=4, dim_head=64, ff_inner=512, mel_dim=100, text_num_embeds=255, text_dim=128,
+                           conv_layers=2, text_mask_padding=1, pe_attn_head=-1, attn_mask_enabled=0, conv_pos_kernel=31, conv_pos_groups=16)
+    ctx = C.c_void_p()
+    assert lib.f5hip_create(C.byref(c), None, 0, C.byref(ctx)) == 1  # F5HIP_ERR_INVALID before touching any device

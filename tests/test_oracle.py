@@ -1,0 +1,103 @@
+"""CPU tests: the oracle restatement against the committed golden fixtures (minted from the live
+reference by oracle/make_golden.py) and, when /root/reference exists, against the reference itself."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from f5_tts_amd import config, synth  # noqa: E402
+from oracle import f5_oracle as O  # noqa: E402
+from oracle import make_golden as MG  # noqa: E402
+from oracle import ref_shims  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 2e-5  # fp32 re-association between two CPU implementations of the same math
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(MG.CASES))
+def test_oracle_matches_reference_golden(name):
+    c = MG.CASES[name]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
+    out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+    g = gold(name)
+    steps = c["kw"]["steps"]
+    assert np.abs(out.numpy() - g["out"]).max() < TOL
+    assert np.abs(traj[1].numpy() - g["traj_1"]).max() < TOL
+    assert np.abs(traj[steps // 2].numpy() - g["traj_mid"]).max() < TOL
+    assert np.abs(traj[-1].numpy() - g["traj_last"]).max() < TOL
+
+
+def test_pins_recorded():
+    pins = json.load(open(os.path.join(GOLD, "pins.json")))
+    for name in list(MG.CASES) + list(MG.FULL_CASES):
+        assert pins[name]["oracle_vs_reference_out"] < TOL
+    assert pins["conv_stft"]["inverse_vs_torch_istft"] < 1e-5
+    assert pins["conv_stft"]["transform_vs_torch_stft"] < 1e-4
+
+
+def test_mel_matches_reference_golden():
+    wav = synth.synth_wave(256 * 37 + 100, seed=13, batch=2)
+    mel = O.vocos_mel(wav)
+    assert mel.shape == (2, 100, 1 + (256 * 37 + 100) // 256)
+    assert np.abs(mel.numpy() - gold("mel_b2")["mel"]).max() < 1e-5
+
+
+def test_istft_semantics_vs_reference_conv_istft():
+    """torch.istft(center=True) == the reference's conv-iSTFT on its first 256*(T-1) samples."""
+    g = gold("istft_conv_reference")
+    spec = torch.complex(torch.from_numpy(g["spec_re"]), torch.from_numpy(g["spec_im"]))
+    w1 = torch.istft(spec, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), center=True)
+    w2 = O.istft_manual(spec)
+    assert w1.shape == (1, 256 * 23)
+    assert np.abs(w1.numpy() - g["wav"]).max() < 5e-5 * max(1.0, np.abs(g["wav"]).max())
+    assert (w1 - w2).abs().max() < 5e-5 * max(1.0, float(w1.abs().max()))
+
+
+def test_vocos_oracle_golden_roundtrip():
+    vcfg = config.VOCOS_TINY
+    vsd = synth.synth_vocos_state_dict(vcfg, seed=1)
+    mel = O.vocos_mel(synth.synth_wave(256 * 80, seed=5))
+    wav = O.vocos_decode(vsd, mel, vcfg.num_layers)
+    assert wav.shape == (1, 256 * (mel.shape[-1] - 1))
+    assert np.abs(wav.numpy() - gold("vocos_tiny")["wav"]).max() < 1e-6
+
+
+def test_time_grid():
+    t = O.time_grid(16, None)
+    assert torch.allclose(t * 32, torch.tensor([0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32.0]))
+    assert torch.allclose(O.time_grid(32, None), torch.linspace(0, 1, 33))
+    ts = O.time_grid(16, -1.0)
+    assert torch.allclose(ts, 1 - torch.cos(torch.pi / 2 * t), atol=1e-6)
+    assert ts[0] == 0 and abs(float(ts[-1]) - 1.0) < 1e-6
+
+
+def test_noise_is_reference_stream():
+    y = O.make_noise(torch.tensor([5, 3]), 100, seed=3)
+    torch.manual_seed(3)
+    r = torch.randn(5, 100)
+    assert torch.equal(y[0], r)
+    torch.manual_seed(3)
+    r3 = torch.randn(3, 100)  # per-sample reseed (cfm.py:197-200); NOT a prefix of the longer draw (vectorised normal fill)
+    assert torch.equal(y[1, :3], r3) and torch.count_nonzero(y[1, 3:]) == 0
+
+
+@pytest.mark.skipif(not ref_shims.reference_available(), reason="/root/reference not present (GPU box)")
+def test_oracle_matches_live_reference():
+    c = MG.CASES["tiny_v1_ragged_b2"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
+    model = MG.build_reference(cfg, sd)
+    with torch.no_grad():
+        out, traj = model.sample(wav, text, duration, lens=lens, **c["kw"])
+    out_o, traj_o = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+    assert (out - out_o).abs().max() < TOL and (traj - traj_o).abs().max() < TOL
