@@ -369,6 +369,7 @@ int finalize_impl(f5hip_ctx* ctx) {
   }
   HIPCHK(init_gemm_kernels());
   HIPCHK(init_convpos_kernels());
+  HIPCHK(init_attention_kernels());
   HIPCHK(hipDeviceSynchronize());
   ctx->finalized = true;
   return F5HIP_OK;
@@ -443,7 +444,9 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
     }
     ENS(scores, (int64_t)2 * B * c.heads * n * np * 4);
   } else {
-    ENS(q16, M * inner * 2); ENS(k16, M * inner * 2); ENS(v16, M * inner * 2);
+    const int64_t ldv = (n + 7) & ~7;
+    ENS(q16, M * inner * 2); ENS(k16, M * inner * 2); ENS(vt16, (int64_t)2 * B * inner * ldv * 2);
+    if (op == OP_F16X3) { ENS(q16_lo, M * inner * 2); ENS(k16_lo, M * inner * 2); ENS(vt16_lo, (int64_t)2 * B * inner * ldv * 2); }
   }
 #undef ENS
   if (moved) ctx->ws_epoch++;
@@ -559,7 +562,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
       e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = n; e.heads = H; e.dh = dh;
       e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
       if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (n + 3) & ~3; }
-      else { e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.v16 = ctx->v16.as<f16>(); }
+      else {
+        e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (n + 7) & ~7;
+        if (op == OP_F16X3) { e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>(); e.vt16_lo = ctx->vt16_lo.as<f16>(); }
+      }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
     {
@@ -580,7 +586,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
         e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
         HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
       } else {
-        HIPCHK(launch_flash_attn(ctx->q16.as<f16>(), ctx->k16.as<f16>(), ctx->v16.as<f16>(), 2 * B, H, n, kvlen, o_hi, o_lo, st));
+        const bool x3 = op == OP_F16X3;
+        HIPCHK(launch_flash_attn(x3 ? 3 : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
+                                 x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
+                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st));
       }
     }
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
@@ -690,7 +699,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
                     &ctx->mods, &ctx->fmods, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->a_lo, &ctx->o32, &ctx->o_hi, &ctx->o_lo, &ctx->f32, &ctx->f_hi, &ctx->f_lo, &ctx->q32, &ctx->k32,
-                    &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->v16, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
+                    &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
                     &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes};
   for (DevBuf* b : bufs) b->release();
   if (ctx->blob) (void)hipFree(ctx->blob);
@@ -751,7 +760,7 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   const std::string k = key;
   if (k == "use_graph") ctx->use_graph = value != 0;
   else if (k == "profile") ctx->profile = value != 0;
-  else if (k == "attn_impl") ctx->attn_impl = (int)value;
+  else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
   return F5HIP_OK;
 }

@@ -1,6 +1,281 @@
-// attention.hip — flash-style attention (fp16 MFMA); see DESIGN.md.  (placeholder until the kernel lands)
+// attention.hip — flash-style non-causal self-attention over mel frames for gfx950 (dh = 64).
+//
+// Replaces F.scaled_dot_product_attention at reference src/f5_tts/model/modules.py:511-520 (the q/k/v
+// head split + rope of :481-509 are fused into the QKV GEMM epilogue, gemm.h EpiQKV).
+//
+// One workgroup = one 128-row query block of one (batch', head): 4 waves x 32 query rows.  Keys/values are
+// walked in 64-key tiles, double-buffered in LDS, with the next tile's global loads in flight in registers
+// during the MFMAs of the current one.  Everything a query row needs lives in ONE lane pair (l, l^32):
+//   S^T = K . Q^T   (v_mfma_f32_32x32x16_f16, A = K tile rows, B = Q rows held in registers)  -> lane (q = l&31, hi = l>>5)
+//                    owns scores of keys (r&3) + 8*(r>>2) + 4*hi of each 32-key block: the row max / row sum are
+//                    in-lane reductions plus one lane^32 exchange; no LDS round trip for P.
+//   O^T = V^T . P^T (A = V^T tile rows, B = P of the lane's own row)                          -> lane owns O[q][d-subset]:
+//                    the online-softmax rescale is a lane-local multiply.
+// The dot product over keys is order-free, so P's registers are used as the B fragment as they are and the V^T
+// fragment is read in the matching key order (two ds_read_b64 per fragment) — no cross-lane shuffles for P.
+// V arrives transposed ([BH, 64, ldv], written by the QKV epilogue) so both tiles are plain 16-byte row copies.
+//
+// NSPLIT == 3: fp16 hi/lo split operands (q, k, v and P), 3 MFMAs per product, ~fp32 accuracy (parity mode
+// "fp16x3"); NSPLIT == 1: plain fp16 operands.  Softmax statistics, P and O accumulate in fp32 in both.
+#include <math.h>
+
 #include "kernels.h"
-bool flash_attn_available() { return false; }
-hipError_t launch_flash_attn(const f16*, const f16*, const f16*, int, int, int, const int32_t*, f16*, f16*, hipStream_t) {
-  return hipErrorNotSupported;
+
+namespace {
+
+constexpr int QB = 128;              // query rows per workgroup
+constexpr int KT = 64;               // keys per tile
+constexpr int K_ROWB = 144;          // K tile LDS row: 64 halves + 16 B pad (conflict-free 32-row ds_read_b128)
+constexpr int V_ROWB = 136;          // V^T tile LDS row: 64 halves + 8 B pad (conflict-free 32-row ds_read_b64)
+constexpr int K_PLANE = KT * K_ROWB;
+constexpr int V_PLANE = 64 * V_ROWB;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct FlashArgs {
+  const f16 *q, *q_lo, *k, *k_lo, *vt, *vt_lo;
+  f16 *o, *o_lo;
+  const int32_t* kvlen;  // per batch' or null
+  int n, ldv, heads, nqb, nwg;
+};
+
+template <int NSPLIT>
+constexpr int flash_lds_bytes() {
+  return 2 * (NSPLIT == 3 ? 2 : 1) * (K_PLANE + V_PLANE);
+}
+
+__device__ __forceinline__ uint4 zero_tail_halves(uint4 v, int first, int limit) {
+  // keep halves whose key index (first + e) < limit
+  Frag f;
+  f.u = v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (first + e >= limit) f.h[e] = (f16)0.f;
+  return f.u;
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
+  constexpr int NPL = NSPLIT == 3 ? 2 : 1;
+  constexpr int STAGE = NPL * (K_PLANE + V_PLANE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, ql = lane & 31;
+  // XCD-aware placement: block b runs on XCD b % 8 (observed; speed only) -> give each XCD a contiguous range of
+  // (batch', head) so the query blocks sharing one K/V slab hit the same L2.  Bijective for any grid size.
+  const int bid = blockIdx.x;
+  const int q8 = a.nwg >> 3, r8 = a.nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int bh = L / a.nqb, qb = L - bh * a.nqb;
+  const int bp = bh / a.heads, hh = bh - bp * a.heads;
+  const int n = a.n;
+  const int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n;
+  const int ntile = (kv_end + KT - 1) / KT;
+
+  const f16* Kp[NPL];
+  const f16* Vp[NPL];
+  const f16* Qp[NPL];
+  Kp[0] = a.k + (int64_t)bh * n * 64;
+  Vp[0] = a.vt + (int64_t)bh * 64 * a.ldv;
+  Qp[0] = a.q + (int64_t)bh * n * 64;
+  if constexpr (NPL == 2) {
+    Kp[1] = a.k_lo + (int64_t)bh * n * 64;
+    Vp[1] = a.vt_lo + (int64_t)bh * 64 * a.ldv;
+    Qp[1] = a.q_lo + (int64_t)bh * n * 64;
+  }
+
+  // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]
+  const int qrow = qb * QB + wave * 32 + ql;
+  Frag fq[NPL][4];
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      fq[p][ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp[p] + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+
+  uint4 rk[NPL][2], rv[NPL][2];
+  auto load_global = [&](int t) {
+    const int key0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = c & 7;
+      const bool okk = key0 + row < n;           // K: tile row = key
+      const int vkey = key0 + col * 8;           // V^T: tile row = d, 8 consecutive keys per chunk
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) {
+        rk[p][i] = okk ? *reinterpret_cast<const uint4*>(Kp[p] + (int64_t)(key0 + row) * 64 + col * 8) : make_uint4(0, 0, 0, 0);
+        uint4 v = vkey < n ? *reinterpret_cast<const uint4*>(Vp[p] + (int64_t)row * a.ldv + vkey) : make_uint4(0, 0, 0, 0);
+        if (vkey + 8 > n && vkey < n) v = zero_tail_halves(v, vkey, n);  // pad columns of the V^T slab are never written
+        rv[p][i] = v;
+      }
+    }
+  };
+  auto store_lds = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 256, row = c >> 3, col = c & 7;
+        *reinterpret_cast<uint4*>(base + p * K_PLANE + row * K_ROWB + col * 16) = rk[p][i];
+        char* vd = base + NPL * K_PLANE + p * V_PLANE + row * V_ROWB + col * 16;  // 8-byte aligned rows
+        *reinterpret_cast<uint2*>(vd) = make_uint2(rv[p][i].x, rv[p][i].y);
+        *reinterpret_cast<uint2*>(vd + 8) = make_uint2(rv[p][i].z, rv[p][i].w);
+      }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    if (t + 1 < ntile) load_global(t + 1);
+    const char* base = smem + (t & 1) * STAGE;
+    const char* sK = base + ql * K_ROWB + hi * 16;
+    const char* sV = base + NPL * K_PLANE + ql * V_ROWB + hi * 8;
+
+    // ---- S^T = K . Q^T for the 64 keys of the tile --------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag fk[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) fk[p].u = *reinterpret_cast<const uint4*>(sK + p * K_PLANE + kb * 32 * K_ROWB + ks * 32);
+        Mma32<f16>::mma(s[kb], fk[0], fq[0][ks]);
+        if constexpr (NPL == 2) {
+          Mma32<f16>::mma(s[kb], fk[0], fq[1][ks]);  // K_hi . Q_lo
+          Mma32<f16>::mma(s[kb], fk[1], fq[0][ks]);  // K_lo . Q_hi
+        }
+      }
+
+    // ---- online softmax (fp32), lane-local per query row ----------------------------------------------
+    if ((t + 1) * KT > kv_end) {  // tail tile: keys >= kv_end do not exist / are masked
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= kv_end) s[kb][r] = -INFINITY;
+        }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    const float mb = m_new * LOG2E;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = exp2f(fmaf(s[kb][r], LOG2E, -mb));
+        s[kb][r] = p;
+        rs += p;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+    // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // 16-key groups of the tile; P registers 8*(g&1) .. +7 of s[g>>1]
+      Frag fp[NPL];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = s[g >> 1][8 * (g & 1) + e];
+        const f16 ph = (f16)p;
+        fp[0].h[e] = ph;
+        if constexpr (NPL == 2) fp[1].h[e] = (f16)(p - (float)ph);
+      }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        Frag fv[NPL];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          const char* src = sV + p * V_PLANE + db * 32 * V_ROWB + g * 32;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(src);       // keys 16g + 4hi + 0..3
+          const uint2 v1 = *reinterpret_cast<const uint2*>(src + 16);  // keys 16g + 8 + 4hi + 0..3
+          fv[p].u = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        }
+        Mma32<f16>::mma(o[db], fv[0], fp[0]);
+        if constexpr (NPL == 2) {
+          Mma32<f16>::mma(o[db], fv[0], fp[1]);  // V_hi . P_lo
+          Mma32<f16>::mma(o[db], fv[1], fp[0]);  // V_lo . P_hi
+        }
+      }
+    }
+
+    if (t + 1 < ntile) store_lds((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane (q, hi) owns O[q][32 db + 8 c + 4 hi + 0..3] --------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (qrow < n) {
+    const float inv = 1.0f / l_tot;
+    const int64_t orow = ((int64_t)bp * n + qrow) * ((int64_t)a.heads * 64) + (int64_t)hh * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = db * 32 + 8 * c + 4 * hi;
+        f16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[db][4 * c + e] * inv;
+          f16 h, l;
+          split_f16(v, h, l);
+          oh[e] = h;
+          ol[e] = l;
+        }
+        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
+        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
+      }
+  }
+}
+
+template <int NSPLIT>
+hipError_t launch(const FlashArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(flash_attn_kernel<NSPLIT>, dim3(a.nwg), dim3(256), flash_lds_bytes<NSPLIT>(), s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool flash_attn_available() { return true; }
+
+hipError_t init_attention_kernels() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     flash_lds_bytes<1>());
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             flash_lds_bytes<3>());
+}
+
+hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
+                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s) {
+  FlashArgs a{};
+  a.q = q; a.q_lo = q_lo; a.k = k; a.k_lo = k_lo; a.vt = vt; a.vt_lo = vt_lo;
+  a.o = o16; a.o_lo = o16_lo; a.kvlen = kvlen;
+  a.n = n; a.ldv = ldv; a.heads = heads;
+  a.nqb = (n + QB - 1) / QB;
+  a.nwg = Bp * heads * a.nqb;
+  if (nsplit == 3) {
+    if (!q_lo || !k_lo || !vt_lo) return hipErrorInvalidValue;
+    return launch<3>(a, s);
+  }
+  return launch<1>(a, s);
 }

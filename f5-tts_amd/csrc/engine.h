@@ -127,7 +127,7 @@ struct f5hip_ctx {
   DevBuf tx, ta, th, tg, sumsq;
   DevBuf step_cond, cconst, y, h, c1, x;
   DevBuf a32, a_hi, a_lo, o32, o_hi, o_lo, f32, f_hi, f_lo;
-  DevBuf q32, k32, vt32, scores, q16, k16, v16;
+  DevBuf q32, k32, vt32, scores, q16, k16, vt16, q16_lo, k16_lo, vt16_lo;
   DevBuf vel, rope, dbg_vel;
   // vocos workspace
   DevBuf vcol, vx, va, vh, vlogits, vframes;

@@ -93,7 +93,8 @@ struct EpiStore {
 // QKV epilogue: bias, rotary embedding on (2i,2i+1) pairs of q and k (x_transformers
 // apply_rotary_pos_emb, reference call sites model/modules.py:503-509), q * scale, scatter to
 // per-head layouts.  n in [0, 3*inner): n / inner selects q|k|v.
-//   half mode  (q16 != null): q16/k16/v16 [B', H, nseq, dh] f16
+//   half mode  (q16 != null): q16/k16 [B'*H, nseq, dh] f16, vt16 [B'*H, dh, ldvt] f16 (V transposed for the
+//                              flash kernel's V^T tiles); optional *_lo planes (fp16 hi/lo split)
 //   float mode (q32 != null): q32/k32 [B'*H, nseq, dh] f32, vt32 [B'*H, dh, ldvt] f32 (V transposed)
 struct EpiQKV {
   const float* bias;    // [3*inner]
@@ -101,7 +102,8 @@ struct EpiQKV {
   int nseq, heads, dh;
   int pe_heads;         // -1 = all
   float qscale;
-  f16 *q16, *k16, *v16;
+  f16 *q16, *k16, *vt16;
+  f16 *q16_lo, *k16_lo, *vt16_lo;
   float *q32, *k32, *vt32;
   int64_t ldvt;
 
@@ -122,9 +124,21 @@ struct EpiQKV {
     if (which == 0) { x[0] *= qscale; x[1] *= qscale; x[2] *= qscale; x[3] *= qscale; }
     const int64_t bh = (int64_t)bp * heads + hh;
     if (q16) {
-      f16* dst = (which == 0 ? q16 : which == 1 ? k16 : v16) + (bh * nseq + pos) * dh + d;
-      f16x4 hv = {(f16)x[0], (f16)x[1], (f16)x[2], (f16)x[3]};
-      *reinterpret_cast<f16x4*>(dst) = hv;
+      f16x4 hv, lv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hv[e] = h; lv[e] = l; }
+      if (which < 2) {
+        const int64_t off = (bh * nseq + pos) * dh + d;
+        *reinterpret_cast<f16x4*>((which == 0 ? q16 : k16) + off) = hv;
+        if (q16_lo) *reinterpret_cast<f16x4*>((which == 0 ? q16_lo : k16_lo) + off) = lv;
+      } else {
+        const int64_t off = (bh * dh + d) * ldvt + pos;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vt16[off + e * ldvt] = hv[e];
+          if (vt16_lo) vt16_lo[off + e * ldvt] = lv[e];
+        }
+      }
     } else {
       if (which < 2) {
         float* dst = (which == 0 ? q32 : k32) + (bh * nseq + pos) * dh + d;

@@ -68,11 +68,13 @@ hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* w
                           hipStream_t s);
 
 // ---- attention.hip ----------------------------------------------------------------------------
-// flash-style non-causal attention, fp16 operands / fp32 softmax+accumulate.
-//   q,k,v [BH, n, 64] f16 (q pre-scaled); o16(/lo) [B', n, H*64]; kvlen per batch' or null
+// flash-style non-causal attention, fp16 operands (nsplit 1) or fp16 hi/lo split operands (nsplit 3), fp32 softmax+accumulate.
+//   q,k [BH, n, 64] f16 (q pre-scaled); vt [BH, 64, ldv] f16 (V transposed, ldv % 8 == 0); o16(/lo) [B', n, H*64];
+//   kvlen per batch' or null.  *_lo planes are required for nsplit == 3.
 bool flash_attn_available();
-hipError_t launch_flash_attn(const f16* q, const f16* k, const f16* v, int Bp, int heads, int n, const int32_t* kvlen,
-                             f16* o16, f16* o16_lo, hipStream_t s);
+hipError_t init_attention_kernels();
+hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
+                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s);
 
 // ---- audio.hip --------------------------------------------------------------------------------
 struct AudioTables {

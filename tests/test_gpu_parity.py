@@ -192,6 +192,56 @@ def test_graph_replay_equals_eager(engines):
     assert torch.equal(eager, g1) and torch.equal(g1, g2)
 
 
+def test_flash_attention_equals_materialised_attention(engines):
+    """The flash kernel (attention.hip) against the materialised-score fp32 attention (three GEMM/softmax launches)
+    inside the same fp16x3 pipeline, at a frame count that is neither a multiple of the 64-key tile nor of the
+    128-row query block."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1)
+    wav = synth.synth_wave(256 * 45, seed=21)
+    text = synth.synth_text_ids(1, 50, cfg.text_num_embeds, seed=22)
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)
+    model = F5HipCFM(eng, precision="fp16x3")
+    try:
+        eng.set_option("attn_impl", 1)
+        exact, _ = model.sample(wav.cuda(), text, 333, **kw)
+        eng.set_option("attn_impl", 2)
+        flash, _ = model.sample(wav.cuda(), text, 333, **kw)
+    finally:
+        eng.set_option("attn_impl", 0)
+    assert maxerr(flash, exact.cpu()) < 5e-5
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", TIGHT)])
+def test_key_padding_mask_ragged_batch(prec, tol):
+    """attn_mask_enabled=True (reference modules.py:513-516): keys beyond each utterance's duration are masked —
+    the kvlen path of both attention implementations, on a ragged batch."""
+    from dataclasses import replace
+
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    cfg = replace(config.DIT_TINY, attn_mask_enabled=True)
+    sd = synth.synth_dit_state_dict(cfg, seed=4)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(sd)
+    try:
+        wav = synth.synth_wave(256 * 40, seed=31, batch=3)
+        text = synth.synth_text_ids(3, 30, cfg.text_num_embeds, seed=32)
+        text[1, 20:] = -1
+        duration = torch.tensor([150, 97, 131])
+        lens = torch.tensor([41, 30, 35])
+        kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+        out, _ = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, lens=lens, **kw)
+        ref, _ = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **kw)
+        for b in range(3):  # rows beyond an utterance's duration are padding in both
+            d = int(duration[b])
+            assert maxerr(out[b, :d], ref[b, :d]) < tol
+    finally:
+        eng.close()
+
+
 def test_determinism_and_batch_consistency(engines):
     """Same inputs twice -> bit-identical; a fixed-length batch of identical utterances gives identical rows."""
     from f5_tts_amd.engine import F5HipCFM

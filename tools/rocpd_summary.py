@@ -1,0 +1,49 @@
+"""Summarise a rocprofv3 rocpd (.db) kernel trace into a per-kernel stats table (the `--stats` view):
+calls, total/avg/min/max duration, share of GPU time.  Usage: python tools/rocpd_summary.py results.db > profiles/x.md"""
+import re
+import sqlite3
+import subprocess
+import sys
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\s*\[clone .*\]$", "", name)
+    m = re.match(r"(?:void\s+)?([\w:]+)(<.*>)?\(", name)
+    if m:
+        t = m.group(2) or ""
+        if len(t) > 60:
+            t = t[:57] + "...>"
+        return m.group(1) + t
+    return name[:90]
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else "kernel_name"
+    rows = c.execute(f"select {name_col}, start, end from kernels").fetchall()
+    agg = {}
+    dm = demangle(sorted({r[0] for r in rows}))
+    for n, s, e in rows:
+        a = agg.setdefault(short(dm[n]), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    print("| kernel | calls | total ms | avg us | min us | max us | % GPU time |")
+    print("|---|---:|---:|---:|---:|---:|---:|")
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"| `{k}` | {a[0]} | {a[1] / 1e6:.3f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / tot:.2f} |")
+    print(f"\ntotal kernel time {tot / 1e6:.3f} ms over {len(rows)} dispatches")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
