@@ -209,6 +209,11 @@ EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_N
 
 double gemm_flops(int64_t M, int64_t N, int64_t K) { return 2.0 * (double)M * (double)N * (double)K; }
 
+// weight operand of a block GEMM in the given operand mode: fp32 blob rows, plain fp16 rows, or packed hi/lo rows
+const void* wsel(int op, const float* w32, const f16* hi, const f16* pk) {
+  return op == OP_F32 ? (const void*)w32 : op == OP_F16 ? (const void*)hi : (const void*)pk;
+}
+
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
 
 // ---- finalize: derived layouts -------------------------------------------------------------------
@@ -222,7 +227,8 @@ int finalize_impl(f5hip_ctx* ctx) {
 
   // f16 hi/lo copies of the per-step GEMM weights
   const int64_t per_block = 3 * inner * D + D * inner + F * D + D * F;
-  HIPCHK(ctx->half_pool.ensure((size_t)(per_block * c.depth * 2) * sizeof(f16)));
+  if (D % 32 || inner % 32 || F % 32) FAIL(F5HIP_ERR_UNSUPPORTED, "dim, heads*dim_head and ff_inner must be multiples of 32 (packed fp16x3 operand rows)");
+  HIPCHK(ctx->half_pool.ensure((size_t)(per_block * c.depth * 3) * sizeof(f16)));  // plain hi + packed hi/lo
   f16* hp = ctx->half_pool.as<f16>();
   ctx->blocks.assign(c.depth, BlockW{});
   for (int i = 0; i < c.depth; ++i) {
@@ -236,23 +242,26 @@ int finalize_impl(f5hip_ctx* ctx) {
     bw.b1 = W(ctx, b + "ff.ff.0.0.bias");
     bw.w2 = W(ctx, b + "ff.ff.2.weight");
     bw.b2 = W(ctx, b + "ff.ff.2.bias");
-    auto carve = [&](const float* src, int64_t n, f16*& hi, f16*& lo) -> hipError_t {
-      hi = hp; hp += n;
-      lo = hp; hp += n;
-      return launch_split_f16(src, n, 1.0f, hi, lo, st);
+    auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk) -> hipError_t {
+      hi = hp; hp += rows * K;
+      pk = hp; hp += 2 * rows * K;
+      hipError_t e = launch_split_f16(src, rows * K, 1.0f, hi, nullptr, st);
+      if (e != hipSuccess) return e;
+      return launch_split_f16_packed(src, rows, (int)K, pk, st);
     };
-    HIPCHK(carve(bw.wqkv, 3 * inner * D, bw.wqkv_hi, bw.wqkv_lo));
-    HIPCHK(carve(bw.wo, D * inner, bw.wo_hi, bw.wo_lo));
-    HIPCHK(carve(bw.w1, F * D, bw.w1_hi, bw.w1_lo));
-    HIPCHK(carve(bw.w2, D * F, bw.w2_hi, bw.w2_lo));
+    HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk));
+    HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk));
+    HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk));
+    HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk));
   }
   ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm.linear.weight");
   ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm.linear.bias");
   {
     const int64_t n = (int64_t)c.mel_dim * D;
     HIPCHK(ctx->wp_hi.ensure(n * sizeof(f16)));
-    HIPCHK(ctx->wp_lo.ensure(n * sizeof(f16)));
-    HIPCHK(launch_split_f16(W(ctx, p + "proj_out.weight"), n, 1.0f, ctx->wp_hi.as<f16>(), ctx->wp_lo.as<f16>(), st));
+    HIPCHK(ctx->wp_pk.ensure(2 * n * sizeof(f16)));
+    HIPCHK(launch_split_f16(W(ctx, p + "proj_out.weight"), n, 1.0f, ctx->wp_hi.as<f16>(), nullptr, st));
+    HIPCHK(launch_split_f16_packed(W(ctx, p + "proj_out.weight"), c.mel_dim, (int)D, ctx->wp_pk.as<f16>(), st));
   }
   // conv_pos weights -> per-tap operand tiles
   const int cpg = (int)(D / c.conv_pos_groups);
@@ -431,8 +440,8 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
   if (op == OP_F32) {
     ENS(a32, M * D * 4); ENS(o32, M * inner * 4); ENS(f32, M * F * 4);
   } else {
-    ENS(a_hi, M * D * 2); ENS(o_hi, M * inner * 2); ENS(f_hi, M * F * 2);
-    if (op == OP_F16X3) { ENS(a_lo, M * D * 2); ENS(o_lo, M * inner * 2); ENS(f_lo, M * F * 2); }
+    const int64_t pl = op == OP_F16X3 ? 2 : 1;  // packed hi/lo rows are twice as long
+    ENS(a_hi, M * D * 2 * pl); ENS(o_hi, M * inner * 2 * pl); ENS(f_hi, M * F * 2 * pl);
   }
   if (exact_attn) {
     const int64_t np = (n + 3) & ~3;
@@ -536,14 +545,16 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   float* a32 = op == OP_F32 ? ctx->a32.as<float>() : nullptr;
   f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() : nullptr;
-  f16* a_lo = op == OP_F16X3 ? ctx->a_lo.as<f16>() : nullptr;
+  const int pk = op == OP_F16X3 ? 1 : 0;      // fp16x3 operands are packed hi/lo rows: lo plane = hi + 32 halves, row stride 2K
+  f16* a_lo = pk ? a_hi + 32 : nullptr;
   const void* A = op == OP_F32 ? (const void*)a32 : (const void*)a_hi;
   float* o32 = op == OP_F32 ? ctx->o32.as<float>() : nullptr;
   f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() : nullptr;
-  f16* o_lo = op == OP_F16X3 ? ctx->o_lo.as<f16>() : nullptr;
+  f16* o_lo = pk ? o_hi + 32 : nullptr;
   float* f32 = op == OP_F32 ? ctx->f32.as<float>() : nullptr;
   f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() : nullptr;
-  f16* f_lo = op == OP_F16X3 ? ctx->f_lo.as<f16>() : nullptr;
+  f16* f_lo = pk ? f_hi + 32 : nullptr;
+  const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
   const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() : nullptr;
   const double ln_bytes = (double)M * D * (4 + wbytes * (op == OP_F16X3 ? 2 : 1));
 
@@ -552,12 +563,11 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
     const float* md = mods_step + (int64_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:323)
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st));
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st, pk, ldA));
     }
     {  // fused to_q|to_k|to_v + rope + 1/sqrt(dh) (modules.py:481-509; SDPA default scale)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-      GemmCore g = core(A, D, op == OP_F32 ? (const void*)bw.wqkv : (const void*)bw.wqkv_hi, D, M, 3 * inner, D);
-      g.A_lo = a_lo; g.W_lo = bw.wqkv_lo;
+      GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
       EpiQKV e{};
       e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = n; e.heads = H; e.dh = dh;
       e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
@@ -582,41 +592,40 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
         g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
         g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
         EpiStore e2 = epi_store(o32, inner, nullptr);
-        e2.out16 = o_hi; e2.out16_lo = o_lo;
         e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
+        if (op != OP_F32) {  // fp16 operand of the out-projection: same (batch', head) addressing, packed rows in fp16x3 mode
+          e2.out16 = o_hi; e2.out16_lo = o_lo; e2.pk16 = pk; e2.ldo16 = ldO;
+          e2.so1_16 = (int64_t)n * ldO; e2.so2_16 = dh;
+        }
         HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
       } else {
-        const bool x3 = op == OP_F16X3;
+        const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
         HIPCHK(launch_flash_attn(x3 ? 3 : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
                                  x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
-                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st));
+                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st, pk));
       }
     }
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, inner, op == OP_F32 ? (const void*)bw.wo : (const void*)bw.wo_hi,
-                        inner, M, D, inner);
-      g.A_lo = o_lo; g.W_lo = bw.wo_lo;
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, a32, a_hi, a_lo, D, st));
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, a32, a_hi, a_lo, D, st, pk, ldA));
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = core(A, D, op == OP_F32 ? (const void*)bw.w1 : (const void*)bw.w1_hi, D, M, F, D);
-      g.A_lo = a_lo; g.W_lo = bw.w1_lo;
+      GemmCore g = core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
-      e.out16 = f_hi; e.out16_lo = f_lo;
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, F, op == OP_F32 ? (const void*)bw.w2 : (const void*)bw.w2_hi, F, M, D, F);
-      g.A_lo = f_lo; g.W_lo = bw.w2_lo;
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -626,11 +635,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
     const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, fm, fm + D, a32, a_hi, a_lo, D, st));
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, fm, fm + D, a32, a_hi, a_lo, D, st, pk, ldA));
     }
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, mel, D), 0);
-    GemmCore g = core(A, D, op == OP_F32 ? (const void*)W(ctx, p + "proj_out.weight") : (const void*)ctx->wp_hi.p, D, M, mel, D);
-    g.A_lo = a_lo; g.W_lo = ctx->wp_lo.p;
+    GemmCore g = core(A, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
     HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
   {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
@@ -694,11 +702,11 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
-                    &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_lo, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
+                    &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
                     &ctx->mods, &ctx->fmods, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
-                    &ctx->a_hi, &ctx->a_lo, &ctx->o32, &ctx->o_hi, &ctx->o_lo, &ctx->f32, &ctx->f_hi, &ctx->f_lo, &ctx->q32, &ctx->k32,
+                    &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
                     &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes};
   for (DevBuf* b : bufs) b->release();
@@ -818,6 +826,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   hipStream_t st = (hipStream_t)stream;
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
+  // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 modes -> flash with the mode's operands), 1 force materialised,
+  // 2 force flash, 3 flash with plain fp16 operands even in fp16x3 mode
   const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
   const int mel = c.mel_dim, D = c.dim;

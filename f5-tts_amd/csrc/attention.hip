@@ -35,7 +35,7 @@ struct FlashArgs {
   const f16 *q, *q_lo, *k, *k_lo, *vt, *vt_lo;
   f16 *o, *o_lo;
   const int32_t* kvlen;  // per batch' or null
-  int n, ldv, heads, nqb, nwg;
+  int n, ldv, heads, nqb, nwg, o_packed;
 };
 
 template <int NSPLIT>
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qrow < n) {
     const float inv = 1.0f / l_tot;
-    const int64_t orow = ((int64_t)bp * n + qrow) * ((int64_t)a.heads * 64) + (int64_t)hh * 64;
+    const int64_t orow = ((int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const int d = db * 32 + 8 * c + 4 * hi;
+        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
         f16x4 oh, ol;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -266,8 +266,9 @@ hipError_t init_attention_kernels() {
 }
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
-                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s) {
+                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed) {
   FlashArgs a{};
+  a.o_packed = o_packed;
   a.q = q; a.q_lo = q_lo; a.k = k; a.k_lo = k_lo; a.vt = vt; a.vt_lo = vt_lo;
   a.o = o16; a.o_lo = o16_lo; a.kvlen = kvlen;
   a.n = n; a.ldv = ldv; a.heads = heads;

@@ -42,21 +42,48 @@ struct Mma32<float> {
 // so a lane owns 4 consecutive output channels of one row per register quad -> 16-byte stores,
 // and rope's (2i, 2i+1) pairs are lane-local.
 
+// buffer-descriptor loads: out-of-range offsets return zeros (hardware bounds check), no predication needed
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+constexpr uint32_t OOB_OFF = 0xFFFFFFF0u;  // >= any num_records used here
+constexpr uint32_t OOB_ROW = 0x80000000u;  // base offset of a non-existent row: stays out of range after adding a k offset
+                                           // (every operand matrix is < 2 GiB; checked by the launchers)
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), /*stride*/ (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buffer_load_b128(BufRsrc r, uint32_t byte_off) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// Packed fp16x3 operand row: k-blocks of 32 elements stored as [32 hi | 32 lo] halves (one 128-byte line per block), so
+// hi(k) sits at pk_off(k) and lo(k) 32 halves later.  pk == 0: plain row (offset k).
+__device__ __host__ __forceinline__ int pk_off(int k, int pk) { return pk ? ((k >> 5) << 6) + (k & 31) : k; }
+
 // activations -------------------------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU_ERF = 2, ACT_GELU_TANH = 3, ACT_MISH = 4 };
 
-__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
+// exp / reciprocal on the hardware transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each): the activation epilogues run once
+// per GEMM output, so libm-grade expf/tanhf/division (30-40 VALU instructions each) would cost as much as a K=1024 main loop.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float act_silu(float x) { return x * fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float act_gelu_tanh(float x) {
-  // torch: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+  // torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3);  0.5*(1+tanh(u)) = 1 - 1/(1+e^{2u})  (no cancellation: the
+  // result is >= 0.5 for u >= 0 and e^{2u}/(1+e^{2u}) is formed directly for u < 0)
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float inner = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  const float u = k0 * (x + k1 * x * x * x);
+  const float e = fast_exp(-2.0f * fabsf(u));           // in (0, 1]
+  const float s = fast_rcp(1.0f + e);                    // sigmoid(2|u|)
+  return x * (u >= 0.f ? s : e * s);                     // sigmoid(2u)
 }
 __device__ __forceinline__ float act_mish(float x) {
-  // x * tanh(softplus(x)); softplus with torch's threshold=20
-  float sp = x > 20.0f ? x : log1pf(expf(x));
-  return x * tanhf(sp);
+  // x * tanh(softplus(x)); with e = e^x: tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2), n = e*(e+2).
+  // torch's softplus threshold (x > 20 -> softplus = x, tanh = 1 in fp32) is kept.
+  const float e = fast_exp(fminf(x, 20.0f));
+  const float n = e * (e + 2.0f);
+  return x > 20.0f ? x : x * n * fast_rcp(n + 2.0f);
 }
 __device__ __forceinline__ float apply_act(int act, float x) {
   switch (act) {

@@ -14,7 +14,8 @@ template <int VPL>  // float4 vectors per lane: D <= 64*4*VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
                                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float* out32, f16* out16, f16* out16_lo, int64_t ldo) {
+                                                         float* out32, f16* out16, f16* out16_lo, int64_t ldo, int pk16,
+                                                         int64_t ldo16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -60,8 +61,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(y[e], h, l); hi[e] = h; lo[e] = l; }
-      *reinterpret_cast<f16x4*>(out16 + o) = hi;
-      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o) = lo;
+      const int64_t o16 = (int64_t)row * ldo16 + pk_off(c, pk16);
+      *reinterpret_cast<f16x4*>(out16 + o16) = hi;
+      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o16) = lo;
     }
   }
 }
@@ -262,6 +264,19 @@ __global__ void rope_table_kernel(const float* inv_freq, int n, int half, float*
   out[2 * (int64_t)i] = cosf(a);
   out[2 * (int64_t)i + 1] = sinf(a);
 }
+// [rows, K] fp32 -> packed fp16x3 operand rows [rows, 2K] ([K/32][32 hi | 32 lo]), K % 32 == 0
+__global__ void split_f16_packed_kernel(const float* src, int64_t rows, int K, f16* dst) {
+  const int64_t n = rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    f16 h, l;
+    split_f16(src[i], h, l);
+    f16* d = dst + r * 2 * K + pk_off(k, 1);
+    d[0] = h;
+    d[32] = l;
+  }
+}
 __global__ void split_f16_kernel(const float* src, int64_t n, float prescale, f16* hi, f16* lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     f16 h, l;
@@ -343,13 +358,14 @@ inline int grid_1d(int64_t total, int block = 256, int cap = 8192) {
 
 hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
                             const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
-                            hipStream_t s) {
+                            hipStream_t s, int pk16, int64_t ldo16) {
   if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
+  if (ldo16 == 0) ldo16 = ldo;
   dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
   return hipGetLastError();
 }
 
@@ -411,6 +427,11 @@ hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStre
 }
 hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out, hipStream_t s) {
   hipLaunchKernelGGL(rope_table_kernel, dim3(grid_1d((int64_t)n * half)), dim3(256), 0, s, inv_freq, n, half, out);
+  return hipGetLastError();
+}
+hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s) {
+  if (K % 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(split_f16_packed_kernel, dim3(grid_1d(rows * K)), dim3(256), 0, s, src, rows, K, dst);
   return hipGetLastError();
 }
 hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s) {

@@ -50,7 +50,8 @@ struct DevBuf {
 
 struct BlockW {  // per DiT block
   const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // fp32 (blob)
-  f16 *wqkv_hi, *wqkv_lo, *wo_hi, *wo_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+  f16 *wqkv_hi, *wo_hi, *w1_hi, *w2_hi;  // plain fp16 rows [N, K]             (precision FP16)
+  f16 *wqkv_pk, *wo_pk, *w1_pk, *w2_pk;  // packed hi/lo rows [N, 2K] (gemm.h) (precision FP16X3)
 };
 struct TextBlockW {
   const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *gamma, *beta, *pw2_w, *pw2_b;
@@ -109,7 +110,7 @@ struct f5hip_ctx {
   std::vector<TextBlockW> tblocks;
   std::vector<VocosLayerW> vlayers;
   DevBuf conv_w32[2], conv_whi[2], conv_wlo[2];
-  DevBuf wp_hi, wp_lo;                 // proj_out f16
+  DevBuf wp_hi, wp_pk;                 // proj_out f16: plain rows, packed hi/lo rows
   DevBuf dwpack;                       // [7,C] depthwise weights (text + vocos)
   DevBuf freqs_cis;                    // [8192, text_dim]
   DevBuf inv_freq;                     // [dh/2]
@@ -126,7 +127,7 @@ struct f5hip_ctx {
   DevBuf tok, valid, textkeep, rowvalid, condmask, kvlen;
   DevBuf tx, ta, th, tg, sumsq;
   DevBuf step_cond, cconst, y, h, c1, x;
-  DevBuf a32, a_hi, a_lo, o32, o_hi, o_lo, f32, f_hi, f_lo;
+  DevBuf a32, a_hi, o32, o_hi, f32, f_hi;  // *_hi: plain fp16 rows, or packed hi/lo rows (twice the size) in fp16x3 mode
   DevBuf q32, k32, vt32, scores, q16, k16, vt16, q16_lo, k16_lo, vt16_lo;
   DevBuf vel, rope, dbg_vel;
   // vocos workspace
@@ -135,7 +136,7 @@ struct f5hip_ctx {
   // options / measurement
   bool use_graph = false;
   bool profile = false;
-  int attn_impl = 0;  // 0 auto (flash for fp16 modes), 1 force exact(materialised), 2 force flash
+  int attn_impl = 0;  // 0 auto (flash for fp16 modes), 1 force exact(materialised), 2 force flash, 3 flash with plain fp16 operands
   KStat stats[KC_COUNT];
   std::vector<ProfRec> prof;
 

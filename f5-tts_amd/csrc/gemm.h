@@ -1,23 +1,26 @@
 // gemm.h — LDS-tiled MFMA GEMM for gfx950:  out[M,N] = epilogue( A[M,K] . W[N,K]^T )
 //
-// Both operands are K-contiguous (torch nn.Linear weight layout [out, in]); tiles of 128 bytes of K
-// per row (64 halves / 32 floats) are staged global -> registers -> LDS (row stride 144 B: the +16 B
-// pad makes the 32-row ds_read_b128 fragment reads conflict-free), double-buffered in LDS with the
-// next tile's global loads in flight during the MFMAs of the current tile.  256 threads = 4 waves as
-// 2(m) x 2(n); each wave owns TM x TN tiles of 32x32 (v_mfma_f32_32x32x16_f16 or 4x
-// v_mfma_f32_32x32x2_f32).  The weight axis is the MFMA "A" operand (accumulator rows) so a lane
-// owns 4 consecutive output channels of one activation row -> 16-byte epilogue accesses.
+// Both operands are K-contiguous (torch nn.Linear weight layout [out, in]).  A k-tile is ONE 128-byte line per row
+// (64 halves, 32 floats, or — fp16x3 — 32 k-elements as [32 hi | 32 lo] halves: the "packed" operand layout, written
+// by every producer of an fp16x3 operand), so global reads are whole cache lines: half-line (64 B) segments reach only
+// ~60 % of the L2->CU rate on MI355X (tools/probes/l2stride.hip).  Tiles are staged global -> registers -> LDS,
+// double-buffered in LDS, with the loads of tile t+2 in flight during the MFMAs of tile t.  The LDS image is
+// unpadded [rows][128 B] with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7: the 32-row ds_read_b128 fragment
+// reads and the 8-lane ds_write_b128 groups are then both bank-conflict free, and the image stays lane-linear
+// (what a direct-to-LDS load needs).  WGM x WGN waves; each wave owns TM x TN tiles of 32x32
+// (v_mfma_f32_32x32x16_f16 or 4x v_mfma_f32_32x32x2_f32).  The weight axis is the MFMA "A" operand (accumulator
+// rows) so a lane owns 4 consecutive output channels of one activation row -> 16-byte epilogue accesses.
 //
 // NSPLIT == 3: fp16 hi/lo split operands, acc += A_hi.W_hi + A_lo.W_hi + A_hi.W_lo (~fp32 accuracy).
 #pragma once
 #include "common.h"
 
 struct GemmCore {
-  const void* A;      // [M, K] activations (hi plane)
-  const void* A_lo;   // lo plane (NSPLIT == 3)
-  const void* W;      // [N, K] weights (hi plane)
+  const void* A;      // [M, K] activations; fp16x3: packed hi/lo rows ([K/32][32 hi | 32 lo], lda >= 2K)
+  const void* A_lo;   // unused (kept for call-site symmetry)
+  const void* W;      // [N, K] weights; fp16x3: packed like A
   const void* W_lo;
-  int64_t lda, ldw;   // row strides in elements
+  int64_t lda, ldw;   // row strides in elements (of the stored type: halves / floats)
   int64_t strideA, strideW;      // blockIdx.z batch strides in elements
   int M, N, K;
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
@@ -46,6 +49,9 @@ struct EpiStore {
   f16* out16;
   f16* out16_lo;
   int64_t ldo;
+  int pk16;           // out16/out16_lo are a packed fp16x3 operand (out16_lo == out16 + 32, row stride ldo16)
+  int64_t ldo16;      // row stride of out16 (0 = ldo)
+  int64_t so1_16, so2_16;  // batch offsets of out16 (used when ldo16 != 0 and zdiv != 0; so2_16 is a k index, packed like n)
   // batch (blockIdx.z) addressing of the outputs/residual: off = (z / zdiv) * so1 + (z % zdiv) * so2
   int zdiv;
   int64_t so1, so2;
@@ -84,8 +90,10 @@ struct EpiStore {
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hi[e] = h; lo[e] = l; }
-      *reinterpret_cast<f16x4*>(out16 + o) = hi;
-      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o) = lo;
+      const int64_t o16 = ldo16 ? (zdiv ? (int64_t)(z / zdiv) * so1_16 : 0) + (int64_t)m * ldo16 + pk_off((zdiv ? (int)((z % zdiv) * so2_16) : 0) + n, pk16)
+                                : o;
+      *reinterpret_cast<f16x4*>(out16 + o16) = hi;
+      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o16) = lo;
     }
   }
 };
@@ -151,75 +159,86 @@ struct EpiQKV {
   }
 };
 
-constexpr int GEMM_ROWB = 144;  // LDS bytes per tile row (128 data + 16 pad)
+constexpr int GEMM_KTB = 128;  // bytes of one operand row per k-tile = one cache line
 
-template <typename T, int NSPLIT, int TM, int TN>
+template <typename T, int NSPLIT, int TM, int TN, int WGM = 2, int WGN = 2>
 constexpr int gemm_lds_bytes() {
-  return 2 * (64 * TM + 64 * TN) * GEMM_ROWB * (NSPLIT == 3 ? 2 : 1);
+  return 2 * (32 * WGM * TM + 32 * WGN * TN) * GEMM_KTB;
 }
 
-template <typename T, int NSPLIT, int TM, int TN, typename Epi>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmCore g, Epi epi) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int KT = 128 / (int)sizeof(T);   // k elements per tile
-  constexpr int KC = 16 / (int)sizeof(T);    // k elements per 16-byte chunk
+// ABL (microbenchmark ablations only): bit0 = no global loads in the k-loop, bit1 = no LDS stores, bit2 = no MFMAs.
+template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi epi) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
-  constexpr int CA = BM * 8 / 256, CW = BN * 8 / 256;  // chunks per thread per plane
-  constexpr int PLANE_A = BM * GEMM_ROWB, PLANE_W = BN * GEMM_ROWB;
-  constexpr int STAGE = NPL * (PLANE_A + PLANE_W);
+  constexpr int CPR = GEMM_KTB / 16;                        // 8 chunks of 16 bytes per tile row
+  constexpr int KSTEPS = NPL == 2 ? 2 : 4;                  // MFMA k-steps per tile (fp16x3: hi chunks 0-3, lo chunks 4-7)
+  constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;     // chunks per thread
+  constexpr int TILE_A = BM * GEMM_KTB, TILE_W = BN * GEMM_KTB;
+  constexpr int STAGE = TILE_A + TILE_W;
+  static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
-
-  const T* Ap[NPL];
-  const T* Wp[NPL];
-  Ap[0] = reinterpret_cast<const T*>(g.A) + (int64_t)z * g.strideA;
-  Wp[0] = reinterpret_cast<const T*>(g.W) + (int64_t)z * g.strideW;
-  if constexpr (NPL == 2) {
-    Ap[1] = reinterpret_cast<const T*>(g.A_lo) + (int64_t)z * g.strideA;
-    Wp[1] = reinterpret_cast<const T*>(g.W_lo) + (int64_t)z * g.strideW;
+  const int wm = wave % WGM, wn = wave / WGM;
+  // Tile order (speed only): blockIdx.x -> XCD = id % 8 (observed dispatch) gets a contiguous run of tiles, channel tiles
+  // fastest, so the workgroups resident on one XCD share a few activation row-panels and sweep the weight panel through
+  // that XCD's L2; each activation panel is fetched from HBM/MALL by one XCD only.  Bijective for any tile count.
+  const int z = blockIdx.z;
+  int m0, n0;
+  {
+    const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
+    const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mt = L / nt;
+    m0 = mt * BM;
+    n0 = (L - mt * nt) * BN;
   }
 
-  uint4 ra[NPL][CA], rw[NPL][CW];
+  // Operands are read through buffer descriptors: a 16-byte chunk outside the matrix (row >= rows, k >= K) gets its
+  // offset forced out of range and the hardware returns zeros — the loads are unconditional and branch-free, so nothing
+  // waits on them until the matching LDS store (a predicated `ok ? load : 0` makes hipcc branch around every load and
+  // drain vmcnt(0) before re-initialising the destination registers).
+  const int kbytes = g.K * (int)sizeof(T) * NPL;  // bytes of one operand row
+  const uint32_t a_bytes = (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * (int64_t)sizeof(T) + kbytes);
+  const uint32_t w_bytes = (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * (int64_t)sizeof(T) + kbytes);
+  const BufRsrc Ar = make_rsrc(reinterpret_cast<const T*>(g.A) + (int64_t)z * g.strideA, a_bytes);
+  const BufRsrc Wr = make_rsrc(reinterpret_cast<const T*>(g.W) + (int64_t)z * g.strideW, w_bytes);
+  // Thread t owns LDS chunk slots t, t + NT, ... (linear image); slot (row, pc) holds the row's logical chunk pc ^ swz(row).
+  uint32_t a_off[CA], w_off[CW];
+  int a_c[CA], w_c[CW];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int c = tid + i * NT, row = c / CPR, lc = (c % CPR) ^ ((row >> 1) & 7);
+    a_c[i] = lc * 16;
+    a_off[i] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * (int64_t)sizeof(T) + lc * 16) : OOB_ROW;
+  }
+#pragma unroll
+  for (int i = 0; i < CW; ++i) {
+    const int c = tid + i * NT, row = c / CPR, lc = (c % CPR) ^ ((row >> 1) & 7);
+    w_c[i] = lc * 16;
+    w_off[i] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * (int64_t)sizeof(T) + lc * 16) : OOB_ROW;
+  }
 
-  auto load_global = [&](int kt) {
-    const int kbase = kt * KT;
+  // Two register sets: the global loads of tile t+2 are issued at the top of iteration t and written to LDS at the end of
+  // iteration t+1, so every load has two full compute phases of flight time.  Static set indexing needs the k-loop
+  // unrolled by two.  A tile index past the end reads zeros (k >= K) and is never stored.
+  uint4 ra0[CA], rw0[CW], ra1[CA], rw1[CW];
+
+  auto load_global = [&](int kt, uint4 (&ra)[CA], uint4 (&rw)[CW]) {
+    const int kb = kt * GEMM_KTB;
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int c = tid + i * 256, row = c >> 3, col = (c & 7) * KC;
-      const int gm = m0 + row, gk = kbase + col;
-      const bool ok = gm < g.a_rows && gk < g.K;
+    for (int i = 0; i < CA; ++i) ra[i] = buffer_load_b128(Ar, (kb + a_c[i]) < kbytes ? a_off[i] + (uint32_t)kb : OOB_OFF);
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        ra[p][i] = ok ? *reinterpret_cast<const uint4*>(Ap[p] + (int64_t)gm * g.lda + gk) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < CW; ++i) {
-      const int c = tid + i * 256, row = c >> 3, col = (c & 7) * KC;
-      const int gn = n0 + row, gk = kbase + col;
-      const bool ok = gn < g.w_rows && gk < g.K;
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        rw[p][i] = ok ? *reinterpret_cast<const uint4*>(Wp[p] + (int64_t)gn * g.ldw + gk) : make_uint4(0, 0, 0, 0);
-    }
+    for (int i = 0; i < CW; ++i) rw[i] = buffer_load_b128(Wr, (kb + w_c[i]) < kbytes ? w_off[i] + (uint32_t)kb : OOB_OFF);
   };
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage, const uint4 (&ra)[CA], const uint4 (&rw)[CW]) {
     char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) {
+    for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(base + (tid + i * NT) * 16) = ra[i];
 #pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        const int c = tid + i * 256, row = c >> 3, col = c & 7;
-        *reinterpret_cast<uint4*>(base + p * PLANE_A + row * GEMM_ROWB + col * 16) = ra[p][i];
-      }
-#pragma unroll
-      for (int i = 0; i < CW; ++i) {
-        const int c = tid + i * 256, row = c >> 3, col = c & 7;
-        *reinterpret_cast<uint4*>(base + NPL * PLANE_A + p * PLANE_W + row * GEMM_ROWB + col * 16) = rw[p][i];
-      }
-    }
+    for (int i = 0; i < CW; ++i) *reinterpret_cast<uint4*>(base + TILE_A + (tid + i * NT) * 16) = rw[i];
   };
 
   f32x16 acc[TM][TN];
@@ -230,43 +249,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmCore g, Epi epi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-  const int nkt = (g.K + KT - 1) / KT;
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
-  const int frag_off = (lane & 31) * GEMM_ROWB + (lane >> 5) * 16;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) load_global(kt + 1);
-    const char* base = smem + (kt & 1) * STAGE;
-    const char* sA = base + (wm * 32 * TM) * GEMM_ROWB + frag_off;
-    const char* sW = base + NPL * PLANE_A + (wn * 32 * TN) * GEMM_ROWB + frag_off;
+  // fragment addressing: lane (i = lane & 31, hi = lane >> 5) reads logical chunk 2 ks + hi (+4 for the lo plane) of row i
+  const int frow = (lane & 31) * GEMM_KTB, fswz = ((lane & 31) >> 1) & 7, fhi = lane >> 5;
+  int foff[NPL][KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) foff[p][ks] = frow + (((p * 4 + 2 * ks + fhi) ^ fswz) << 4);
+
+  auto compute = [&](int stage) {
+    const char* sA = smem + stage * STAGE + (wm * 32 * TM) * GEMM_KTB;
+    const char* sW = smem + stage * STAGE + TILE_A + (wn * 32 * TN) * GEMM_KTB;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
       Frag fa[NPL][TM], fw[NPL][TN];
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-          fa[p][j].u = *reinterpret_cast<const uint4*>(sA + p * PLANE_A + j * 32 * GEMM_ROWB + ks * 32);
+        for (int j = 0; j < TM; ++j) fa[p][j].u = *reinterpret_cast<const uint4*>(sA + j * 32 * GEMM_KTB + foff[p][ks]);
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-          fw[p][i].u = *reinterpret_cast<const uint4*>(sW + p * PLANE_W + i * 32 * GEMM_ROWB + ks * 32);
+        for (int i = 0; i < TN; ++i) fw[p][i].u = *reinterpret_cast<const uint4*>(sW + i * 32 * GEMM_KTB + foff[p][ks]);
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-          Mma32<T>::mma(acc[j][i], fw[0][i], fa[0][j]);
-          if constexpr (NPL == 2) {
-            Mma32<T>::mma(acc[j][i], fw[0][i], fa[1][j]);  // W_hi . A_lo
-            Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);  // W_lo . A_hi
+          if constexpr (ABL & 4) {  // keep the fragment reads alive without the MFMAs
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+              asm volatile("" ::"v"(fw[p][i].u.x), "v"(fw[p][i].u.y), "v"(fw[p][i].u.z), "v"(fw[p][i].u.w), "v"(fa[p][j].u.x), "v"(fa[p][j].u.y),
+                           "v"(fa[p][j].u.z), "v"(fa[p][j].u.w));
+          } else {
+            Mma32<T>::mma(acc[j][i], fw[0][i], fa[0][j]);
+            if constexpr (NPL == 2) {
+              Mma32<T>::mma(acc[j][i], fw[0][i], fa[1][j]);  // W_hi . A_lo
+              Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);  // W_lo . A_hi
+            }
           }
         }
     }
-    if (kt + 1 < nkt) store_lds((kt + 1) & 1);
+  };
+
+  const int nkt = (kbytes + GEMM_KTB - 1) / GEMM_KTB;
+  load_global(0, ra0, rw0);
+  load_global(1, ra1, rw1);
+  store_lds(0, ra0, rw0);
+  __syncthreads();
+
+  int kt = 0;
+  for (; kt + 1 < nkt; kt += 2) {
+    // even phase: tile kt in stage 0; set 1 holds tile kt+1 (in flight); set 0 is free
+    if constexpr (!(ABL & 1)) load_global(kt + 2, ra0, rw0);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top of the phase (hipcc otherwise sinks them below the LDS stores)
+    compute(0);
+    if constexpr (!(ABL & 2)) store_lds(1, ra1, rw1);
+    __syncthreads();
+    // odd phase: tile kt+1 in stage 1; set 0 holds tile kt+2; set 1 is free
+    if constexpr (!(ABL & 1)) load_global(kt + 3, ra1, rw1);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(1);
+    if constexpr (!(ABL & 2)) store_lds(0, ra0, rw0);
     __syncthreads();
   }
+  if (kt < nkt) compute(0);  // odd tile count: the last tile sits in stage 0
 
   // epilogue: lane owns row m = .. + (lane & 31), channels n = .. + 8q + 4*(lane>>5) + 0..3
 #pragma unroll

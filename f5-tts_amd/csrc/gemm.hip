@@ -1,52 +1,131 @@
 // gemm.hip — instantiations and launch heuristics of the MFMA GEMM (gemm.h)
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace {
 
-template <typename T, int NSPLIT, int TM, int TN, typename Epi>
+// One tile variant: TM x TN 32x32 tiles per wave, WGM x WGN waves.
+template <int TM_, int TN_, int WGM_, int WGN_>
+struct V {
+  static constexpr int TM = TM_, TN = TN_, WGM = WGM_, WGN = WGN_;
+  static constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
+};
+
+// variant ids (rows x output channels): 0 = 64x128, 1 = 128x64, 2 = 128x128 (4 waves);
+//                                       3 = 256x128, 4 = 128x256 (8 waves), 5 = 256x256 (16 waves)
+// every mode stages one 128-byte line per operand row per k-tile, so LDS per workgroup is the same in all modes
+template <typename T, int NSPLIT, int ID>
+struct Variant;
+#define F5_VARIANT(ID, TM, TN, WGM, WGN)                                                    \
+  template <typename T, int NSPLIT>                                                         \
+  struct Variant<T, NSPLIT, ID> : V<TM, TN, WGM, WGN> {}
+F5_VARIANT(0, 1, 2, 2, 2);
+F5_VARIANT(1, 2, 1, 2, 2);
+F5_VARIANT(2, 2, 2, 2, 2);
+F5_VARIANT(3, 2, 2, 4, 2);
+F5_VARIANT(4, 2, 2, 2, 4);
+F5_VARIANT(5, 2, 2, 4, 4);
+#undef F5_VARIANT
+
+template <typename T, int NSPLIT, int ID, typename Epi>
 hipError_t set_attr() {
-  constexpr int lds = gemm_lds_bytes<T, NSPLIT, TM, TN>();
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, NSPLIT, TM, TN, Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  using C = Variant<T, NSPLIT, ID>;
+  constexpr int lds = gemm_lds_bytes<T, NSPLIT, C::TM, C::TN, C::WGM, C::WGN>();
+  if (lds > 160 * 1024) return hipSuccess;  // variant does not exist in this mode (launch_one rejects it)
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, NSPLIT, C::TM, C::TN, Epi, C::WGM, C::WGN>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+template <typename T, int NSPLIT, typename Epi>
+hipError_t set_attrs_op() {
+  hipError_t e;
+  if ((e = set_attr<T, NSPLIT, 0, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 1, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 2, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 3, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 4, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 5, Epi>()) != hipSuccess) return e;
+  return hipSuccess;
 }
 
 template <typename Epi>
 hipError_t set_attrs_epi() {
   hipError_t e;
-  if ((e = set_attr<float, 1, 1, 2, Epi>()) != hipSuccess) return e;
-  if ((e = set_attr<float, 1, 2, 2, Epi>()) != hipSuccess) return e;
-  if ((e = set_attr<f16, 1, 1, 2, Epi>()) != hipSuccess) return e;
-  if ((e = set_attr<f16, 1, 2, 2, Epi>()) != hipSuccess) return e;
-  if ((e = set_attr<f16, 3, 1, 2, Epi>()) != hipSuccess) return e;
-  if ((e = set_attr<f16, 3, 2, 2, Epi>()) != hipSuccess) return e;
+  if ((e = set_attrs_op<float, 1, Epi>()) != hipSuccess) return e;
+  if ((e = set_attrs_op<f16, 1, Epi>()) != hipSuccess) return e;
+  if ((e = set_attrs_op<f16, 3, Epi>()) != hipSuccess) return e;
   return hipSuccess;
 }
 
-template <typename T, int NSPLIT, int TM, int TN, typename Epi>
+template <typename T, int NSPLIT, int ID, typename Epi>
 hipError_t launch_one(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
-  constexpr int lds = gemm_lds_bytes<T, NSPLIT, TM, TN>();
-  auto kern = gemm_kernel<T, NSPLIT, TM, TN, Epi>;
-  dim3 grid((g.M + 64 * TM - 1) / (64 * TM), (g.N + 64 * TN - 1) / (64 * TN), batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, e);
+  using C = Variant<T, NSPLIT, ID>;
+  constexpr int lds = gemm_lds_bytes<T, NSPLIT, C::TM, C::TN, C::WGM, C::WGN>();
+  auto kern = gemm_kernel<T, NSPLIT, C::TM, C::TN, Epi, C::WGM, C::WGN>;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  // operands are addressed with 32-bit byte offsets through buffer descriptors; offsets >= 2 GiB mean "no such row"
+  if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
+    return hipErrorInvalidValue;
+  dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN), lds, s, g, e);
+  return hipGetLastError();
+}
+
+int pick_variant(const GemmCore& g, int batch) {
+  if (g.M <= 64) return 0;
+  // 128x128 tiles unless that leaves the 2 x 256 workgroup slots of the chip badly filled (B=1: M=2812, N=1024 -> 176 tiles)
+  const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
+  return big >= 384 ? 2 : 1;
+}
+
+// microbenchmark ablations of the 128x128 variant (variant id 8 + ABL); EpiStore only
+template <typename T, int NSPLIT, int ABL, typename Epi>
+hipError_t launch_abl(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
+  using C = Variant<T, NSPLIT, 2>;
+  constexpr int lds = gemm_lds_bytes<T, NSPLIT, C::TM, C::TN, C::WGM, C::WGN>();
+  auto kern = gemm_kernel<T, NSPLIT, C::TM, C::TN, Epi, C::WGM, C::WGN, ABL>;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (err != hipSuccess) return err;
+  dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN), lds, s, g, e);
   return hipGetLastError();
 }
 
 template <typename T, int NSPLIT, typename Epi>
-hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
-  // 128x128 tiles unless that leaves most of the 256 CUs idle (B=1: M=2812, N=1024 -> 176 tiles)
-  const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
-  if (big >= 384 || g.M <= 64) {
-    if (g.M <= 64) return launch_one<T, NSPLIT, 1, 2, Epi>(g, e, batch, s);
-    return launch_one<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
+hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant, hipStream_t s) {
+  if (variant < 0) variant = pick_variant(g, batch);
+  switch (variant) {
+    case 0: return launch_one<T, NSPLIT, 0, Epi>(g, e, batch, s);
+    case 1: return launch_one<T, NSPLIT, 1, Epi>(g, e, batch, s);
+    case 2: return launch_one<T, NSPLIT, 2, Epi>(g, e, batch, s);
+    case 3: return launch_one<T, NSPLIT, 3, Epi>(g, e, batch, s);
+    case 4: return launch_one<T, NSPLIT, 4, Epi>(g, e, batch, s);
+    case 5: return launch_one<T, NSPLIT, 5, Epi>(g, e, batch, s);
+    default: break;
   }
-  return launch_one<T, NSPLIT, 1, 2, Epi>(g, e, batch, s);
+  if constexpr (std::is_same<Epi, EpiStore>::value && !std::is_same<T, float>::value) {
+    switch (variant) {
+      case 9: return launch_abl<T, NSPLIT, 1, Epi>(g, e, batch, s);
+      case 10: return launch_abl<T, NSPLIT, 2, Epi>(g, e, batch, s);
+      case 11: return launch_abl<T, NSPLIT, 3, Epi>(g, e, batch, s);
+      case 12: return launch_abl<T, NSPLIT, 4, Epi>(g, e, batch, s);
+      case 15: return launch_abl<T, NSPLIT, 7, Epi>(g, e, batch, s);
+      default: break;
+    }
+  }
+  return hipErrorInvalidValue;
+  switch (0) {
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <typename Epi>
-hipError_t dispatch(int op, const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
+hipError_t dispatch(int op, const GemmCore& g, const Epi& e, int batch, int variant, hipStream_t s) {
   switch (op) {
-    case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, s);
-    case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, s);
-    case OP_F16X3: return launch_tiled<f16, 3, Epi>(g, e, batch, s);
+    case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, variant, s);
+    case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, variant, s);
+    case OP_F16X3: return launch_tiled<f16, 3, Epi>(g, e, batch, variant, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -54,9 +133,12 @@ hipError_t dispatch(int op, const GemmCore& g, const Epi& e, int batch, hipStrea
 }  // namespace
 
 hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s) {
-  return dispatch<EpiStore>(op, g, e, batch, s);
+  return dispatch<EpiStore>(op, g, e, batch, -1, s);
 }
-hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s) { return dispatch<EpiQKV>(op, g, e, 1, s); }
+hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
+  return dispatch<EpiStore>(op, g, e, batch, variant, s);
+}
+hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s) { return dispatch<EpiQKV>(op, g, e, 1, -1, s); }
 
 hipError_t init_gemm_kernels() {
   hipError_t e = set_attrs_epi<EpiStore>();

@@ -11,6 +11,8 @@ enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2 };  // GEMM operand kind
 // batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
 hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s);
 hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s);
+// explicit tile variant (microbenchmarks): 0 = 64x128, 1 = 128x64, 2 = 128x128 (rows x channels), -1 = heuristic
+hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s);
 // one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
 hipError_t init_gemm_kernels();
 hipError_t init_convpos_kernels();
@@ -20,7 +22,7 @@ hipError_t init_convpos_kernels();
 // AdaLN modulation: y = ln(x) * (1 + scale) + shift.  Writes fp32 and/or f16 hi(/lo) planes.
 hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
                             const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
-                            hipStream_t s);
+                            hipStream_t s, int pk16 = 0, int64_t ldo16 = 0);
 // text token embedding + absolute sinusoid position + masks (reference model/backbones/dit.py:86-127)
 //   tok [B, n] int32 (0 = filler), valid [B, n] u8 (pos < seq_len[b]); out [2B, n, T]: rows [0,B) cond, [B,2B) uncond (ids zeroed)
 hipError_t launch_text_embed(const int32_t* tok, const uint8_t* valid, const float* table, const float* freqs_cis,
@@ -49,6 +51,8 @@ hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStre
 hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out, hipStream_t s);
 // fp32 -> f16 hi/lo planes (weights, one-time), optional power-of-two prescale
 hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s);
+// [rows, K] fp32 -> packed fp16x3 operand [rows, 2K]: k-blocks of 32 as [32 hi | 32 lo] (gemm.h), K % 32 == 0
+hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s);
 // conv_pos weights [D, cpg, K] -> per-tap operand layout [G][K][cpg(co)][cpg(ci)] (fp32 + f16 hi/lo)
 hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo, hipStream_t s);
 // [C, 1, 7] depthwise weights -> [7, C]
@@ -70,11 +74,13 @@ hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* w
 // ---- attention.hip ----------------------------------------------------------------------------
 // flash-style non-causal attention, fp16 operands (nsplit 1) or fp16 hi/lo split operands (nsplit 3), fp32 softmax+accumulate.
 //   q,k [BH, n, 64] f16 (q pre-scaled); vt [BH, 64, ldv] f16 (V transposed, ldv % 8 == 0); o16(/lo) [B', n, H*64];
-//   kvlen per batch' or null.  *_lo planes are required for nsplit == 3.
+//   kvlen per batch' or null.  *_lo planes are required for nsplit == 3.  o_packed: o16 is a packed fp16x3 operand
+//   (row stride 2*H*64, o16_lo == o16 + 32).
 bool flash_attn_available();
 hipError_t init_attention_kernels();
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
-                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s);
+                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s,
+                             int o_packed = 0);
 
 // ---- audio.hip --------------------------------------------------------------------------------
 struct AudioTables {

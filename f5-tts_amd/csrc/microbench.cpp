@@ -1,0 +1,127 @@
+// microbench.cpp — kernel-level measurement entry points of the C ABI (f5hip_bench_*): time ONE kernel of the hot path on
+// synthetic operands with HIP events on the launch stream.  Used by tools/kernel_bench.py to tune tile variants; no model state.
+#include <cstdio>
+#include <vector>
+
+#include "engine.h"
+
+namespace {
+
+__global__ void fill_f32_kernel(float* x, int64_t n, uint32_t seed, float scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    x[i] = scale * ((float)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f);  // uniform [-scale, scale): full-range random operands
+  }
+}
+
+struct Tmp {
+  std::vector<void*> ptrs;
+  ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+  template <typename T>
+  T* get(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+hipError_t fill(float* x, int64_t n, uint32_t seed, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(1024), dim3(256), 0, s, x, n, seed, scale);
+  return hipGetLastError();
+}
+
+template <typename F>
+int time_it(F&& launch, int iters, hipStream_t s, double* avg_ms) {
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return F5HIP_ERR_HIP;
+  for (int i = 0; i < 2; ++i)
+    if (launch() != hipSuccess) return F5HIP_ERR_HIP;
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters; ++i)
+    if (launch() != hipSuccess) return F5HIP_ERR_HIP;
+  (void)hipEventRecord(e1, s);
+  if (hipEventSynchronize(e1) != hipSuccess) return F5HIP_ERR_HIP;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / iters;
+  return F5HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[M,N] = gelu_tanh(A[M,K] . W[N,K]^T + bias) written as fp32 (fp32 mode) or f16 hi(/lo) planes — the FF1 GEMM of a DiT block.
+int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms) {
+  if (!ctx || !avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (K % 8) || (N % 4)) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
+  if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
+  hipStream_t s = nullptr;
+  Tmp t;
+  const int op = precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3;
+  float* a32 = t.get<float>((size_t)M * K);
+  float* w32 = t.get<float>((size_t)N * K);
+  float* bias = t.get<float>(N);
+  float* o32 = t.get<float>((size_t)M * N);
+  float* res = t.get<float>((size_t)M * N);
+  const bool x3 = op == OP_F16X3;
+  if (x3 && (K % 32 || N % 32)) return F5HIP_ERR_INVALID;
+  const size_t pl = x3 ? 2 : 1;  // packed hi/lo rows are twice as long
+  f16 *ah = t.get<f16>((size_t)M * K * pl), *wh = t.get<f16>((size_t)N * K * pl), *oh = t.get<f16>((size_t)M * N * pl);
+  if (!res || !a32 || !w32 || !bias || !o32 || !ah || !wh || !oh) return F5HIP_ERR_HIP;
+  if (fill(a32, (int64_t)M * K, 1u, 1.0f, s) != hipSuccess || fill(w32, (int64_t)N * K, 2u, 0.05f, s) != hipSuccess ||
+      fill(bias, N, 3u, 0.02f, s) != hipSuccess)
+    return F5HIP_ERR_HIP;
+  if (x3) {
+    if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
+  } else if (launch_split_f16(a32, (int64_t)M * K, 1.0f, ah, nullptr, s) != hipSuccess ||
+             launch_split_f16(w32, (int64_t)N * K, 1.0f, wh, nullptr, s) != hipSuccess) {
+    return F5HIP_ERR_HIP;
+  }
+  GemmCore g{};
+  g.A = op == OP_F32 ? (const void*)a32 : (const void*)ah;
+  g.W = op == OP_F32 ? (const void*)w32 : (const void*)wh;
+  g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
+  EpiStore e{};
+  e.alpha = 1.f; e.bias = bias; e.ldo = N; e.ldres = N;
+  if (epilogue == 2) {  // out-proj / FF2: x += gate * (acc + bias), fp32 residual stream
+    if (fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess) return F5HIP_ERR_HIP;
+    e.colscale = bias; e.res = res; e.out32 = res;
+  } else {               // 0: bias only, 1: FF1 (tanh-GELU); operand rows of the next GEMM
+    e.act = epilogue == 1 ? ACT_GELU_TANH : ACT_NONE;
+    if (op == OP_F32) e.out32 = o32;
+    else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = 1; e.ldo16 = 2 * (int64_t)N; } }
+  }
+  return time_it([&] { return launch_gemm_store_variant(op, g, e, 1, variant, s); }, iters, s, avg_ms);
+}
+
+// flash attention over [batch2 * heads, n, 64]; precision FP16 -> plain fp16 operands, FP16X3 -> hi/lo split
+int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms) {
+  if (!ctx || !avg_ms || batch2 <= 0 || heads <= 0 || n <= 0 || iters <= 0 || precision == F5HIP_PREC_FP32) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
+  if (init_attention_kernels() != hipSuccess) return F5HIP_ERR_HIP;
+  hipStream_t s = nullptr;
+  Tmp t;
+  const int ldv = (n + 7) & ~7;
+  const size_t BH = (size_t)batch2 * heads, nq = BH * n * 64, nv = BH * 64 * ldv;
+  float* tmp = t.get<float>(nv > nq ? nv : nq);
+  f16 *qh = t.get<f16>(nq), *ql = t.get<f16>(nq), *kh = t.get<f16>(nq), *kl = t.get<f16>(nq), *vh = t.get<f16>(nv), *vl = t.get<f16>(nv);
+  f16 *oh = t.get<f16>(nq), *ol = t.get<f16>(nq);
+  if (!tmp || !qh || !ql || !kh || !kl || !vh || !vl || !oh || !ol) return F5HIP_ERR_HIP;
+  if (fill(tmp, nq, 11u, 0.5f, s) != hipSuccess || launch_split_f16(tmp, nq, 1.0f, qh, ql, s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (fill(tmp, nq, 12u, 2.0f, s) != hipSuccess || launch_split_f16(tmp, nq, 1.0f, kh, kl, s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (fill(tmp, nv, 13u, 1.0f, s) != hipSuccess || launch_split_f16(tmp, nv, 1.0f, vh, vl, s) != hipSuccess) return F5HIP_ERR_HIP;
+  const bool x3 = precision == F5HIP_PREC_FP16X3;
+  return time_it([&] {
+    return launch_flash_attn(x3 ? 3 : 1, qh, x3 ? ql : nullptr, kh, x3 ? kl : nullptr, vh, x3 ? vl : nullptr, ldv, batch2, heads, n, nullptr, oh,
+                             x3 ? ol : nullptr, s);
+  }, iters, s, avg_ms);
+}
+
+}  // extern "C"

@@ -150,6 +150,15 @@ int f5hip_kernel_stat(const f5hip_ctx* ctx, int index, const char** name, int64_
                       double* flops, double* bytes);
 int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
 
+/* Kernel microbenchmarks (tools/kernel_bench.py; no reference counterpart): average milliseconds of ONE launch of a
+ * hot-path kernel on full-range random synthetic operands, HIP events on the launch stream, 2 warm-up launches.
+ *   gemm:      a DiT block GEMM A[M,K] W[N,K]^T; epilogue 0 = +bias -> operand planes, 1 = FF1 (tanh-GELU -> operand planes),
+ *              2 = out-proj/FF2 (fp32 residual += gate * (acc + bias)); variant -1 = launch heuristic, 0..5 = 64x128, 128x64,
+ *              128x128, 256x128, 128x256, 256x256 tiles (rows x output channels)
+ *   attention: the flash kernel over [batch2*heads, n, 64] (precision FP16 or FP16X3) */
+int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms);
+int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC passes over one GEMM microbench config (run on the GPU box).  usage: tools/pmc_gemm.sh <tag> <kernel_bench args...>
+set -u
+tag=$1; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC" \
+           "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $out/p$i -o p$i -- python $GRAFT_REPO_ROOT/tools/kernel_bench.py "$@" > $out/p$i.log 2>&1
+done
+python - <<PY
+import csv, glob, collections
+for f in sorted(glob.glob("$out/p*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k, d in agg.items():
+        if "gemm_kernel" in k or "flash" in k:
+            print(f, k)
+            for c, v in d.items():
+                print(f"   {c:28s} total {v:.4g}  per-dispatch {v / cnt[(k, c)]:.4g}  dispatches {cnt[(k, c)]}")
+PY
