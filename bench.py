@@ -48,13 +48,28 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota (a 256-thread EPYC box with a
+    16-CPU quota runs the oracle 80x slower with 256 OpenMP threads than with 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen):
-    """Oracle (port of the reference CPU path) on the host cores, bounded sample: mel + text-embed + `probe` ODE steps
-    + vocoder at full size, per-step time extrapolated to `nfe` steps (every step does identical work)."""
+    """Oracle (port of the reference CPU path) on the host cores, bounded sample (~10-30 s of CPU work): mel + text-embed +
+    1 ODE step, then 1 + `probe` steps, + the vocoder, all at full size; per-step time extrapolated to `nfe` steps (every
+    step does identical work)."""
     from oracle import f5_oracle as O
 
     probe = 2
-    torch.set_num_threads(os.cpu_count() or 1)
+    cores = host_cores()
+    torch.set_num_threads(cores)
     kw = dict(cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, use_epss=False)
     t0 = time.perf_counter()
     O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1, **kw)
@@ -67,10 +82,32 @@ def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen):
     per_step = ((t2 - t1) - (t1 - t0)) / probe
     setup = max((t1 - t0) - per_step, 0.0)
     total = setup + nfe * per_step + (t3 - t2)
-    return {"value": t_gen / total, "unit": "gen_mel_frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    cpu_name = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_name = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": t_gen / total, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_name,
             "rtf": total / (HOP * (t_gen - 1) / SR), "seconds_per_utterance_extrapolated": total,
             "sample": f"full-size model, 1 utterance: mel + text-embed + {probe + 2} ODE steps + vocoder measured "
-                      f"({t3 - t0:.1f} s of CPU), per-step time extrapolated to NFE={nfe}"}
+                      f"({t3 - t0:.1f} s of CPU on {cores} threads), per-step time ({per_step:.2f} s) extrapolated to NFE={nfe}"}
+
+
+def pmc_traffic(a, B):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of this workload (profiles/*.json)."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("precision") == a.precision and d.get("batch") == B and d.get("nfe") == a.nfe and d.get("model") == a.model:
+            return d.get("hbm_bytes_per_launch")
+    return None
 
 
 def main():
@@ -149,9 +186,13 @@ def main():
         avg_s = 1e-3 * g["ms"] / g["calls"]
         ach = g["flops"] / g["calls"] / avg_s / 1e12
         res["roofline"] = {"kernel": "gemm_kernel (DiT block QKV/out/FF1/FF2)", "bound": "mfma", "achieved": ach,
-                           "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE, "traffic": None,
-                           "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
-                           "note": "achieved = algorithmic FLOPs (2MNK) / avg launch duration; fp16x3 issues 3 MFMAs per product"}
+                           "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE,
+                           "traffic": pmc_traffic(a, B), "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
+                           "mfma_issue_tflops": ach * (3 if a.precision == "fp16x3" else 1),
+                           "note": "achieved = algorithmic FLOPs (2MNK, SURVEY.md 8d) / avg launch duration, HIP events on the launch "
+                                   "stream; fp16x3 issues 3 fp16 MFMAs per algorithmic product (mfma_issue_tflops = 3x achieved); "
+                                   "traffic = HBM bytes per launch from the committed rocprofv3 PMC pass of the same command "
+                                   "(profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null if none matches"}
     res["kernel_classes_ms"] = {k: round(v["ms"], 3) for k, v in stats.items() if v["calls"]}
     if not a.no_cpu_baseline and world == 1:
         try:

@@ -599,8 +599,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
         }
         HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
       } else {
+        // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
+        // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
         const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
-        HIPCHK(launch_flash_attn(x3 ? 3 : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
+        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
                                  x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
                                  (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st, pk));
       }
@@ -827,7 +829,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
   // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 modes -> flash with the mode's operands), 1 force materialised,
-  // 2 force flash, 3 flash with plain fp16 operands even in fp16x3 mode
+  // 2 flash with every operand split in fp16x3 mode, 3 flash with plain fp16 operands even in fp16x3 mode
   const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
   const int mel = c.mel_dim, D = c.dim;

@@ -15,8 +15,8 @@
 // fragment is read in the matching key order (two ds_read_b64 per fragment) — no cross-lane shuffles for P.
 // V arrives transposed ([BH, 64, ldv], written by the QKV epilogue) so both tiles are plain 16-byte row copies.
 //
-// NSPLIT == 3: fp16 hi/lo split operands (q, k, v and P), 3 MFMAs per product, ~fp32 accuracy (parity mode
-// "fp16x3"); NSPLIT == 1: plain fp16 operands.  Softmax statistics, P and O accumulate in fp32 in both.
+// NSPLIT/PVSPLIT == 3: fp16 hi/lo split operands (q, k / v, P), 3 MFMAs per product, ~fp32 accuracy (parity mode
+// "fp16x3"); == 1: plain fp16 operands.  Softmax statistics, P and O accumulate in fp32 in all variants.
 #include <math.h>
 
 #include "kernels.h"
@@ -38,9 +38,12 @@ struct FlashArgs {
   int n, ldv, heads, nqb, nwg, o_packed;
 };
 
-template <int NSPLIT>
+// NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
+// their rounding matters ~10x more than that of P and V: NSPLIT = 3 with PVSPLIT = 1 keeps near-fp32 scores at 4 instead of 6
+// MFMAs per key-query pair.
+template <int NSPLIT, int PVSPLIT>
 constexpr int flash_lds_bytes() {
-  return 2 * (NSPLIT == 3 ? 2 : 1) * (K_PLANE + V_PLANE);
+  return 2 * ((NSPLIT == 3 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
 }
 
 __device__ __forceinline__ uint4 zero_tail_halves(uint4 v, int first, int limit) {
@@ -53,10 +56,11 @@ __device__ __forceinline__ uint4 zero_tail_halves(uint4 v, int first, int limit)
   return f.u;
 }
 
-template <int NSPLIT>
+template <int NSPLIT, int PVSPLIT>
 __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
-  constexpr int NPL = NSPLIT == 3 ? 2 : 1;
-  constexpr int STAGE = NPL * (K_PLANE + V_PLANE);
+  constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
+  constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
+  constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, ql = lane & 31;
@@ -72,16 +76,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   const int ntile = (kv_end + KT - 1) / KT;
 
   const f16* Kp[NPL];
-  const f16* Vp[NPL];
+  const f16* Vp[NPV];
   const f16* Qp[NPL];
   Kp[0] = a.k + (int64_t)bh * n * 64;
   Vp[0] = a.vt + (int64_t)bh * 64 * a.ldv;
   Qp[0] = a.q + (int64_t)bh * n * 64;
   if constexpr (NPL == 2) {
     Kp[1] = a.k_lo + (int64_t)bh * n * 64;
-    Vp[1] = a.vt_lo + (int64_t)bh * 64 * a.ldv;
     Qp[1] = a.q_lo + (int64_t)bh * n * 64;
   }
+  if constexpr (NPV == 2) Vp[1] = a.vt_lo + (int64_t)bh * 64 * a.ldv;
 
   // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]
   const int qrow = qb * QB + wave * 32 + ql;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     for (int ks = 0; ks < 4; ++ks)
       fq[p][ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp[p] + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
 
-  uint4 rk[NPL][2], rv[NPL][2];
+  uint4 rk[NPL][2], rv[NPV][2];
   auto load_global = [&](int t) {
     const int key0 = t * KT;
 #pragma unroll
@@ -101,8 +105,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
       const bool okk = key0 + row < n;           // K: tile row = key
       const int vkey = key0 + col * 8;           // V^T: tile row = d, 8 consecutive keys per chunk
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) {
+      for (int p = 0; p < NPL; ++p)
         rk[p][i] = okk ? *reinterpret_cast<const uint4*>(Kp[p] + (int64_t)(key0 + row) * 64 + col * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int p = 0; p < NPV; ++p) {
         uint4 v = vkey < n ? *reinterpret_cast<const uint4*>(Vp[p] + (int64_t)row * a.ldv + vkey) : make_uint4(0, 0, 0, 0);
         if (vkey + 8 > n && vkey < n) v = zero_tail_halves(v, vkey, n);  // pad columns of the V^T slab are never written
         rv[p][i] = v;
@@ -112,15 +118,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   auto store_lds = [&](int stage) {
     char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int p = 0; p < NPL; ++p)
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = c & 7;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c = tid + i * 256, row = c >> 3, col = c & 7;
-        *reinterpret_cast<uint4*>(base + p * K_PLANE + row * K_ROWB + col * 16) = rk[p][i];
+      for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint4*>(base + p * K_PLANE + row * K_ROWB + col * 16) = rk[p][i];
+#pragma unroll
+      for (int p = 0; p < NPV; ++p) {
         char* vd = base + NPL * K_PLANE + p * V_PLANE + row * V_ROWB + col * 16;  // 8-byte aligned rows
         *reinterpret_cast<uint2*>(vd) = make_uint2(rv[p][i].x, rv[p][i].y);
         *reinterpret_cast<uint2*>(vd + 8) = make_uint2(rv[p][i].z, rv[p][i].w);
       }
+    }
   };
 
   f32x16 o[2];
@@ -192,26 +200,26 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // 16-key groups of the tile; P registers 8*(g&1) .. +7 of s[g>>1]
-      Frag fp[NPL];
+      Frag fp[NPV];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float p = s[g >> 1][8 * (g & 1) + e];
         const f16 ph = (f16)p;
         fp[0].h[e] = ph;
-        if constexpr (NPL == 2) fp[1].h[e] = (f16)(p - (float)ph);
+        if constexpr (NPV == 2) fp[1].h[e] = (f16)(p - (float)ph);
       }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        Frag fv[NPL];
+        Frag fv[NPV];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
+        for (int p = 0; p < NPV; ++p) {
           const char* src = sV + p * V_PLANE + db * 32 * V_ROWB + g * 32;
           const uint2 v0 = *reinterpret_cast<const uint2*>(src);       // keys 16g + 4hi + 0..3
           const uint2 v1 = *reinterpret_cast<const uint2*>(src + 16);  // keys 16g + 8 + 4hi + 0..3
           fv[p].u = make_uint4(v0.x, v0.y, v1.x, v1.y);
         }
         Mma32<f16>::mma(o[db], fv[0], fp[0]);
-        if constexpr (NPL == 2) {
+        if constexpr (NPV == 2) {
           Mma32<f16>::mma(o[db], fv[0], fp[1]);  // V_hi . P_lo
           Mma32<f16>::mma(o[db], fv[1], fp[0]);  // V_lo . P_hi
         }
@@ -247,10 +255,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   }
 }
 
-template <int NSPLIT>
+template <int NSPLIT, int PVSPLIT>
 hipError_t launch(const FlashArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(flash_attn_kernel<NSPLIT>, dim3(a.nwg), dim3(256), flash_lds_bytes<NSPLIT>(), s, a);
+  constexpr int lds = flash_lds_bytes<NSPLIT, PVSPLIT>();
+  auto kern = flash_attn_kernel<NSPLIT, PVSPLIT>;
+  hipLaunchKernelGGL(kern, dim3(a.nwg), dim3(256), lds, s, a);
   return hipGetLastError();
+}
+template <int NSPLIT, int PVSPLIT>
+hipError_t set_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             flash_lds_bytes<NSPLIT, PVSPLIT>());
 }
 
 }  // namespace
@@ -258,11 +273,10 @@ hipError_t launch(const FlashArgs& a, hipStream_t s) {
 bool flash_attn_available() { return true; }
 
 hipError_t init_attention_kernels() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     flash_lds_bytes<1>());
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             flash_lds_bytes<3>());
+  hipError_t e;
+  if ((e = set_attr<1, 1>()) != hipSuccess) return e;
+  if ((e = set_attr<3, 1>()) != hipSuccess) return e;
+  return set_attr<3, 3>();
 }
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
@@ -274,9 +288,13 @@ hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f1
   a.n = n; a.ldv = ldv; a.heads = heads;
   a.nqb = (n + QB - 1) / QB;
   a.nwg = Bp * heads * a.nqb;
-  if (nsplit == 3) {
+  if (nsplit == 3) {  // hi/lo q, k, v, P
     if (!q_lo || !k_lo || !vt_lo) return hipErrorInvalidValue;
-    return launch<3>(a, s);
+    return launch<3, 3>(a, s);
   }
-  return launch<1>(a, s);
+  if (nsplit == 2) {  // hi/lo q and k (scores), plain fp16 P and V
+    if (!q_lo || !k_lo) return hipErrorInvalidValue;
+    return launch<3, 1>(a, s);
+  }
+  return launch<1, 1>(a, s);
 }

@@ -74,9 +74,10 @@ hipError_t launch_one(const GemmCore& g, const Epi& e, int batch, hipStream_t s)
 
 int pick_variant(const GemmCore& g, int batch) {
   if (g.M <= 64) return 0;
-  // 128x128 tiles unless that leaves the 2 x 256 workgroup slots of the chip badly filled (B=1: M=2812, N=1024 -> 176 tiles)
+  // 128x64 tiles (3 workgroups per CU) until the grid is several waves deep, then 128x128 (higher FLOP per byte staged):
+  // measured crossover between M = 2812 (B=1: 128x64 wins on all four block GEMMs) and M = 22496 (B=8: 128x128 wins).
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
-  return big >= 384 ? 2 : 1;
+  return big >= 1024 ? 2 : 1;
 }
 
 // microbenchmark ablations of the 128x128 variant (variant id 8 + ABL); EpiStore only

@@ -119,7 +119,7 @@ int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, 
   if (fill(tmp, nv, 13u, 1.0f, s) != hipSuccess || launch_split_f16(tmp, nv, 1.0f, vh, vl, s) != hipSuccess) return F5HIP_ERR_HIP;
   const bool x3 = precision == F5HIP_PREC_FP16X3;
   return time_it([&] {
-    return launch_flash_attn(x3 ? 3 : 1, qh, x3 ? ql : nullptr, kh, x3 ? kl : nullptr, vh, x3 ? vl : nullptr, ldv, batch2, heads, n, nullptr, oh,
+    return launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, qh, x3 ? ql : nullptr, kh, x3 ? kl : nullptr, vh, x3 ? vl : nullptr, ldv, batch2, heads, n, nullptr, oh,
                              x3 ? ol : nullptr, s);
   }, iters, s, avg_ms);
 }

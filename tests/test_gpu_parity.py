@@ -207,11 +207,14 @@ def test_flash_attention_equals_materialised_attention(engines):
     try:
         eng.set_option("attn_impl", 1)
         exact, _ = model.sample(wav.cuda(), text, 333, **kw)
-        eng.set_option("attn_impl", 2)
+        eng.set_option("attn_impl", 2)  # every attention operand hi/lo split
         flash, _ = model.sample(wav.cuda(), text, 333, **kw)
+        eng.set_option("attn_impl", 0)  # default: split q/k, plain fp16 P/V
+        mixed, _ = model.sample(wav.cuda(), text, 333, **kw)
     finally:
         eng.set_option("attn_impl", 0)
     assert maxerr(flash, exact.cpu()) < 5e-5
+    assert maxerr(mixed, exact.cpu()) < 2e-4
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", TIGHT)])

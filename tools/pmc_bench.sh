@@ -1,0 +1,12 @@
+#!/bin/bash
+# HBM-traffic PMC passes over one bench.py invocation (run on the GPU box; separate passes, counters only — no tracing).
+# usage: tools/pmc_bench.sh <tag> <bench.py args...>      -> gpurun_out/pmc_<tag>/{fetch,write}/..., gpurun_out/pmc_<tag>.json
+set -u
+tag=$1; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o fetch -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o write -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $out/write.log 2>&1
+python $GRAFT_REPO_ROOT/tools/pmc_summarize.py $out "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.json
+cat $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.json

@@ -1,0 +1,67 @@
+"""Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench.sh) into HBM bytes per launch per kernel class.
+FETCH_SIZE / WRITE_SIZE are reported in KiB-units of 1024 B by rocprofv3; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
+for wide coalesced reads, so it is doubled (/opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def klass(name):
+    if "gemm_kernel" in name:
+        if "EpiQKV" in name or "EpiStore" in name:
+            if "DF16_Li3" in name or "_Float16, 3" in name:
+                return "gemm_fp16x3"
+            if "DF16_Li1" in name or "_Float16, 1" in name:
+                return "gemm_fp16"
+            return "gemm_fp32"
+    if "flash_attn" in name:
+        return "flash_attn"
+    if "layernorm" in name:
+        return "layernorm"
+    if "convpos_kernel" in name:
+        return "convpos"
+    return None
+
+
+def load(d, counter):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = klass(r["Kernel_Name"])
+            if k:
+                agg[k][0] += float(r["Counter_Value"])
+                agg[k][1] += 1
+    return agg
+
+
+def main():
+    out = sys.argv[1]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--nfe", type=int, default=16)
+    ap.add_argument("--precision", default="fp16x3")
+    ap.add_argument("--model", default="F5TTS_v1_Base")
+    a, _ = ap.parse_known_args(sys.argv[2:])
+    fetch, write = load(os.path.join(out, "fetch"), "FETCH_SIZE"), load(os.path.join(out, "write"), "WRITE_SIZE")
+    res = {"precision": a.precision, "batch": a.batch, "nfe": a.nfe, "model": a.model, "classes": {}}
+    for k in sorted(set(fetch) | set(write)):
+        f, w = fetch.get(k, [0, 0]), write.get(k, [0, 0])
+        res["classes"][k] = {"launches": f[1] or w[1], "fetch_bytes_per_launch_x2": 2 * 1024 * f[0] / max(f[1], 1),
+                             "write_bytes_per_launch": 1024 * w[0] / max(w[1], 1)}
+    dom = "gemm_" + a.precision
+    if dom in res["classes"]:
+        c = res["classes"][dom]
+        res["dominant"] = dom
+        res["hbm_bytes_per_launch"] = c["fetch_bytes_per_launch_x2"] + c["write_bytes_per_launch"]
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

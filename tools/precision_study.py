@@ -24,7 +24,7 @@ def main():
     eng = F5HipEngine(cfg, None, device=0)
     eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
     print("golden generated-mel range", float(gold[:, 468:].min()), float(gold[:, 468:].max()), "std", float(gold[:, 468:].std()))
-    modes = [("fp32", 0), ("fp16x3", 0), ("fp16x3", 3), ("fp16", 0)]
+    modes = [("fp32", 0), ("fp16x3", 0), ("fp16x3", 2), ("fp16x3", 3), ("fp16", 0)]
     for prec, attn in modes:
         eng.set_option("attn_impl", attn)
         model = F5HipCFM(eng, precision=prec)
