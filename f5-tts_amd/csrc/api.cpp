@@ -454,8 +454,13 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
     ENS(scores, (int64_t)2 * B * c.heads * n * np * 4);
   } else {
     const int64_t ldv = (n + 7) & ~7;
-    ENS(q16, M * inner * 2); ENS(k16, M * inner * 2); ENS(vt16, (int64_t)2 * B * inner * ldv * 2);
-    if (op == OP_F16X3) { ENS(q16_lo, M * inner * 2); ENS(k16_lo, M * inner * 2); ENS(vt16_lo, (int64_t)2 * B * inner * ldv * 2); }
+    ENS(q16, M * inner * 2); ENS(k16, M * inner * 2);
+    // V^T slabs: the pad columns [n, ldv) are never written by the QKV epilogue and must not hold NaN/Inf bit patterns
+    HIPCHK(ctx->vt16.ensure((size_t)((int64_t)2 * B * inner * ldv * 2), &moved, /*zero=*/true));
+    if (op == OP_F16X3) {
+      ENS(q16_lo, M * inner * 2); ENS(k16_lo, M * inner * 2);
+      HIPCHK(ctx->vt16_lo.ensure((size_t)((int64_t)2 * B * inner * ldv * 2), &moved, /*zero=*/true));
+    }
   }
 #undef ENS
   if (moved) ctx->ws_epoch++;

@@ -46,18 +46,8 @@ constexpr int flash_lds_bytes() {
   return 2 * ((NSPLIT == 3 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
 }
 
-__device__ __forceinline__ uint4 zero_tail_halves(uint4 v, int first, int limit) {
-  // keep halves whose key index (first + e) < limit
-  Frag f;
-  f.u = v;
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (first + e >= limit) f.h[e] = (f16)0.f;
-  return f.u;
-}
-
 template <int NSPLIT, int PVSPLIT>
-__global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
   constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
@@ -75,17 +65,20 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   const int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n;
   const int ntile = (kv_end + KT - 1) / KT;
 
-  const f16* Kp[NPL];
-  const f16* Vp[NPV];
+  // K / V^T slabs of this (batch', head) through buffer descriptors: rows or keys past the end read as zeros (hardware
+  // bounds check), so the tile loads are unconditional and nothing waits on them until the matching LDS store.
+  // V^T pad columns [n, ldv) are zero-initialised once at allocation and never written; a key >= kv_end gets P = 0 exactly.
+  const uint32_t k_bytes = (uint32_t)n * 128u, v_bytes = (uint32_t)(64 * a.ldv) * 2u;
+  BufRsrc Kr[NPL], Vr[NPV];
   const f16* Qp[NPL];
-  Kp[0] = a.k + (int64_t)bh * n * 64;
-  Vp[0] = a.vt + (int64_t)bh * 64 * a.ldv;
+  Kr[0] = make_rsrc(a.k + (int64_t)bh * n * 64, k_bytes);
+  Vr[0] = make_rsrc(a.vt + (int64_t)bh * 64 * a.ldv, v_bytes);
   Qp[0] = a.q + (int64_t)bh * n * 64;
   if constexpr (NPL == 2) {
-    Kp[1] = a.k_lo + (int64_t)bh * n * 64;
+    Kr[1] = make_rsrc(a.k_lo + (int64_t)bh * n * 64, k_bytes);
     Qp[1] = a.q_lo + (int64_t)bh * n * 64;
   }
-  if constexpr (NPV == 2) Vp[1] = a.vt_lo + (int64_t)bh * 64 * a.ldv;
+  if constexpr (NPV == 2) Vr[1] = make_rsrc(a.vt_lo + (int64_t)bh * 64 * a.ldv, v_bytes);
 
   // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]
   const int qrow = qb * QB + wave * 32 + ql;
@@ -96,26 +89,28 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     for (int ks = 0; ks < 4; ++ks)
       fq[p][ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp[p] + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
 
-  uint4 rk[NPL][2], rv[NPV][2];
-  auto load_global = [&](int t) {
-    const int key0 = t * KT;
+  // thread -> 16-byte chunk c = tid + 256 i of a tile: K tile row = key (c >> 3), V^T tile row = d (c >> 3), 8 chunks per row
+  uint32_t k_off[2], v_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256, row = c >> 3, col = c & 7;
+    k_off[i] = (uint32_t)(row * 128 + col * 16);                 // + key0 * 128
+    v_off[i] = (uint32_t)(row * a.ldv * 2 + col * 16);           // + key0 * 2
+  }
+  uint4 rk0[NPL][2], rv0[NPV][2], rk1[NPL][2], rv1[NPV][2];
+  auto load_global = [&](int t, uint4 (&rk)[NPL][2], uint4 (&rv)[NPV][2]) {
+    const uint32_t key0 = (uint32_t)t * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + i * 256, row = c >> 3, col = c & 7;
-      const bool okk = key0 + row < n;           // K: tile row = key
-      const int vkey = key0 + col * 8;           // V^T: tile row = d, 8 consecutive keys per chunk
+      const uint32_t vkey_off = key0 * 2 + (uint32_t)((tid + i * 256) & 7) * 16;  // byte offset of the chunk within a V^T row
+      const uint32_t voff = vkey_off < (uint32_t)a.ldv * 2 ? v_off[i] + key0 * 2 : OOB_OFF;
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        rk[p][i] = okk ? *reinterpret_cast<const uint4*>(Kp[p] + (int64_t)(key0 + row) * 64 + col * 8) : make_uint4(0, 0, 0, 0);
+      for (int p = 0; p < NPL; ++p) rk[p][i] = buffer_load_b128(Kr[p], k_off[i] + key0 * 128);
 #pragma unroll
-      for (int p = 0; p < NPV; ++p) {
-        uint4 v = vkey < n ? *reinterpret_cast<const uint4*>(Vp[p] + (int64_t)row * a.ldv + vkey) : make_uint4(0, 0, 0, 0);
-        if (vkey + 8 > n && vkey < n) v = zero_tail_halves(v, vkey, n);  // pad columns of the V^T slab are never written
-        rv[p][i] = v;
-      }
+      for (int p = 0; p < NPV; ++p) rv[p][i] = buffer_load_b128(Vr[p], voff);
     }
   };
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](int stage, const uint4 (&rk)[NPL][2], const uint4 (&rv)[NPV][2]) {
     char* base = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -136,13 +131,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
-  for (int t = 0; t < ntile; ++t) {
-    if (t + 1 < ntile) load_global(t + 1);
-    const char* base = smem + (t & 1) * STAGE;
+  // one 64-key tile held in LDS stage `stage`: scores, online softmax, O update
+  auto process = [&](int t, int stage) {
+    const char* base = smem + stage * STAGE;
     const char* sK = base + ql * K_ROWB + hi * 16;
     const char* sV = base + NPL * K_PLANE + ql * V_ROWB + hi * 8;
 
@@ -181,14 +172,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
     const float mb = m_new * LOG2E;
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(fmaf(s[kb][r], LOG2E, -mb));
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mb));
         s[kb][r] = p;
         rs += p;
       }
@@ -225,10 +216,28 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(FlashArgs a) {
         }
       }
     }
+  };
 
-    if (t + 1 < ntile) store_lds((t + 1) & 1);
+  // Two register sets, as in gemm.h: the loads of tile t+2 are issued at the top of iteration t and written to LDS at the end
+  // of iteration t+1.  Tiles past the end read zeros / stale finite data and are never processed.
+  load_global(0, rk0, rv0);
+  load_global(1, rk1, rv1);
+  store_lds(0, rk0, rv0);
+  __syncthreads();
+  int t = 0;
+  for (; t + 1 < ntile; t += 2) {
+    load_global(t + 2, rk0, rv0);
+    __builtin_amdgcn_sched_barrier(0);
+    process(t, 0);
+    store_lds(1, rk1, rv1);
+    __syncthreads();
+    load_global(t + 3, rk1, rv1);
+    __builtin_amdgcn_sched_barrier(0);
+    process(t + 1, 1);
+    store_lds(0, rk0, rv0);
     __syncthreads();
   }
+  if (t < ntile) process(t, 0);
 
   // ---- normalise and store: lane (q, hi) owns O[q][32 db + 8 c + 4 hi + 0..3] --------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

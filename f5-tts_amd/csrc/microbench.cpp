@@ -114,6 +114,7 @@ int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, 
   f16 *qh = t.get<f16>(nq), *ql = t.get<f16>(nq), *kh = t.get<f16>(nq), *kl = t.get<f16>(nq), *vh = t.get<f16>(nv), *vl = t.get<f16>(nv);
   f16 *oh = t.get<f16>(nq), *ol = t.get<f16>(nq);
   if (!tmp || !qh || !ql || !kh || !kl || !vh || !vl || !oh || !ol) return F5HIP_ERR_HIP;
+  if (hipMemsetAsync(vh, 0, nv * sizeof(f16), s) != hipSuccess || hipMemsetAsync(vl, 0, nv * sizeof(f16), s) != hipSuccess) return F5HIP_ERR_HIP;
   if (fill(tmp, nq, 11u, 0.5f, s) != hipSuccess || launch_split_f16(tmp, nq, 1.0f, qh, ql, s) != hipSuccess) return F5HIP_ERR_HIP;
   if (fill(tmp, nq, 12u, 2.0f, s) != hipSuccess || launch_split_f16(tmp, nq, 1.0f, kh, kl, s) != hipSuccess) return F5HIP_ERR_HIP;
   if (fill(tmp, nv, 13u, 1.0f, s) != hipSuccess || launch_split_f16(tmp, nv, 1.0f, vh, vl, s) != hipSuccess) return F5HIP_ERR_HIP;

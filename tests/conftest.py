@@ -11,6 +11,12 @@ import f5_tts_amd  # noqa: E402,F401  (registers the hyphenated package dir unde
 
 
 def pytest_configure(config):
+    try:  # the CPU oracle is small-tensor work: a few threads beat an oversubscribed pool on shared CI hosts
+        import torch
+
+        torch.set_num_threads(min(4, os.cpu_count() or 1))
+    except Exception:  # pragma: no cover
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
 
 
