@@ -20,7 +20,7 @@ PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 class DitConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim", "conv_layers",
-        "text_mask_padding", "pe_attn_head", "attn_mask_enabled", "conv_pos_kernel", "conv_pos_groups")]
+        "text_mask_padding", "pe_attn_head", "attn_mask_enabled", "conv_pos_kernel", "conv_pos_groups", "backbone")]
 
 
 class VocosConfigC(C.Structure):
@@ -74,7 +74,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if lib.f5hip_abi_version() != 1:
+    if lib.f5hip_abi_version() != 2:
         raise F5HipError("libf5hip ABI version mismatch")
     if path == LIB_PATH:
         _lib = lib

@@ -41,7 +41,12 @@ class DiTConfig:
         return int(self.dim * self.ff_mult)
 
     def arch_kwargs(self) -> dict:
-        """kwargs accepted by the reference ``DiT(**model_cfg, text_num_embeds=..., mel_dim=...)``."""
+        """kwargs accepted by the reference ``DiT(**model_cfg, text_num_embeds=..., mel_dim=...)`` / ``UNetT(...)``."""
+        if self.backbone == "UNetT":
+            return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_mult=self.ff_mult,
+                        text_dim=self.text_dim, text_mask_padding=self.text_mask_padding, conv_layers=self.conv_layers,
+                        pe_attn_head=self.pe_attn_head, attn_mask_enabled=self.attn_mask_enabled, mel_dim=self.mel_dim,
+                        text_num_embeds=self.text_num_embeds)
         return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head,
                     ff_mult=self.ff_mult, text_dim=self.text_dim, text_mask_padding=self.text_mask_padding,
                     conv_layers=self.conv_layers, pe_attn_head=self.pe_attn_head,
@@ -64,11 +69,17 @@ class VocosConfig:
 
 
 F5TTS_V1_BASE = DiTConfig()  # api/cli default (reference src/f5_tts/api.py:26)
+# E2-TTS: flat U-Net transformer (reference src/f5_tts/model/backbones/unett.py:108-186, configs/E2TTS_Base.yaml:25-31):
+# text_dim defaults to mel_dim, no ConvNeXt text blocks, ff_mult 4, rope on head 0 only, concat skip connections
+E2TTS_BASE = DiTConfig(dim=1024, depth=24, heads=16, dim_head=64, ff_mult=4, text_dim=N_MEL_CHANNELS, conv_layers=0,
+                       text_mask_padding=False, pe_attn_head=1, backbone="UNetT")
 F5TTS_BASE = replace(F5TTS_V1_BASE, text_mask_padding=False, pe_attn_head=1)
 # reduced sizes used by the parity tests (same code path, seconds on the CPU oracle)
 DIT_TINY = DiTConfig(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, text_dim=128, conv_layers=2,
                      text_num_embeds=255)
 DIT_TINY_V0 = replace(DIT_TINY, text_mask_padding=False, pe_attn_head=1)
+UNETT_TINY = DiTConfig(dim=256, depth=4, heads=4, dim_head=64, ff_mult=4, text_dim=N_MEL_CHANNELS, conv_layers=0,
+                       text_mask_padding=False, pe_attn_head=1, text_num_embeds=255, backbone="UNetT")
 VOCOS_MEL_24K = VocosConfig()
 VOCOS_TINY = VocosConfig(dim=128, intermediate_dim=384, num_layers=2)
 
@@ -77,4 +88,6 @@ PRESETS = {
     "F5TTS_Base": F5TTS_BASE,
     "tiny": DIT_TINY,
     "tiny_v0": DIT_TINY_V0,
+    "E2TTS_Base": E2TTS_BASE,
+    "tiny_unett": UNETT_TINY,
 }

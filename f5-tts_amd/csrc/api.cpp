@@ -88,9 +88,33 @@ void build_slots(f5hip_ctx* ctx) {
     add_slot(ctx, b + "bias", D);
   }
   add_slot(ctx, p + "rotary_embed.inv_freq", c.dim_head / 2, /*optional=*/true);
-  for (int i = 0; i < c.depth; ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.weight", 6 * D * D);
-  for (int i = 0; i < c.depth; ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.bias", 6 * D);
-  for (int i = 0; i < c.depth; ++i) {
+  if (c.backbone == 1) {  // UNetT: reference unett.py:147-186 -> keys layers.{i}.{0: skip_proj, 1: attn_norm, 2: attn, 3: ff_norm, 4: ff}
+    for (int i = 0; i < c.depth; ++i) {
+      const std::string b = p + "layers." + std::to_string(i) + ".";
+      if (i >= c.depth / 2) add_slot(ctx, b + "0.weight", D * 2 * D);
+      add_slot(ctx, b + "1.g", D);
+      add_slot(ctx, b + "2.to_q.weight", inner * D);
+      add_slot(ctx, b + "2.to_k.weight", inner * D);
+      add_slot(ctx, b + "2.to_v.weight", inner * D);
+      add_slot(ctx, b + "2.to_q.bias", inner);
+      add_slot(ctx, b + "2.to_k.bias", inner);
+      add_slot(ctx, b + "2.to_v.bias", inner);
+      add_slot(ctx, b + "2.to_out.0.weight", D * inner);
+      add_slot(ctx, b + "2.to_out.0.bias", D);
+      add_slot(ctx, b + "3.g", D);
+      add_slot(ctx, b + "4.ff.0.0.weight", F * D);
+      add_slot(ctx, b + "4.ff.0.0.bias", F);
+      add_slot(ctx, b + "4.ff.2.weight", D * F);
+      add_slot(ctx, b + "4.ff.2.bias", D);
+    }
+    add_slot(ctx, p + "norm_out.g", D);
+    add_slot(ctx, p + "proj_out.weight", mel * D);
+    add_slot(ctx, p + "proj_out.bias", mel);
+  }
+  for (int i = 0; i < (c.backbone == 1 ? 0 : c.depth); ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.weight", 6 * D * D);
+  const int dit_depth = c.backbone == 1 ? 0 : c.depth;
+  for (int i = 0; i < dit_depth; ++i) add_slot(ctx, p + "transformer_blocks." + std::to_string(i) + ".attn_norm.linear.bias", 6 * D);
+  for (int i = 0; i < dit_depth; ++i) {
     const std::string b = p + "transformer_blocks." + std::to_string(i) + ".";
     add_slot(ctx, b + "attn.to_q.weight", inner * D);
     add_slot(ctx, b + "attn.to_k.weight", inner * D);
@@ -105,10 +129,12 @@ void build_slots(f5hip_ctx* ctx) {
     add_slot(ctx, b + "ff.ff.2.weight", D * F);
     add_slot(ctx, b + "ff.ff.2.bias", D);
   }
-  add_slot(ctx, p + "norm_out.linear.weight", 2 * D * D);
-  add_slot(ctx, p + "norm_out.linear.bias", 2 * D);
-  add_slot(ctx, p + "proj_out.weight", mel * D);
-  add_slot(ctx, p + "proj_out.bias", mel);
+  if (c.backbone != 1) {
+    add_slot(ctx, p + "norm_out.linear.weight", 2 * D * D);
+    add_slot(ctx, p + "norm_out.linear.bias", 2 * D);
+    add_slot(ctx, p + "proj_out.weight", mel * D);
+    add_slot(ctx, p + "proj_out.bias", mel);
+  }
   add_slot(ctx, p + "text_embed.freqs_cis", 8192 * T, /*optional=*/true);  // non-persistent buffer (dit.py:48)
   ctx->dit_elems = ctx->blob_elems;
   if (ctx->has_vocos) {
@@ -228,20 +254,28 @@ int finalize_impl(f5hip_ctx* ctx) {
   // f16 hi/lo copies of the per-step GEMM weights
   const int64_t per_block = 3 * inner * D + D * inner + F * D + D * F;
   if (D % 32 || inner % 32 || F % 32) FAIL(F5HIP_ERR_UNSUPPORTED, "dim, heads*dim_head and ff_inner must be multiples of 32 (packed fp16x3 operand rows)");
-  HIPCHK(ctx->half_pool.ensure((size_t)(per_block * c.depth * 3) * sizeof(f16)));  // plain hi + packed hi/lo
+  const bool unett = c.backbone == 1;
+  const int64_t skip_elems = unett ? (int64_t)(c.depth / 2) * D * 2 * D : 0;
+  HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
   f16* hp = ctx->half_pool.as<f16>();
   ctx->blocks.assign(c.depth, BlockW{});
   for (int i = 0; i < c.depth; ++i) {
-    const std::string b = p + "transformer_blocks." + std::to_string(i) + ".";
+    const std::string b = p + (unett ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
+    const std::string ba = b + (unett ? "2." : "attn."), bf = b + (unett ? "4." : "ff.");
     BlockW& bw = ctx->blocks[i];
-    bw.wqkv = W(ctx, b + "attn.to_q.weight");
-    bw.bqkv = W(ctx, b + "attn.to_q.bias");
-    bw.wo = W(ctx, b + "attn.to_out.0.weight");
-    bw.bo = W(ctx, b + "attn.to_out.0.bias");
-    bw.w1 = W(ctx, b + "ff.ff.0.0.weight");
-    bw.b1 = W(ctx, b + "ff.ff.0.0.bias");
-    bw.w2 = W(ctx, b + "ff.ff.2.weight");
-    bw.b2 = W(ctx, b + "ff.ff.2.bias");
+    bw.wqkv = W(ctx, ba + "to_q.weight");
+    bw.bqkv = W(ctx, ba + "to_q.bias");
+    bw.wo = W(ctx, ba + "to_out.0.weight");
+    bw.bo = W(ctx, ba + "to_out.0.bias");
+    bw.w1 = W(ctx, bf + "ff.0.0.weight");
+    bw.b1 = W(ctx, bf + "ff.0.0.bias");
+    bw.w2 = W(ctx, bf + "ff.2.weight");
+    bw.b2 = W(ctx, bf + "ff.2.bias");
+    if (unett) {
+      bw.g_attn = W(ctx, b + "1.g");
+      bw.g_ff = W(ctx, b + "3.g");
+      bw.wskip = i >= c.depth / 2 ? W(ctx, b + "0.weight") : nullptr;
+    }
     auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk) -> hipError_t {
       hi = hp; hp += rows * K;
       pk = hp; hp += 2 * rows * K;
@@ -253,9 +287,14 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk));
     HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk));
     HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk));
+    if (bw.wskip) HIPCHK(carve(bw.wskip, D, 2 * D, bw.wskip_hi, bw.wskip_pk));
   }
-  ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm.linear.weight");
-  ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm.linear.bias");
+  if (unett) {
+    ctx->norm_out_g = W(ctx, p + "norm_out.g");
+  } else {
+    ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm.linear.weight");
+    ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm.linear.bias");
+  }
   {
     const int64_t n = (int64_t)c.mel_dim * D;
     HIPCHK(ctx->wp_hi.ensure(n * sizeof(f16)));
@@ -403,8 +442,13 @@ int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, 
   HIPCHK(ctx->tsin.ensure((size_t)steps * 256 * sizeof(float), &moved));
   HIPCHK(ctx->th1.ensure((size_t)steps * D * sizeof(float), &moved));
   HIPCHK(ctx->tsilu.ensure((size_t)steps * D * sizeof(float), &moved));
-  HIPCHK(ctx->mods.ensure((size_t)steps * c.depth * 6 * D * sizeof(float), &moved));
-  HIPCHK(ctx->fmods.ensure((size_t)steps * 2 * D * sizeof(float), &moved));
+  const bool unett = c.backbone == 1;
+  if (unett) {
+    HIPCHK(ctx->temb.ensure((size_t)steps * D * sizeof(float), &moved));
+  } else {
+    HIPCHK(ctx->mods.ensure((size_t)steps * c.depth * 6 * D * sizeof(float), &moved));
+    HIPCHK(ctx->fmods.ensure((size_t)steps * 2 * D * sizeof(float), &moved));
+  }
   if (moved) ctx->ws_epoch++;
   ctx->t_host.assign(t, t + steps + 1);
   HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ctx->t_host.data(), (steps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
@@ -415,6 +459,10 @@ int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, 
     GemmCore g = core(ctx->tsin.p, 256, W(ctx, p + "time_embed.time_mlp.0.weight"), 256, steps, (int)D, 256);
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->th1.as<float>(), D, W(ctx, p + "time_embed.time_mlp.0.bias"), ACT_SILU), 1, st));
     g = core(ctx->th1.p, D, W(ctx, p + "time_embed.time_mlp.2.weight"), D, steps, (int)D, (int)D);
+    if (unett) {  // the raw embedding is the time token (unett.py:272); there is no AdaLN
+      HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->temb.as<float>(), D, W(ctx, p + "time_embed.time_mlp.2.bias")), 1, st));
+      return F5HIP_OK;
+    }
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->tsilu.as<float>(), D, W(ctx, p + "time_embed.time_mlp.2.bias"), ACT_SILU), 1, st));
     const int nm = c.depth * 6 * (int)D;
     g = core(ctx->tsilu.p, D, ctx->adaln_w, D, steps, nm, (int)D);
@@ -429,14 +477,17 @@ int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, 
 int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
-  const int64_t BN = (int64_t)B * n, M = 2 * BN;
+  const bool unett = c.backbone == 1;
+  const int ns = n + (unett ? 1 : 0);                 // tokens per sequence inside the backbone (UNetT prepends the time token)
+  const int64_t BN = (int64_t)B * n, M = 2 * (int64_t)B * ns;
   bool moved = false;
 #define ENS(buf, bytes) HIPCHK(ctx->buf.ensure((size_t)(bytes), &moved))
   ENS(tok, BN * 4); ENS(valid, BN); ENS(textkeep, M); ENS(rowvalid, M); ENS(condmask, BN); ENS(kvlen, 2 * B * 4);
   ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, 2 * B * 2 * T * 4);
   ENS(step_cond, BN * mel * 4); ENS(cconst, M * D * 4); ENS(y, BN * mel * 4);
   ENS(h, M * D * 4); ENS(c1, M * D * 4); ENS(x, M * D * 4);
-  ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)n * c.dim_head * 4);
+  ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)ns * c.dim_head * 4);
+  if (unett) ENS(skipcat, (int64_t)(c.depth / 2) * M * 2 * D * (op == OP_F16 ? 2 : 4));
   if (op == OP_F32) {
     ENS(a32, M * D * 4); ENS(o32, M * inner * 4); ENS(f32, M * F * 4);
   } else {
@@ -444,16 +495,16 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
     ENS(a_hi, M * D * 2 * pl); ENS(o_hi, M * inner * 2 * pl); ENS(f_hi, M * F * 2 * pl);
   }
   if (exact_attn) {
-    const int64_t np = (n + 3) & ~3;
+    const int64_t np = (ns + 3) & ~3;
     ENS(q32, M * inner * 4); ENS(k32, M * inner * 4);
     if ((size_t)(2 * B * c.heads * c.dim_head * np * 4) > ctx->vt32.cap) {
       HIPCHK(ctx->vt32.ensure((size_t)(2 * B * c.heads * c.dim_head * np * 4), &moved, /*zero=*/true));
     } else if (ctx->ws_n != n) {
       HIPCHK(hipMemset(ctx->vt32.p, 0, ctx->vt32.cap));  // padding columns must be zero for the new row stride
     }
-    ENS(scores, (int64_t)2 * B * c.heads * n * np * 4);
+    ENS(scores, (int64_t)2 * B * c.heads * ns * np * 4);
   } else {
-    const int64_t ldv = (n + 7) & ~7;
+    const int64_t ldv = (ns + 7) & ~7;
     ENS(q16, M * inner * 2); ENS(k16, M * inner * 2);
     // V^T slabs: the pad columns [n, ldv) are never written by the QKV epilogue and must not hold NaN/Inf bit patterns
     HIPCHK(ctx->vt16.ensure((size_t)((int64_t)2 * B * inner * ldv * 2), &moved, /*zero=*/true));
@@ -477,7 +528,8 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
   std::vector<int32_t> tok(BN);
   std::vector<uint8_t> valid(BN), keep(M);
   for (int b = 0; b < B; ++b) {
-    const int64_t sl = use_mask ? std::min<int64_t>(duration[b], n) : n;
+    // DiT: per-sample valid length when a mask is passed (dit.py:295-298); UNetT: the padded frame count for every sample (unett.py:218-228)
+    const int64_t sl = (use_mask && c.backbone != 1) ? std::min<int64_t>(duration[b], n) : n;
     for (int pos = 0; pos < n; ++pos) {
       int64_t id = pos < nt ? text[(int64_t)b * nt + pos] + 1 : 0;  // +1, 0 = filler (dit.py:87,95-96)
       const bool ok = pos < sl;
@@ -513,6 +565,44 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
     e.rowmask = keepd; e.mask_mode = 2;  // masked_fill after the residual add (dit.py:127)
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
   }
+  return F5HIP_OK;
+}
+
+
+// ---- attention over [2B * H] (batch', head) slabs of ns tokens: q/k/v were written by the QKV epilogue -------------------------------
+int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
+                  int64_t ldO, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int H = c.heads, dh = c.dim_head, inner = H * dh;
+  {
+      Prof pr(ctx, st, KC_ATTN, 4.0 * (double)(2 * B) * H * (double)n * n * dh, 0);
+      if (exact_attn) {
+        // materialised-score attention in fp32: S = QK^T (batched GEMM), row softmax, O = PV (batched GEMM)
+        const int np = (n + 3) & ~3;
+        GemmCore g = core(ctx->q32.p, dh, ctx->k32.p, dh, n, np, dh);
+        g.w_rows = n; g.strideA = (int64_t)n * dh; g.strideW = (int64_t)n * dh;
+        EpiStore e = epi_store(ctx->scores.as<float>(), np, nullptr);
+        e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
+        HIPCHK(launch_gemm_store(OP_F32, g, e, 2 * B * H, st));
+        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)2 * B * H * n, np, n, H, kvlen, n, st));
+        g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
+        g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
+        EpiStore e2 = epi_store(o32, inner, nullptr);
+        e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
+        if (op != OP_F32) {  // fp16 operand of the out-projection: same (batch', head) addressing, packed rows in fp16x3 mode
+          e2.out16 = o_hi; e2.out16_lo = o_lo; e2.pk16 = pk; e2.ldo16 = ldO;
+          e2.so1_16 = (int64_t)n * ldO; e2.so2_16 = dh;
+        }
+        HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
+      } else {
+        // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
+        // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
+        const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
+        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
+                                 x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
+                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st, pk));
+      }
+    }
   return F5HIP_OK;
 }
 
@@ -583,35 +673,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
-    {
-      Prof pr(ctx, st, KC_ATTN, 4.0 * (double)(2 * B) * H * (double)n * n * dh, 0);
-      if (exact_attn) {
-        // materialised-score attention in fp32: S = QK^T (batched GEMM), row softmax, O = PV (batched GEMM)
-        const int np = (n + 3) & ~3;
-        GemmCore g = core(ctx->q32.p, dh, ctx->k32.p, dh, n, np, dh);
-        g.w_rows = n; g.strideA = (int64_t)n * dh; g.strideW = (int64_t)n * dh;
-        EpiStore e = epi_store(ctx->scores.as<float>(), np, nullptr);
-        e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
-        HIPCHK(launch_gemm_store(OP_F32, g, e, 2 * B * H, st));
-        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)2 * B * H * n, np, n, H, kvlen, n, st));
-        g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
-        g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
-        EpiStore e2 = epi_store(o32, inner, nullptr);
-        e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
-        if (op != OP_F32) {  // fp16 operand of the out-projection: same (batch', head) addressing, packed rows in fp16x3 mode
-          e2.out16 = o_hi; e2.out16_lo = o_lo; e2.pk16 = pk; e2.ldo16 = ldO;
-          e2.so1_16 = (int64_t)n * ldO; e2.so2_16 = dh;
-        }
-        HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
-      } else {
-        // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
-        // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
-        const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
-        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
-                                 x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
-                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st, pk));
-      }
-    }
+    CHK(run_attention(ctx, B, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
       GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
@@ -656,8 +718,149 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
   return F5HIP_OK;
 }
 
+
+// ---- one ODE function evaluation + Euler update, UNetT backbone (reference src/f5_tts/model/backbones/unett.py:244-307) -------------
+int run_step_unett(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
+  const int ns = n + 1, S = 2 * B;
+  const int64_t BN = (int64_t)B * n;
+  const int M = S * ns;
+  const std::string p = "transformer.";
+  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;  // [S, ns], time token valid (unett.py:273-274)
+  float* x = ctx->x.as<float>();
+  float* h = ctx->h.as<float>();
+  const int wbytes = op == OP_F32 ? 4 : 2;
+  const int pk = op == OP_F16X3 ? 1 : 0;
+  const int64_t pl = pk ? 2 : 1;
+  const int64_t ldA = D * pl, ldO = inner * pl, ldF = F * pl, ldC = 2 * D * pl;  // operand row strides (elements)
+  float* a32 = op == OP_F32 ? ctx->a32.as<float>() : nullptr;
+  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() : nullptr;
+  f16* a_lo = pk ? a_hi + 32 : nullptr;
+  const void* A = op == OP_F32 ? (const void*)a32 : (const void*)a_hi;
+  float* o32 = op == OP_F32 ? ctx->o32.as<float>() : nullptr;
+  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() : nullptr;
+  f16* o_lo = pk ? o_hi + 32 : nullptr;
+  float* f32 = op == OP_F32 ? ctx->f32.as<float>() : nullptr;
+  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() : nullptr;
+  f16* f_lo = pk ? f_hi + 32 : nullptr;
+  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() : nullptr;
+  const double ln_bytes = (double)M * D * (4 + wbytes * pl);
+  // concat buffer of skip level l: [M, 2D] in the operand layout; columns [0, D) = current x, [D, 2D) = the saved skip
+  const int64_t cat_elem_bytes = op == OP_F16 ? 2 : 4;  // fp32: 4 B; fp16: 2 B; packed hi/lo: 2 x 2 B per logical element
+  auto cat_ptr = [&](int level) { return ctx->skipcat.as<char>() + (int64_t)level * M * 2 * D * cat_elem_bytes; };
+  // write an operand copy of x (mode 2 = no normalisation) into columns [col0, col0 + D) of a concat buffer
+  auto emit_cat = [&](int level, int col0) -> hipError_t {
+    char* base = cat_ptr(level);
+    if (op == OP_F32) return launch_layernorm(x, D, M, D, 0.f, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<float*>(base) + col0, nullptr, nullptr, 2 * D, st, 0, 0, 2);
+    f16* hi = reinterpret_cast<f16*>(base) + pk_off(col0, pk);
+    return launch_layernorm(x, D, M, D, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, hi, pk ? hi + 32 : nullptr, 0, st, pk, ldC, 2);
+  };
+
+  {  // InputEmbedding.proj (unett.py:100): per-step x columns + the step-invariant cond/text part
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
+    GemmCore g = core(ctx->y.p, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
+    EpiStore e = epi_store(h, D, nullptr);
+    e.res = ctx->cconst.as<float>(); e.ldres = D;
+    e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D;
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  {  // ConvPositionEmbedding WITHOUT a mask (unett.py:101) + residual, written behind the time token of each sequence
+    const int cpg = D / c.conv_pos_groups;
+    Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops((int64_t)S * n, D, (int64_t)cpg * c.conv_pos_kernel), 0);
+    HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), nullptr, nullptr, S, n, D, c.conv_pos_groups, c.conv_pos_kernel,
+                          ctx->c1.as<float>(), st));
+    HIPCHK(launch_convpos(op, ctx->c1.as<float>(), ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), nullptr, h, S, n, D, c.conv_pos_groups, c.conv_pos_kernel, x, st,
+                          ns, 1));
+    HIPCHK(launch_set_token_rows(x, ctx->temb.as<float>() + (int64_t)step * D, S, ns, D, st));  // unett.py:272
+  }
+
+  for (int i = 0; i < c.depth; ++i) {
+    const BlockW& bw = ctx->blocks[i];
+    if (i < c.depth / 2) {  // skips.append(x) (unett.py:286-287): kept as the right half of that level's concat operand
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(emit_cat(i, D));
+    } else {  // x = skip_proj(cat(x, skips.pop())) (unett.py:289-293)
+      const int level = c.depth - 1 - i;
+      {
+        Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+        HIPCHK(emit_cat(level, 0));
+      }
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, 2 * D), 0);
+      GemmCore g = core(cat_ptr(level), ldC, wsel(op, bw.wskip, bw.wskip_hi, bw.wskip_pk), ldC, M, D, 2 * D);
+      HIPCHK(launch_gemm_store(op, g, epi_store(x, D, nullptr), 1, st));
+    }
+    {  // attn_norm: x_transformers RMSNorm
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_attn, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
+    }
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), 0);
+      GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
+      EpiQKV e{};
+      e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
+      e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
+      if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (ns + 3) & ~3; }
+      else {
+        e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (ns + 7) & ~7;
+        if (op == OP_F16X3) { e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>(); e.vt16_lo = ctx->vt16_lo.as<f16>(); }
+      }
+      HIPCHK(launch_gemm_qkv(op, g, e, st));
+    }
+    CHK(run_attention(ctx, B, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
+      EpiStore e = epi_store(x, D, bw.bo);
+      e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_ff, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
+    }
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
+      GemmCore g = core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
+      EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {  // x = ff(...) + x (unett.py:301)
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), 0);
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
+      EpiStore e = epi_store(x, D, bw.b2);
+      e.res = x; e.ldres = D;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+  }
+  {  // norm_out(x)[:, 1:, :] -> proj_out (unett.py:305-307): one GEMM per sequence over rows 1..n of the normalised operand
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, M, D, 0.f, ctx->norm_out_g, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
+    }
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops((int64_t)S * n, mel, D), 0);
+    const char* Arow1 = reinterpret_cast<const char*>(A) + ldA * (op == OP_F32 ? 4 : 2);  // skip the time token of sequence 0
+    GemmCore g = core(Arow1, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, n, mel, D);
+    g.strideA = (int64_t)ns * ldA;
+    EpiStore e = epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias"));
+    e.zdiv = 1; e.so1 = (int64_t)n * mel; e.so2 = 0;
+    HIPCHK(launch_gemm_store(op, g, e, S, st));
+  }
+  {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
+    HIPCHK(launch_cfg_euler(ctx->y.as<float>(), ctx->vel.as<float>(), BN * mel, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            traj ? traj + (int64_t)(step + 1) * BN * mel : nullptr, ctx->dbg_vel.as<float>(), st));
+  }
+  return F5HIP_OK;
+}
+
 int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
-  for (int s = 0; s < steps; ++s) CHK(run_step(ctx, B, n, s, op, exact_attn, use_mask, traj, st));
+  const bool unett = ctx->cfg.backbone == 1;
+  for (int s = 0; s < steps; ++s) CHK(unett ? run_step_unett(ctx, B, n, s, op, exact_attn, use_mask, traj, st)
+                                            : run_step(ctx, B, n, s, op, exact_attn, use_mask, traj, st));
   return F5HIP_OK;
 }
 
@@ -681,6 +884,8 @@ int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int d
   if (cpg != 16 && cpg != 32 && cpg != 64) return bad("dim/conv_pos_groups must be 16, 32 or 64");
   if (!(dc->conv_pos_kernel & 1)) return bad("conv_pos_kernel must be odd");
   if (dc->mel_dim > 256) return bad("mel_dim must be <= 256");
+  if (dc->backbone != 0 && dc->backbone != 1) return bad("backbone must be 0 (DiT) or 1 (UNetT)");
+  if (dc->backbone == 1 && (dc->conv_layers != 0 || (dc->depth & 1))) return bad("UNetT: conv_layers must be 0 and depth even (unett.py:130)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
     g_create_err = "no such HIP device (libf5hip has no CPU fallback)";
@@ -711,7 +916,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
-                    &ctx->mods, &ctx->fmods, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
+                    &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
@@ -845,13 +1050,16 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
 
   // masks (cfm.py:128-158)
   {
-    std::vector<uint8_t> rv(2 * BN);
+    // rows of the backbone's token sequences: UNetT prepends the (always valid) time token (unett.py:272-274)
+    const int tok0 = c.backbone == 1 ? 1 : 0, ns = n + tok0;
+    const int64_t BNs = (int64_t)B * ns;
+    std::vector<uint8_t> rv(2 * BNs);
     std::vector<int32_t> kv(2 * B);
     for (int b = 0; b < B; ++b) {
-      for (int pos = 0; pos < n; ++pos) rv[(int64_t)b * n + pos] = rv[BN + (int64_t)b * n + pos] = pos < duration[b] ? 1 : 0;
-      kv[b] = kv[B + b] = (int32_t)duration[b];
+      for (int r = 0; r < ns; ++r) rv[(int64_t)b * ns + r] = rv[BNs + (int64_t)b * ns + r] = (r < tok0 || r - tok0 < duration[b]) ? 1 : 0;
+      kv[b] = kv[B + b] = (int32_t)duration[b] + tok0;
     }
-    HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv.data(), 2 * BN, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv.data(), 2 * BNs, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->kvlen.p, kv.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->condmask.p, cond_mask, BN, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -861,7 +1069,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     HIPCHK(launch_mask_select(cond, ctx->condmask.as<uint8_t>(), BN, mel, ctx->step_cond.as<float>(), st));  // cfm.py:151-153
     HIPCHK(hipMemcpyAsync(ctx->y.p, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (trajectory) HIPCHK(hipMemcpyAsync(trajectory, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCHK(launch_rope_table(ctx->inv_freq.as<float>(), n, c.dim_head / 2, ctx->rope.as<float>(), st));
+    HIPCHK(launch_rope_table(ctx->inv_freq.as<float>(), n + (c.backbone == 1 ? 1 : 0), c.dim_head / 2, ctx->rope.as<float>(), st));
   }
   CHK(run_text_embed(ctx, B, n, text, nt, duration, use_mask, st));
   {  // step-invariant part of InputEmbedding.proj: W_c.cond + W_t.text + b  (cond branch), W_t.text_uncond + b (uncond, cond=0)

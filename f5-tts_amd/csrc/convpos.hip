@@ -23,7 +23,7 @@ struct ConvCfg {
 template <typename T, int NPL, int CPG>
 __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ x, const T* __restrict__ w, const T* __restrict__ w_lo,
                                                       const float* __restrict__ bias, const uint8_t* __restrict__ rowvalid,
-                                                      const float* __restrict__ residual, int n, int D, int K, float* out) {
+                                                      const float* __restrict__ residual, int n, int D, int K, float* out, int out_n, int out_off) {
   using C = ConvCfg<T, NPL, CPG>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
   if (m >= n) return;
   const int64_t grow = (int64_t)s * n + m;
   const bool dead = rowvalid && !rowvalid[grow];
+  const int64_t orow = (int64_t)s * out_n + m + out_off;  // output rows may live in a longer sequence (UNetT: time token first)
 #pragma unroll
   for (int i = 0; i < C::COT; ++i) {
 #pragma unroll
@@ -150,30 +151,31 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         const float4 r = *reinterpret_cast<const float4*>(residual + grow * D + ch);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
-      *reinterpret_cast<float4*>(out + grow * D + ch) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + orow * D + ch) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
 
 template <typename T, int NPL, int CPG>
 hipError_t launch_cfg(const float* x, const T* w, const T* w_lo, const float* bias, const uint8_t* rowvalid, const float* residual,
-                      int S, int n, int D, int groups, int K, float* out, hipStream_t s) {
+                      int S, int n, int D, int groups, int K, float* out, hipStream_t s, int out_n, int out_off) {
   using C = ConvCfg<T, NPL, CPG>;
   const int lds = NPL * (C::BMR + K - 1) * C::ROWB + 2 * C::WSTAGE;
   auto kern = convpos_kernel<T, NPL, CPG>;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   dim3 grid((n + C::BMR - 1) / C::BMR, groups, S);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, w, w_lo, bias, rowvalid, residual, n, D, K, out);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, w, w_lo, bias, rowvalid, residual, n, D, K, out, out_n, out_off);
   return hipGetLastError();
 }
 
 template <int CPG>
 hipError_t launch_cpg(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
-                      const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out, hipStream_t s) {
+                      const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out, hipStream_t s, int out_n,
+                      int out_off) {
   switch (op) {
-    case OP_F32: return launch_cfg<float, 1, CPG>(x, w32, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s);
-    case OP_F16: return launch_cfg<f16, 1, CPG>(x, whi, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s);
-    case OP_F16X3: return launch_cfg<f16, 2, CPG>(x, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case OP_F32: return launch_cfg<float, 1, CPG>(x, w32, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
+    case OP_F16: return launch_cfg<f16, 1, CPG>(x, whi, nullptr, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
+    case OP_F16X3: return launch_cfg<f16, 2, CPG>(x, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
     default: return hipErrorInvalidValue;
   }
 }
@@ -182,13 +184,14 @@ hipError_t launch_cpg(int op, const float* x, const float* w32, const f16* whi, 
 
 hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
                           const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out,
-                          hipStream_t s) {
+                          hipStream_t s, int out_n, int out_off) {
+  if (out_n <= 0) out_n = n;
   const int cpg = D / groups;
   if (cpg * groups != D || (K & 1) == 0) return hipErrorInvalidValue;
   switch (cpg) {
-    case 16: return launch_cpg<16>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
-    case 32: return launch_cpg<32>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
-    case 64: return launch_cpg<64>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s);
+    case 16: return launch_cpg<16>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
+    case 32: return launch_cpg<32>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
+    case 64: return launch_cpg<64>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
     default: return hipErrorInvalidValue;
   }
 }

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          float* out32, f16* out16, f16* out16_lo, int64_t ldo, int pk16,
-                                                         int64_t ldo16) {
+                                                         int64_t ldo16, int mode) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  const float mean = wave_sum(sum) / (float)D;
+  const float mean = mode == 0 ? wave_sum(sum) / (float)D : 0.f;  // RMSNorm / copy: no centring
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  float rstd;
+  if (mode == 0) rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  else if (mode == 1) rstd = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(sq)), 1e-12f);  // F.normalize(x, dim=-1) * sqrt(D)
+  else rstd = 1.0f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (i * 64 + lane) * 4;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
     if (weight) {
       const float4 w = *reinterpret_cast<const float4*>(weight + c);
-      const float4 b = *reinterpret_cast<const float4*>(bias + c);
+      const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       y[0] = y[0] * w.x + b.x; y[1] = y[1] * w.y + b.y; y[2] = y[2] * w.z + b.z; y[3] = y[3] * w.w + b.w;
     }
     if (scale) {
@@ -358,14 +361,14 @@ inline int grid_1d(int64_t total, int block = 256, int cap = 8192) {
 
 hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
                             const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
-                            hipStream_t s, int pk16, int64_t ldo16) {
+                            hipStream_t s, int pk16, int64_t ldo16, int mode) {
   if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
   if (ldo16 == 0) ldo16 = ldo;
   dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16);
+  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
+  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
+  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
   return hipGetLastError();
 }
 
@@ -427,6 +430,19 @@ hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStre
 }
 hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out, hipStream_t s) {
   hipLaunchKernelGGL(rope_table_kernel, dim3(grid_1d((int64_t)n * half)), dim3(256), 0, s, inv_freq, n, half, out);
+  return hipGetLastError();
+}
+namespace {
+__global__ void set_token_rows_kernel(float* x, const float* t, int S, int64_t seq_stride, int D4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * D4) return;
+  const int sq = i / D4, c = i - sq * D4;
+  reinterpret_cast<float4*>(x + (int64_t)sq * seq_stride)[c] = reinterpret_cast<const float4*>(t)[c];
+}
+}  // namespace
+hipError_t launch_set_token_rows(float* x, const float* t, int S, int nseq, int D, hipStream_t s) {
+  if (D % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(set_token_rows_kernel, dim3((S * (D / 4) + 255) / 256), dim3(256), 0, s, x, t, S, (int64_t)nseq * D, D / 4);
   return hipGetLastError();
 }
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s) {

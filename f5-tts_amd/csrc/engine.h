@@ -52,6 +52,9 @@ struct BlockW {  // per DiT block
   const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // fp32 (blob)
   f16 *wqkv_hi, *wo_hi, *w1_hi, *w2_hi;  // plain fp16 rows [N, K]             (precision FP16)
   f16 *wqkv_pk, *wo_pk, *w1_pk, *w2_pk;  // packed hi/lo rows [N, 2K] (gemm.h) (precision FP16X3)
+  // UNetT only: RMSNorm gains and the later-half skip projection Linear(2D -> D, no bias)
+  const float *g_attn = nullptr, *g_ff = nullptr, *wskip = nullptr;
+  f16 *wskip_hi = nullptr, *wskip_pk = nullptr;
 };
 struct TextBlockW {
   const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *gamma, *beta, *pw2_w, *pw2_b;
@@ -121,6 +124,9 @@ struct f5hip_ctx {
   // time-grid dependent tables (cached on the last grid)
   std::vector<float> t_host;
   DevBuf t_dev, dt_dev, cfg_dev, tsin, th1, tsilu, mods, fmods;
+  DevBuf temb;                         // UNetT: raw time embedding per step [steps, D] (the time token)
+  const float* norm_out_g = nullptr;   // UNetT final RMSNorm gain
+  DevBuf skipcat;                      // UNetT: depth/2 concat buffers [2B*(n+1), 2D] in the mode's operand layout
 
   // workspace (grow-only)
   int ws_B = 0, ws_n = 0;

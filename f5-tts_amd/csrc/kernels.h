@@ -22,7 +22,11 @@ hipError_t init_convpos_kernels();
 // AdaLN modulation: y = ln(x) * (1 + scale) + shift.  Writes fp32 and/or f16 hi(/lo) planes.
 hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps, const float* weight, const float* bias,
                             const float* scale, const float* shift, float* out32, f16* out16, f16* out16_lo, int64_t ldo,
-                            hipStream_t s, int pk16 = 0, int64_t ldo16 = 0);
+                            hipStream_t s, int pk16 = 0, int64_t ldo16 = 0, int mode = 0);
+// mode: 0 = LayerNorm, 1 = x_transformers RMSNorm (F.normalize(x) * sqrt(D) * weight; bias/scale/shift unused),
+//       2 = no normalisation (operand conversion / copy only)
+// rows [seq, 0, :] of x [S, nseq, D] <- t[D]   (UNetT: the time embedding is a token, reference backbones/unett.py:272)
+hipError_t launch_set_token_rows(float* x, const float* t, int S, int nseq, int D, hipStream_t s);
 // text token embedding + absolute sinusoid position + masks (reference model/backbones/dit.py:86-127)
 //   tok [B, n] int32 (0 = filler), valid [B, n] u8 (pos < seq_len[b]); out [2B, n, T]: rows [0,B) cond, [B,2B) uncond (ids zeroed)
 hipError_t launch_text_embed(const int32_t* tok, const uint8_t* valid, const float* table, const float* freqs_cis,
@@ -69,7 +73,7 @@ hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_m
 //   model/modules.py:187-201: input and conv output zero-filled outside the mask)
 hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
                           const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out,
-                          hipStream_t s);
+                          hipStream_t s, int out_n = 0, int out_off = 0);  // output row of (seq, m) = seq * out_n + m + out_off (out_n 0 = n)
 
 // ---- attention.hip ----------------------------------------------------------------------------
 // flash-style non-causal attention, fp16 operands (nsplit 1) or fp16 hi/lo split operands (nsplit 3), fp32 softmax+accumulate.

@@ -81,7 +81,7 @@ class F5HipEngine:
                        text_mask_padding=int(dit_cfg.text_mask_padding),
                        pe_attn_head=-1 if dit_cfg.pe_attn_head is None else int(dit_cfg.pe_attn_head),
                        attn_mask_enabled=int(dit_cfg.attn_mask_enabled), conv_pos_kernel=dit_cfg.conv_pos_kernel,
-                       conv_pos_groups=dit_cfg.conv_pos_groups)
+                       conv_pos_groups=dit_cfg.conv_pos_groups, backbone=1 if dit_cfg.backbone == "UNetT" else 0)
         v = None
         if vocos_cfg is not None:
             v = VocosConfigC(input_channels=vocos_cfg.input_channels, dim=vocos_cfg.dim,

@@ -57,6 +57,22 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
         sd[p + b + "bias"] = _normal(g, (D,), 0.02)
     sd[p + "rotary_embed.inv_freq"] = 1.0 / (10000.0 ** (torch.arange(0, cfg.dim_head, 2).float() / cfg.dim_head))
     inner = cfg.heads * cfg.dim_head
+    if cfg.backbone == "UNetT":  # reference src/f5_tts/model/backbones/unett.py:147-186 key layout: layers.{i}.{0..4}
+        for i in range(cfg.depth):
+            b = f"layers.{i}."
+            if i >= cfg.depth // 2:
+                sd[p + b + "0.weight"] = _normal(g, (D, 2 * D), 1.0 / math.sqrt(2 * D))  # skip_proj, no bias
+            sd[p + b + "1.g"] = 1.0 + _normal(g, (D,), 0.05)
+            linear(b + "2.to_q", inner, D)
+            linear(b + "2.to_k", inner, D)
+            linear(b + "2.to_v", inner, D)
+            linear(b + "2.to_out.0", D, inner, w_std=0.3 / math.sqrt(inner))
+            sd[p + b + "3.g"] = 1.0 + _normal(g, (D,), 0.05)
+            linear(b + "4.ff.0.0", cfg.ff_inner, D)
+            linear(b + "4.ff.2", D, cfg.ff_inner, w_std=0.3 / math.sqrt(cfg.ff_inner))
+        sd[p + "norm_out.g"] = 1.0 + _normal(g, (D,), 0.05)
+        linear("proj_out", mel, D, w_std=0.04, b_std=0.02)
+        return sd
     for i in range(cfg.depth):
         b = f"transformer_blocks.{i}."
         linear(b + "attn_norm.linear", 6 * D, D, w_std=0.02, b_std=0.05)  # zero-init in the reference

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 1
+#define F5HIP_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -45,8 +45,8 @@ enum {
  *   FP16    fp16 operands, fp32 accumulate (what the reference runs on GPU: utils_infer.py:191-199) */
 enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2 };
 
-/* Architecture of the DiT backbone: the keyword arguments of reference
- * src/f5_tts/model/backbones/dit.py:171-192 that change inference arithmetic. */
+/* Architecture of the backbone: the keyword arguments of reference src/f5_tts/model/backbones/dit.py:171-192 (DiT) /
+ * unett.py:109-128 (UNetT) that change inference arithmetic. */
 typedef struct f5hip_dit_config {
   int32_t dim, depth, heads, dim_head, ff_inner;
   int32_t mel_dim, text_num_embeds, text_dim, conv_layers;
@@ -54,6 +54,8 @@ typedef struct f5hip_dit_config {
   int32_t pe_attn_head;        /* -1 = rope on all heads (None), k>0 = first k heads */
   int32_t attn_mask_enabled;   /* bool: key-padding mask inside attention */
   int32_t conv_pos_kernel, conv_pos_groups;
+  int32_t backbone;            /* 0 = DiT (F5-TTS, dit.py), 1 = UNetT (E2-TTS, reference src/f5_tts/model/backbones/unett.py:108-307:
+                                  time embedding as a prepended token, x_transformers RMSNorm pre-norm, concat skip connections) */
 } f5hip_dit_config;
 
 /* Vocos (charactr/vocos-mel-24khz config.yaml; loader reference utils_infer.py:106-129). */

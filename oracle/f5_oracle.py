@@ -291,6 +291,58 @@ def dit_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, tex
 
 
 # ---------------------------------------------------------------------------------------------
+# UNetT backbone (E2-TTS): src/f5_tts/model/backbones/unett.py
+# ---------------------------------------------------------------------------------------------
+def x_rmsnorm(x: Tensor, g: Tensor) -> Tensor:
+    """x_transformers RMSNorm (import unett.py:19; upstream: F.normalize(x, dim=-1) * sqrt(dim) * g)."""
+    return F.normalize(x, dim=-1) * (x.shape[-1] ** 0.5) * g
+
+
+def unett_text_embedding(sd: SD, cfg, text: Tensor, seq_len: int, drop_text: bool) -> Tensor:
+    """unett.py:54-84 with conv_layers == 0 (E2TTS_Base.yaml): +1, curtail/pad to seq_len, embed.  mask_padding only acts inside
+    the extra-modeling branch, so it is inert here."""
+    assert cfg.conv_layers == 0, "UNetT text ConvNeXt blocks are not built (no shipped config uses them)"
+    text = text + 1
+    text = text[:, :seq_len]
+    text = F.pad(text, (0, seq_len - text.shape[1]), value=0)
+    if drop_text:
+        text = torch.zeros_like(text)
+    return F.embedding(text, sd["transformer.text_embed.text_embed.weight"])
+
+
+def unett_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, text_uncond: Tensor, time: Tensor,
+                      mask: Optional[Tensor]):
+    """unett.py:244-307 with cfg_infer=True, cache=True -> [2b, n, mel]."""
+    b, n = x.shape[0], x.shape[1]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = timestep_embedding(sd, time)
+    # InputEmbedding.forward (unett.py:96-102): conv_pos_embed is called WITHOUT the mask
+    x_c = input_embedding(sd, cfg, x, cond, text_cond, False, None)
+    x_u = input_embedding(sd, cfg, x, cond, text_uncond, True, None)
+    h = torch.cat((x_c, x_u), dim=0)
+    t = torch.cat((t, t), dim=0)
+    m2 = torch.cat((mask, mask), dim=0) if mask is not None else None
+    h = torch.cat([t.unsqueeze(1), h], dim=1)  # time token first (:272)
+    if m2 is not None:
+        m2 = F.pad(m2, (1, 0), value=True)
+    freqs = rotary_freqs(cfg.dim_head, n + 1)
+    skips = []
+    for i in range(cfg.depth):
+        pfx = f"transformer.layers.{i}."
+        if i < cfg.depth // 2:
+            skips.append(h)
+        else:
+            h = F.linear(torch.cat((h, skips.pop()), dim=-1), sd[pfx + "0.weight"])
+        h = attention(sd, cfg, pfx + "2.", x_rmsnorm(h, sd[pfx + "1.g"]), m2, freqs) + h
+        f = F.linear(x_rmsnorm(h, sd[pfx + "3.g"]), sd[pfx + "4.ff.0.0.weight"], sd[pfx + "4.ff.0.0.bias"])
+        f = F.linear(F.gelu(f, approximate="tanh"), sd[pfx + "4.ff.2.weight"], sd[pfx + "4.ff.2.bias"])
+        h = f + h
+    h = x_rmsnorm(h, sd["transformer.norm_out.g"])[:, 1:, :]
+    return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+
+
+# ---------------------------------------------------------------------------------------------
 # sampler
 # ---------------------------------------------------------------------------------------------
 def make_noise(duration: Tensor, mel_dim: int, seed: Optional[int]) -> Tensor:
@@ -308,7 +360,7 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
                cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None, seed: Optional[int] = None,
                max_duration: int = 65536, use_epss: bool = True, edit_mask: Optional[Tensor] = None,
                return_steps: bool = False):
-    """src/f5_tts/model/cfm.py:83-229 with a DiT backbone, CFG on (cfg_strength >= 1e-5), euler.
+    """src/f5_tts/model/cfm.py:83-229 with a DiT or UNetT backbone (cfg.backbone), CFG on (cfg_strength >= 1e-5), euler.
     cond: wave [b, nw] or mel [b, n, mel]; text: int64 [b, nt] (already tokenised, -1 padded)."""
     if cond.ndim == 2:
         cond = vocos_mel(cond).permute(0, 2, 1)
@@ -330,16 +382,22 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
     step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
     mask = lens_to_mask(duration) if batch > 1 else None
 
-    seq_len = n if mask is None else mask.sum(dim=1)  # dit.py:295-298
-    text_cond = text_embedding(sd, cfg, text, seq_len, drop_text=False)
-    text_uncond = text_embedding(sd, cfg, text, seq_len, drop_text=True)
+    unett = getattr(cfg, "backbone", "DiT") == "UNetT"
+    if unett:  # unett.py:218-228: seq_len is the padded frame count for every sample
+        text_cond = unett_text_embedding(sd, cfg, text, n, drop_text=False)
+        text_uncond = unett_text_embedding(sd, cfg, text, n, drop_text=True)
+    else:
+        seq_len = n if mask is None else mask.sum(dim=1)  # dit.py:295-298
+        text_cond = text_embedding(sd, cfg, text, seq_len, drop_text=False)
+        text_uncond = text_embedding(sd, cfg, text, seq_len, drop_text=True)
+    forward_cfg = unett_forward_cfg if unett else dit_forward_cfg
 
     y = make_noise(duration, cfg.mel_dim, seed)
     t = time_grid(steps, sway_sampling_coef, use_epss)
     traj = [y]
     vel = []
     for i in range(steps):  # torchdiffeq euler on the supplied grid (cfm.py:218)
-        pred_cfg = dit_forward_cfg(sd, cfg, y, step_cond, text_cond, text_uncond, t[i], mask)
+        pred_cfg = forward_cfg(sd, cfg, y, step_cond, text_cond, text_uncond, t[i], mask)
         pred, null = torch.chunk(pred_cfg, 2, dim=0)
         v = pred + (pred - null) * cfg_strength  # cfm.py:190-191
         y = y + (t[i + 1] - t[i]) * v

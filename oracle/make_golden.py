@@ -48,6 +48,11 @@ CASES = {
                                  kw=dict(steps=32, cfg_strength=1.5, sway_sampling_coef=None, seed=11)),
     "tiny_v1_ragged_b2": dict(preset="tiny", wseed=1, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
                               pad_from=30, kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    # E2-TTS flat U-Net transformer (reference backbones/unett.py): single utterance and a ragged batch
+    "tiny_unett_nfe8": dict(preset="tiny_unett", wseed=3, nw=256 * 50, wavseed=6, batch=1, nt=30, tseed=4, duration=140, lens=None,
+                            kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
+    "tiny_unett_ragged_b2": dict(preset="tiny_unett", wseed=3, nw=256 * 50, wavseed=6, batch=2, nt=30, tseed=4, duration=[140, 111],
+                                 lens=[51, 40], pad_from=22, kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
     "tiny_v1_b3_fixed": dict(preset="tiny", wseed=1, nw=256 * 30, wavseed=9, batch=3, nt=20, tseed=6, duration=96, lens=None,
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
@@ -70,8 +75,9 @@ def case_inputs(c):
 
 
 def build_reference(cfg, sd):
-    CFM, DiT, _ = ref_shims.reference_classes()
-    model = CFM(transformer=DiT(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method="euler"))
+    CFM, DiT, UNetT = ref_shims.reference_classes()
+    backbone = UNetT if cfg.backbone == "UNetT" else DiT
+    model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method="euler"))
     model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
     return model.eval()
 

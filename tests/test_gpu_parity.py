@@ -2,8 +2,8 @@
 (libf5hip.so); the oracle and the committed goldens (minted from the reference itself) are the checkers.
 
 Tolerance: BASELINE.json north_star — <= 1e-3 max-abs on the generated mel vs the reference CPU path.
-fp32 / fp16x3 must meet 1e-3 (they are held to 1e-4 here); plain fp16 (what the reference itself runs on a
-GPU, utils_infer.py:191-199) is measured and bounded at 2e-2 — it is NOT the parity mode."""
+fp32 / fp16x3 must meet 1e-3 (held to 1e-4 / 3e-4 here: fp16x3 keeps P and V of the attention in plain fp16); plain fp16 (what the
+reference itself runs on a GPU, utils_infer.py:191-199) is measured and bounded at 2e-2 — it is NOT the parity mode."""
 import os
 import sys
 
@@ -20,7 +20,8 @@ from oracle import make_golden as MG  # noqa: E402
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden")
 MEL_TOL = 1e-3  # north_star tolerance on the generated mel
-TIGHT = 1e-4    # what the fp32 / fp16x3 modes are actually held to
+TIGHT = 1e-4    # what the fp32 mode is actually held to
+X3TOL = 3e-4    # fp16x3: split GEMM operands and attention scores, plain fp16 P.V (measured 1.1e-4 on the full-size model)
 
 
 def gold(name):
@@ -56,7 +57,7 @@ def maxerr(a, b):
 
 
 @pytest.mark.parametrize("name", sorted(MG.CASES))
-@pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", TIGHT), ("fp16", 2e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL), ("fp16", 2e-2)])
 def test_sample_matches_reference_golden(engines, name, prec, tol):
     from f5_tts_amd.engine import F5HipCFM
 
@@ -217,7 +218,7 @@ def test_flash_attention_equals_materialised_attention(engines):
     assert maxerr(mixed, exact.cpu()) < 2e-4
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", TIGHT)])
+@pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL)])
 def test_key_padding_mask_ragged_batch(prec, tol):
     """attn_mask_enabled=True (reference modules.py:513-516): keys beyond each utterance's duration are masked —
     the kvlen path of both attention implementations, on a ragged batch."""
