@@ -669,7 +669,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
       if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (n + 3) & ~3; }
       else {
         e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (n + 7) & ~7;
-        if (op == OP_F16X3) { e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>(); e.vt16_lo = ctx->vt16_lo.as<f16>(); }
+        if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
+          e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
+          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+        }
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
@@ -805,7 +808,10 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_at
       if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (ns + 3) & ~3; }
       else {
         e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (ns + 7) & ~7;
-        if (op == OP_F16X3) { e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>(); e.vt16_lo = ctx->vt16_lo.as<f16>(); }
+        if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
+          e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
+          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+        }
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }

@@ -328,3 +328,177 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant: the k-tiles are fetched by LDS-DMA (buffer_load_dwordx4 ... lds: the wave writes 64 x 16 B to a
+// lane-linear 1 KiB LDS run, no VGPR round trip, no ds_write) into a ring of NS stages.  The swizzle lives on the per-lane
+// SOURCE offset (the LDS image is the same as gemm_kernel's).  Tile t+2 is issued at the top of phase t into the stage that
+// phase t-1 finished reading (one barrier earlier), tile t+1 is awaited with a COUNTED vmcnt before the single barrier of the
+// phase, so two tiles stay in flight across it.  Raw s_barrier (no __syncthreads: its fence would drain vmcnt to 0).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int NSPLIT, int TM, int TN, int WGM = 2, int WGN = 2, int NS = 3>
+constexpr int gemm_glds_lds_bytes() {
+  return NS * (32 * WGM * TM + 32 * WGN * TN) * GEMM_KTB;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, Epi epi) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
+  constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
+  constexpr int CPR = GEMM_KTB / 16;
+  constexpr int KSTEPS = NPL == 2 ? 2 : 4;
+  constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;  // DMA pieces per thread per tile
+  constexpr int LPT = CA + CW;
+  constexpr int TILE_A = BM * GEMM_KTB, TILE_W = BN * GEMM_KTB;
+  constexpr int STAGE = TILE_A + TILE_W;
+  static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
+  static_assert(NS == 3, "ring depth 3: two tiles in flight");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WGM, wn = wave / WGM;
+  const int z = blockIdx.z;
+  int m0, n0;
+  {
+    const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
+    const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int mt = L / nt;
+    m0 = mt * BM;
+    n0 = (L - mt * nt) * BN;
+  }
+  const int kbytes = g.K * (int)sizeof(T) * NPL;
+  const uint32_t a_bytes = (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * (int64_t)sizeof(T) + kbytes);
+  const uint32_t w_bytes = (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * (int64_t)sizeof(T) + kbytes);
+  const BufRsrc Ar = make_rsrc(reinterpret_cast<const T*>(g.A) + (int64_t)z * g.strideA, a_bytes);
+  const BufRsrc Wr = make_rsrc(reinterpret_cast<const T*>(g.W) + (int64_t)z * g.strideW, w_bytes);
+  uint32_t a_off[CA], w_off[CW];
+  int a_c[CA], w_c[CW];
+#pragma unroll
+  for (int i = 0; i < CA; ++i) {
+    const int c = tid + i * NT, row = c / CPR, lc = (c % CPR) ^ ((row >> 1) & 7);
+    a_c[i] = lc * 16;
+    a_off[i] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * (int64_t)sizeof(T) + lc * 16) : OOB_ROW;
+  }
+#pragma unroll
+  for (int i = 0; i < CW; ++i) {
+    const int c = tid + i * NT, row = c / CPR, lc = (c % CPR) ^ ((row >> 1) & 7);
+    w_c[i] = lc * 16;
+    w_off[i] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * (int64_t)sizeof(T) + lc * 16) : OOB_ROW;
+  }
+  // LDS-DMA of one k-tile: piece i of this wave lands at stage + (wave * 64 + i * NT) * 16 + lane * 16
+  auto issue = [&](int kt, int stage) {
+    const int kb = kt * GEMM_KTB;
+    char* base = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < CA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(Ar, (__attribute__((address_space(3))) void*)(base + i * NT * 16), 16,
+                                               (int)((kb + a_c[i]) < kbytes ? a_off[i] + (uint32_t)kb : OOB_OFF), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < CW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(Wr, (__attribute__((address_space(3))) void*)(base + TILE_A + i * NT * 16), 16,
+                                               (int)((kb + w_c[i]) < kbytes ? w_off[i] + (uint32_t)kb : OOB_OFF), 0, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  const int frow = (lane & 31) * GEMM_KTB, fswz = ((lane & 31) >> 1) & 7, fhi = lane >> 5;
+  int foff[NPL][KSTEPS];
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) foff[p][ks] = frow + (((p * 4 + 2 * ks + fhi) ^ fswz) << 4);
+
+  // Fragment reads are inline asm: hipcc drains vmcnt(0) before any ds_read it can see while an LDS-DMA is in flight (it cannot
+  // prove the read does not alias the DMA target), which would serialise the whole ring.  The asm reads are ordered by hand:
+  // fragments of k-step ks+1 are issued before the MFMAs of k-step ks, `s_waitcnt lgkmcnt(0)` + sched_barrier precede their use.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto lds_read = [&](uint32_t addr) -> uint4 {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  auto read_frags = [&](uint32_t sA, uint32_t sW, int ks, Frag (&fa)[NPL][TM], Frag (&fw)[NPL][TN]) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[p][j].u = lds_read(sA + j * 32 * GEMM_KTB + foff[p][ks]);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[p][i].u = lds_read(sW + i * 32 * GEMM_KTB + foff[p][ks]);
+    }
+  };
+  auto mma_step = [&](const Frag (&fa)[NPL][TM], const Frag (&fw)[NPL][TN]) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        Mma32<T>::mma(acc[j][i], fw[0][i], fa[0][j]);
+        if constexpr (NPL == 2) {
+          Mma32<T>::mma(acc[j][i], fw[0][i], fa[1][j]);
+          Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);
+        }
+      }
+  };
+  auto compute = [&](int stage) {
+    const uint32_t sA = lds0 + stage * STAGE + (wm * 32 * TM) * GEMM_KTB;
+    const uint32_t sW = lds0 + stage * STAGE + TILE_A + (wn * 32 * TN) * GEMM_KTB;
+    Frag fa0[NPL][TM], fw0[NPL][TN], fa1[NPL][TM], fw1[NPL][TN];
+    read_frags(sA, sW, 0, fa0, fw0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks += 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sA, sW, ks + 1, fa1, fw1);
+      mma_step(fa0, fw0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < KSTEPS) read_frags(sA, sW, ks + 2, fa0, fw0);
+      mma_step(fa1, fw1);
+    }
+  };
+
+  const int nkt = (kbytes + GEMM_KTB - 1) / GEMM_KTB;
+  issue(0, 0);
+  issue(1, 1);
+  wait_vmcnt<LPT>();  // tile 0 landed (this wave's pieces); tile 1 in flight
+  wg_barrier();
+  int st = 0;  // stage of tile kt
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int st2 = st == 0 ? 2 : st - 1;  // (st + 2) % 3: the stage phase kt-1 finished reading before the last barrier
+    issue(kt + 2, st2);                    // past the end: zeros, never read
+    compute(st);
+    wait_vmcnt<LPT>();                     // tile kt+1 landed; tile kt+2 stays in flight across the barrier
+    wg_barrier();
+    st = st == 2 ? 0 : st + 1;
+  }
+  wait_vmcnt<0>();  // drain the two dummy tiles before the workgroup's LDS is released
+
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * 32 * TM + j * 32 + (lane & 31);
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 32 * TN + i * 32 + 8 * q + 4 * (lane >> 5);
+        if (n < g.N) epi(m, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]), z);
+      }
+    }
+  }
+}

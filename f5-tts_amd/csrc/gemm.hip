@@ -1,4 +1,5 @@
 // gemm.hip — instantiations and launch heuristics of the MFMA GEMM (gemm.h)
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -73,11 +74,35 @@ hipError_t launch_one(const GemmCore& g, const Epi& e, int batch, hipStream_t s)
 }
 
 int pick_variant(const GemmCore& g, int batch) {
+  static const int forced = [] { const char* e = getenv("F5HIP_GEMM_VARIANT"); return e ? atoi(e) : -1; }();  // tuning / test knob
+  if (forced >= 0) return forced;
   if (g.M <= 64) return 0;
   // 128x64 tiles (3 workgroups per CU) until the grid is several waves deep, then 128x128 (higher FLOP per byte staged):
   // measured crossover between M = 2812 (B=1: 128x64 wins on all four block GEMMs) and M = 22496 (B=8: 128x128 wins).
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
-  return big >= 1024 ? 2 : 1;
+  if (big >= 1024) return 2;
+  // small grids: the direct-to-LDS ring (variant 6) wins where the tile count is lowest (N <= 1024: out-projection, FF2: -10 %),
+  // the register-staged kernel elsewhere (tools/kernel_bench.py, B=1)
+  return (g.N <= 1024 && g.M > 256 && batch == 1) ? 6 : 1;
+}
+
+// direct-to-LDS ring variants (variant ids 6 = 128x64, 7 = 128x128, 3-stage ring)
+template <typename T, int NSPLIT, int TM, int TN, typename Epi>
+hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
+  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, TM, TN>();
+  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    attr_done = true;
+  }
+  if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
+    return hipErrorInvalidValue;
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, e);
+  return hipGetLastError();
 }
 
 // microbenchmark ablations of the 128x128 variant (variant id 8 + ABL); EpiStore only
@@ -103,6 +128,8 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 3: return launch_one<T, NSPLIT, 3, Epi>(g, e, batch, s);
     case 4: return launch_one<T, NSPLIT, 4, Epi>(g, e, batch, s);
     case 5: return launch_one<T, NSPLIT, 5, Epi>(g, e, batch, s);
+    case 6: return launch_glds<T, NSPLIT, 2, 1, Epi>(g, e, batch, s);
+    case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
     default: break;
   }
   if constexpr (std::is_same<Epi, EpiStore>::value && !std::is_same<T, float>::value) {
