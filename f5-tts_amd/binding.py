@@ -41,8 +41,8 @@ SYMBOLS = {
     "f5hip_mark_all_loaded": (C.c_int, [_P]),
     "f5hip_finalize_weights": (C.c_int, [_P]),
     "f5hip_mel": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int, _P]),
-    "f5hip_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int,
-                               _P, _P, _P]),
+    "f5hip_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float,
+                               C.c_int, _P, _P, _P]),
     "f5hip_debug_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "f5hip_vocos_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "f5hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),

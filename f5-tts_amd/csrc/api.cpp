@@ -235,6 +235,15 @@ EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_N
 
 double gemm_flops(int64_t M, int64_t N, int64_t K) { return 2.0 * (double)M * (double)N * (double)K; }
 
+// One function evaluation of the ODE solve: which time-table row it uses and which state buffers it reads / updates.
+struct Stage {
+  int eidx;            // row of the per-evaluation time tables (embeddings, AdaLN modulations, update coefficient)
+  const float* yin;    // state the backbone is evaluated on            [B*n, mel]
+  const float* ybase;  // dst = ybase + coef[eidx] * velocity
+  float* ydst;
+  float* traj;         // optional copy of dst (trajectory slot) or null
+};
+
 // weight operand of a block GEMM in the given operand mode: fp32 blob rows, plain fp16 rows, or packed hi/lo rows
 const void* wsel(int op, const float* w32, const f16* hi, const f16* pk) {
   return op == OP_F32 ? (const void*)w32 : op == OP_F16 ? (const void*)hi : (const void*)pk;
@@ -424,21 +433,21 @@ int finalize_impl(f5hip_ctx* ctx) {
 }
 
 // ---- time-grid tables: every step's time embedding and AdaLN modulation in 4 GEMMs -------------------
-int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, hipStream_t st) {
+// te: the E evaluation times of the solve (euler: t_0..t_{steps-1}; midpoint: t_i and t_i + dt_i/2); coef: the E update coefficients
+int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, float cfg_strength, hipStream_t st) {
   const auto& c = ctx->cfg;
   const int64_t D = c.dim;
   const std::string p = "transformer.";
-  std::vector<float> dt(steps);
-  for (int i = 0; i < steps; ++i) dt[i] = t[i + 1] - t[i];
+  const float* t = te;
   HIPCHK(ctx->dt_dev.ensure(std::max(steps, 64) * sizeof(float)));
   HIPCHK(ctx->cfg_dev.ensure(16));
-  HIPCHK(hipMemcpyAsync(ctx->dt_dev.p, dt.data(), steps * sizeof(float), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->dt_dev.p, coef, steps * sizeof(float), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->cfg_dev.p, &cfg_strength, sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // dt / cfg are stack temporaries
-  const bool same = (int)ctx->t_host.size() == steps + 1 && memcmp(ctx->t_host.data(), t, (steps + 1) * sizeof(float)) == 0;
+  HIPCHK(hipStreamSynchronize(st));  // coef / cfg may be temporaries of the caller
+  const bool same = (int)ctx->t_host.size() == steps && memcmp(ctx->t_host.data(), t, steps * sizeof(float)) == 0;
   if (same) return F5HIP_OK;
   bool moved = false;
-  HIPCHK(ctx->t_dev.ensure((steps + 1) * sizeof(float), &moved));
+  HIPCHK(ctx->t_dev.ensure(steps * sizeof(float), &moved));
   HIPCHK(ctx->tsin.ensure((size_t)steps * 256 * sizeof(float), &moved));
   HIPCHK(ctx->th1.ensure((size_t)steps * D * sizeof(float), &moved));
   HIPCHK(ctx->tsilu.ensure((size_t)steps * D * sizeof(float), &moved));
@@ -450,8 +459,8 @@ int prepare_time(f5hip_ctx* ctx, const float* t, int steps, float cfg_strength, 
     HIPCHK(ctx->fmods.ensure((size_t)steps * 2 * D * sizeof(float), &moved));
   }
   if (moved) ctx->ws_epoch++;
-  ctx->t_host.assign(t, t + steps + 1);
-  HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ctx->t_host.data(), (steps + 1) * sizeof(float), hipMemcpyHostToDevice, st));
+  ctx->t_host.assign(t, t + steps);
+  HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ctx->t_host.data(), steps * sizeof(float), hipMemcpyHostToDevice, st));
   {
     Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
     HIPCHK(launch_time_sinus(ctx->t_dev.as<float>(), steps, 256, ctx->tsin.as<float>(), st));
@@ -574,8 +583,9 @@ int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const i
                   int64_t ldO, hipStream_t st) {
   const auto& c = ctx->cfg;
   const int H = c.heads, dh = c.dim_head, inner = H * dh;
+  const int S = ctx->nb * B;  // packed sequences: cond (+ uncond with CFG)
   {
-      Prof pr(ctx, st, KC_ATTN, 4.0 * (double)(2 * B) * H * (double)n * n * dh, 0);
+      Prof pr(ctx, st, KC_ATTN, 4.0 * (double)S * H * (double)n * n * dh, 0);
       if (exact_attn) {
         // materialised-score attention in fp32: S = QK^T (batched GEMM), row softmax, O = PV (batched GEMM)
         const int np = (n + 3) & ~3;
@@ -583,8 +593,8 @@ int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const i
         g.w_rows = n; g.strideA = (int64_t)n * dh; g.strideW = (int64_t)n * dh;
         EpiStore e = epi_store(ctx->scores.as<float>(), np, nullptr);
         e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
-        HIPCHK(launch_gemm_store(OP_F32, g, e, 2 * B * H, st));
-        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)2 * B * H * n, np, n, H, kvlen, n, st));
+        HIPCHK(launch_gemm_store(OP_F32, g, e, S * H, st));
+        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)S * H * n, np, n, H, kvlen, n, st));
         g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
         g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
         EpiStore e2 = epi_store(o32, inner, nullptr);
@@ -593,25 +603,26 @@ int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const i
           e2.out16 = o_hi; e2.out16_lo = o_lo; e2.pk16 = pk; e2.ldo16 = ldO;
           e2.so1_16 = (int64_t)n * ldO; e2.so2_16 = dh;
         }
-        HIPCHK(launch_gemm_store(OP_F32, g, e2, 2 * B * H, st));
+        HIPCHK(launch_gemm_store(OP_F32, g, e2, S * H, st));
       } else {
         // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
         // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
         const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
         HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
                                  x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
-                                 (n + 7) & ~7, 2 * B, H, n, kvlen, o_hi, o_lo, st, pk));
+                                 (n + 7) & ~7, S, H, n, kvlen, o_hi, o_lo, st, pk));
       }
     }
   return F5HIP_OK;
 }
 
 // ---- one ODE function evaluation + Euler update ---------------------------------------------------
-int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st) {
+  const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
   const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
   const int64_t BN = (int64_t)B * n;
-  const int M = (int)(2 * BN);
+  const int M = (int)(nb * BN);
   const std::string p = "transformer.";
   const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;
   float* x = ctx->x.as<float>();
@@ -621,20 +632,20 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
 
   {  // InputEmbedding.proj: only the x columns are per-step (dit.py:162); cond/text part is in cconst
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
-    GemmCore g = core(ctx->y.p, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
+    GemmCore g = core(sg.yin, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
     EpiStore e = epi_store(h, D, nullptr);
     e.res = ctx->cconst.as<float>(); e.ldres = D;
-    e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D;
+    if (nb == 2) { e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D; }  // uncond rows: same x columns, uncond constant part
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
   }
   {  // ConvPositionEmbedding + residual (dit.py:163, modules.py:187-201)
     const int cpg = D / c.conv_pos_groups;
     Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops(M, D, (int64_t)cpg * c.conv_pos_kernel) * (npl == 3 ? 1 : 1), 0);
     HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
-                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, 2 * B, n, D, c.conv_pos_groups,
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, nb * B, n, D, c.conv_pos_groups,
                           c.conv_pos_kernel, ctx->c1.as<float>(), st));
     HIPCHK(launch_convpos(op, ctx->c1.as<float>(), ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
-                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, 2 * B, n, D, c.conv_pos_groups,
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, nb * B, n, D, c.conv_pos_groups,
                           c.conv_pos_kernel, x, st));
   }
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
@@ -715,18 +726,19 @@ int run_step(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, in
   }
   {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
-    HIPCHK(launch_cfg_euler(ctx->y.as<float>(), ctx->vel.as<float>(), BN * mel, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
-                            traj ? traj + (int64_t)(step + 1) * BN * mel : nullptr, ctx->dbg_vel.as<float>(), st));
+    HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            sg.traj, ctx->dbg_vel.as<float>(), st));
   }
   return F5HIP_OK;
 }
 
 
 // ---- one ODE function evaluation + Euler update, UNetT backbone (reference src/f5_tts/model/backbones/unett.py:244-307) -------------
-int run_step_unett(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st) {
+  const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
   const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
-  const int ns = n + 1, S = 2 * B;
+  const int ns = n + 1, S = nb * B;
   const int64_t BN = (int64_t)B * n;
   const int M = S * ns;
   const std::string p = "transformer.";
@@ -762,10 +774,10 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_at
 
   {  // InputEmbedding.proj (unett.py:100): per-step x columns + the step-invariant cond/text part
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
-    GemmCore g = core(ctx->y.p, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
+    GemmCore g = core(sg.yin, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
     EpiStore e = epi_store(h, D, nullptr);
     e.res = ctx->cconst.as<float>(); e.ldres = D;
-    e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D;
+    if (nb == 2) { e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D; }
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
   }
   {  // ConvPositionEmbedding WITHOUT a mask (unett.py:101) + residual, written behind the time token of each sequence
@@ -857,16 +869,29 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, int step, int op, bool exact_at
   }
   {
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
-    HIPCHK(launch_cfg_euler(ctx->y.as<float>(), ctx->vel.as<float>(), BN * mel, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
-                            traj ? traj + (int64_t)(step + 1) * BN * mel : nullptr, ctx->dbg_vel.as<float>(), st));
+    HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            sg.traj, ctx->dbg_vel.as<float>(), st));
   }
   return F5HIP_OK;
 }
 
-int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+// The whole solve on the given evaluation tables: euler = one evaluation per step; midpoint (torchdiffeq fixed-grid "midpoint":
+// y_mid = y + f(t, y) dt/2; y += dt f(t + dt/2, y_mid)) = two, through the scratch state ymid.
+int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int method, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
   const bool unett = ctx->cfg.backbone == 1;
-  for (int s = 0; s < steps; ++s) CHK(unett ? run_step_unett(ctx, B, n, s, op, exact_attn, use_mask, traj, st)
-                                            : run_step(ctx, B, n, s, op, exact_attn, use_mask, traj, st));
+  const int64_t slab = (int64_t)B * n * ctx->cfg.mel_dim;
+  float* y = ctx->y.as<float>();
+  float* ymid = ctx->ymid.as<float>();
+  auto eval = [&](const Stage& sg) { return unett ? run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, st) : run_step(ctx, B, n, sg, op, exact_attn, use_mask, st); };
+  for (int s = 0; s < steps; ++s) {
+    float* tr = traj ? traj + (int64_t)(s + 1) * slab : nullptr;
+    if (method == 0) {
+      CHK(eval(Stage{s, y, y, y, tr}));
+    } else {
+      CHK(eval(Stage{2 * s, y, y, ymid, nullptr}));
+      CHK(eval(Stage{2 * s + 1, ymid, y, y, tr}));
+    }
+  }
   return F5HIP_OK;
 }
 
@@ -922,7 +947,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
-                    &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
+                    &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
@@ -1028,15 +1053,15 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float*
 
 // ---- sampler -------------------------------------------------------------------------------------
 int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t* cond_mask, const int64_t* text, int nt,
-                 const int64_t* duration, int use_mask, const float* y0, const float* t, int steps, float cfg_strength, int precision,
-                 float* out, float* trajectory, void* stream) {
+                 const int64_t* duration, int use_mask, const float* y0, const float* t, int steps, int ode_method, float cfg_strength,
+                 int precision, float* out, float* trajectory, void* stream) {
   if (!ctx) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
   if (!cond || !cond_mask || !text || !duration || !y0 || !t || !out) FAIL(F5HIP_ERR_INVALID, "null argument");
   if (B <= 0 || n <= 0 || steps <= 0 || nt <= 0) FAIL(F5HIP_ERR_INVALID, "batch, n, nt and steps must be positive");
   if (n > 8192 && ctx->cfg.conv_layers > 0) FAIL(F5HIP_ERR_INVALID, "n=%d exceeds the 8192-frame text position table (dit.py:47)", n);
-  if (cfg_strength < 1e-5f) FAIL(F5HIP_ERR_UNSUPPORTED, "cfg_strength < 1e-5 (single-branch forward) is not built");
+  if (ode_method != 0 && ode_method != 1) FAIL(F5HIP_ERR_UNSUPPORTED, "ode_method %d: only euler (0) and midpoint (1) are built", ode_method);
   if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
   for (int b = 0; b < B; ++b)
     if (duration[b] <= 0 || duration[b] > n) FAIL(F5HIP_ERR_INVALID, "duration[%d]=%lld outside (0, n=%d]", b, (long long)duration[b], n);
@@ -1051,8 +1076,21 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   const int mel = c.mel_dim, D = c.dim;
   const int64_t BN = (int64_t)B * n;
 
+  // cfg_strength < 1e-5: the reference evaluates only the conditional branch (cfm.py:166-177); otherwise cond + uncond rows are packed
+  const int nb = cfg_strength < 1e-5f ? 1 : 2;
+  if (ctx->nb != nb) { ctx->nb = nb; ctx->ws_epoch++; }
   CHK(ensure_workspace(ctx, B, n, op, exact_attn));
-  CHK(prepare_time(ctx, t, steps, cfg_strength, st));
+  HIPCHK(ctx->ymid.ensure((size_t)BN * mel * sizeof(float)));
+  {  // evaluation times and update coefficients of the chosen fixed-grid solver (torchdiffeq euler / midpoint on the supplied grid)
+    const int E = ode_method == 0 ? steps : 2 * steps;
+    std::vector<float> te(E), coef(E);
+    for (int i = 0; i < steps; ++i) {
+      const float dt = t[i + 1] - t[i];
+      if (ode_method == 0) { te[i] = t[i]; coef[i] = dt; }
+      else { const float half = 0.5f * dt; te[2 * i] = t[i]; coef[2 * i] = half; te[2 * i + 1] = t[i] + half; coef[2 * i + 1] = dt; }
+    }
+    CHK(prepare_time(ctx, te.data(), coef.data(), E, cfg_strength, st));
+  }
 
   // masks (cfm.py:128-158)
   {
@@ -1099,24 +1137,24 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   if (ctx->use_graph && !ctx->profile) {
     auto& k = ctx->graph_key;
     const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
-                     k.traj == trajectory && k.ws_epoch == ctx->ws_epoch;
+                     k.method == ode_method && k.traj == trajectory && k.ws_epoch == ctx->ws_epoch;
     if (!hit) {
       if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
       if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
-      int r = enqueue_steps(ctx, B, n, steps, op, exact_attn, use_mask, trajectory, ctx->cap_stream);
+      int r = enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, trajectory, ctx->cap_stream);
       hipError_t ce = hipStreamEndCapture(ctx->cap_stream, &graph);
       if (r != F5HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
       HIPCHK(ce);
       HIPCHK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.traj = trajectory; k.ws_epoch = ctx->ws_epoch;
+      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = trajectory; k.ws_epoch = ctx->ws_epoch;
     }
     HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
     done = true;
   }
-  if (!done) CHK(enqueue_steps(ctx, B, n, steps, op, exact_attn, use_mask, trajectory, st));
+  if (!done) CHK(enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, trajectory, st));
 
   {  // out = where(cond_mask, cond, y_final) (cfm.py:221-223)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 0);

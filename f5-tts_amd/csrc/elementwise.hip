@@ -228,17 +228,19 @@ __global__ void where_rows_kernel(const uint8_t* mask, const float* a, const flo
 }
 
 // v [2*half]: first half cond prediction, second half uncond.  (reference cfm.py:190-191; euler step)
-__global__ void cfg_euler_kernel(float* y, const float* __restrict__ v, int64_t half4, const float* dt_ptr, const float* cfg_ptr,
-                                 float* traj_next, float* vel_dbg) {
-  const float dt = *dt_ptr, cfg = *cfg_ptr;
+__global__ void cfg_euler_kernel(const float* __restrict__ base, float* dst, const float* __restrict__ v, int64_t half4, int has_uncond,
+                                 const float* coef_ptr, const float* cfg_ptr, float* traj_next, float* vel_dbg) {
+  const float dt = *coef_ptr, cfg = *cfg_ptr;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half4; i += (int64_t)gridDim.x * blockDim.x) {
     const float4 c = reinterpret_cast<const float4*>(v)[i];
-    const float4 u = reinterpret_cast<const float4*>(v)[half4 + i];
-    float4 yy = reinterpret_cast<float4*>(y)[i];
-    float4 g;
-    g.x = c.x + (c.x - u.x) * cfg; g.y = c.y + (c.y - u.y) * cfg; g.z = c.z + (c.z - u.z) * cfg; g.w = c.w + (c.w - u.w) * cfg;
+    float4 g = c;
+    if (has_uncond) {
+      const float4 u = reinterpret_cast<const float4*>(v)[half4 + i];
+      g.x = c.x + (c.x - u.x) * cfg; g.y = c.y + (c.y - u.y) * cfg; g.z = c.z + (c.z - u.z) * cfg; g.w = c.w + (c.w - u.w) * cfg;
+    }
+    float4 yy = reinterpret_cast<const float4*>(base)[i];
     yy.x += dt * g.x; yy.y += dt * g.y; yy.z += dt * g.z; yy.w += dt * g.w;
-    reinterpret_cast<float4*>(y)[i] = yy;
+    reinterpret_cast<float4*>(dst)[i] = yy;
     if (traj_next) reinterpret_cast<float4*>(traj_next)[i] = yy;
     if (vel_dbg) reinterpret_cast<float4*>(vel_dbg)[i] = g;
   }
@@ -417,11 +419,11 @@ hipError_t launch_where_rows(const uint8_t* mask, const float* a, const float* b
   hipLaunchKernelGGL(where_rows_kernel, dim3(grid_1d(rows * (C / 4))), dim3(256), 0, s, mask, a, b, rows, C / 4, out);
   return hipGetLastError();
 }
-hipError_t launch_cfg_euler(float* y, const float* v, int64_t half_elems, const float* dt_ptr, const float* cfg_ptr, float* traj_next,
-                            float* vel_dbg, hipStream_t s) {
+hipError_t launch_cfg_euler(const float* base, float* dst, const float* v, int64_t half_elems, int has_uncond, const float* coef_ptr,
+                            const float* cfg_ptr, float* traj_next, float* vel_dbg, hipStream_t s) {
   if (half_elems % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_1d(half_elems / 4)), dim3(256), 0, s, y, v, half_elems / 4, dt_ptr, cfg_ptr, traj_next,
-                     vel_dbg);
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_1d(half_elems / 4)), dim3(256), 0, s, base, dst, v, half_elems / 4, has_uncond, coef_ptr, cfg_ptr,
+                     traj_next, vel_dbg);
   return hipGetLastError();
 }
 hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStream_t s) {

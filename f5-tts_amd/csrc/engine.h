@@ -135,7 +135,8 @@ struct f5hip_ctx {
   DevBuf step_cond, cconst, y, h, c1, x;
   DevBuf a32, a_hi, o32, o_hi, f32, f_hi;  // *_hi: plain fp16 rows, or packed hi/lo rows (twice the size) in fp16x3 mode
   DevBuf q32, k32, vt32, scores, q16, k16, vt16, q16_lo, k16_lo, vt16_lo;
-  DevBuf vel, rope, dbg_vel;
+  DevBuf vel, rope, dbg_vel, ymid;     // ymid: scratch ODE state of the midpoint solver
+  int nb = 2;                          // packed branches per utterance: 2 = cond + uncond (CFG), 1 = cond only (cfg_strength < 1e-5)
   // vocos workspace
   DevBuf vcol, vx, va, vh, vlogits, vframes;
 
@@ -153,7 +154,7 @@ struct f5hip_ctx {
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
-    int B = 0, n = 0, steps = 0, prec = -1, use_mask = 0;
+    int B = 0, n = 0, steps = 0, prec = -1, use_mask = 0, method = 0;
     float* traj = nullptr;
     uint64_t ws_epoch = 0;
   } graph_key;

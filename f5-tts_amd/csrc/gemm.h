@@ -166,7 +166,7 @@ constexpr int gemm_lds_bytes() {
   return 2 * (32 * WGM * TM + 32 * WGN * TN) * GEMM_KTB;
 }
 
-// ABL (microbenchmark ablations only): bit0 = no global loads in the k-loop, bit1 = no LDS stores, bit2 = no MFMAs.
+// ABL (microbenchmark ablations only): bit0 = no global loads in the k-loop, bit1 = no LDS stores, bit2 = no MFMAs, bit3 = no epilogue.
 template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi epi) {
   constexpr int NT = 64 * WGM * WGN;
@@ -323,7 +323,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 32 * TN + i * 32 + 8 * q + 4 * (lane >> 5);
-        if (n < g.N) epi(m, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]), z);
+        if constexpr (ABL & 8) {  // no epilogue: keep the accumulators alive
+          asm volatile("" ::"v"(acc[j][i][4 * q]), "v"(acc[j][i][4 * q + 1]), "v"(acc[j][i][4 * q + 2]), "v"(acc[j][i][4 * q + 3]));
+        } else {
+          if (n < g.N) epi(m, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]), z);
+        }
       }
     }
   }

@@ -27,6 +27,7 @@ F5_VARIANT(2, 2, 2, 2, 2);
 F5_VARIANT(3, 2, 2, 4, 2);
 F5_VARIANT(4, 2, 2, 2, 4);
 F5_VARIANT(5, 2, 2, 4, 4);
+F5_VARIANT(8, 1, 1, 2, 2);  // 64x64
 #undef F5_VARIANT
 
 template <typename T, int NSPLIT, int ID, typename Epi>
@@ -47,6 +48,7 @@ hipError_t set_attrs_op() {
   if ((e = set_attr<T, NSPLIT, 3, Epi>()) != hipSuccess) return e;
   if ((e = set_attr<T, NSPLIT, 4, Epi>()) != hipSuccess) return e;
   if ((e = set_attr<T, NSPLIT, 5, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 8, Epi>()) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -106,9 +108,9 @@ hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s
 }
 
 // microbenchmark ablations of the 128x128 variant (variant id 8 + ABL); EpiStore only
-template <typename T, int NSPLIT, int ABL, typename Epi>
+template <typename T, int NSPLIT, int ABL, typename Epi, int VID = 2>
 hipError_t launch_abl(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
-  using C = Variant<T, NSPLIT, 2>;
+  using C = Variant<T, NSPLIT, VID>;
   constexpr int lds = gemm_lds_bytes<T, NSPLIT, C::TM, C::TN, C::WGM, C::WGN>();
   auto kern = gemm_kernel<T, NSPLIT, C::TM, C::TN, Epi, C::WGM, C::WGN, ABL>;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -130,6 +132,7 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 5: return launch_one<T, NSPLIT, 5, Epi>(g, e, batch, s);
     case 6: return launch_glds<T, NSPLIT, 2, 1, Epi>(g, e, batch, s);
     case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
+    case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     default: break;
   }
   if constexpr (std::is_same<Epi, EpiStore>::value && !std::is_same<T, float>::value) {
@@ -139,6 +142,10 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
       case 11: return launch_abl<T, NSPLIT, 3, Epi>(g, e, batch, s);
       case 12: return launch_abl<T, NSPLIT, 4, Epi>(g, e, batch, s);
       case 15: return launch_abl<T, NSPLIT, 7, Epi>(g, e, batch, s);
+      case 17: return launch_abl<T, NSPLIT, 8, Epi, 1>(g, e, batch, s);   // 128x64: no epilogue
+      case 18: return launch_abl<T, NSPLIT, 4, Epi, 1>(g, e, batch, s);   // 128x64: no MFMA
+      case 19: return launch_abl<T, NSPLIT, 15, Epi, 1>(g, e, batch, s);  // 128x64: prologue + reads + barriers only
+      case 20: return launch_abl<T, NSPLIT, 3, Epi, 1>(g, e, batch, s);   // 128x64: no loads / LDS stores in the loop
       default: break;
     }
   }

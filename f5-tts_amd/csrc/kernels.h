@@ -46,9 +46,10 @@ hipError_t launch_zero_rows(float* x, const uint8_t* mask, int64_t rows, int C, 
 hipError_t launch_mask_select(const float* a, const uint8_t* mask, int64_t rows, int C, float* out, hipStream_t s);
 // out = where(mask, a, b)
 hipError_t launch_where_rows(const uint8_t* mask, const float* a, const float* b, int64_t rows, int C, float* out, hipStream_t s);
-// CFG + Euler (reference cfm.py:190-191 + torchdiffeq euler): y += dt * (vc + (vc - vu) * cfg); optional copies
-hipError_t launch_cfg_euler(float* y, const float* v, int64_t half_elems, const float* dt_ptr, const float* cfg_ptr,
-                            float* traj_next, float* vel_dbg, hipStream_t s);
+// CFG combine + one explicit ODE stage (reference cfm.py:190-191 + torchdiffeq fixed-grid euler / midpoint stages):
+//   g = has_uncond ? vc + (vc - vu) * cfg : vc;   dst = base + coef * g;   optional copies of dst (trajectory) and g (debug tap)
+hipError_t launch_cfg_euler(const float* base, float* dst, const float* v, int64_t half_elems, int has_uncond, const float* coef_ptr,
+                            const float* cfg_ptr, float* traj_next, float* vel_dbg, hipStream_t s);
 // sinusoidal time embedding (reference model/modules.py:157-169): t [S] -> out [S, 256]
 hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStream_t s);
 // rope table: out [n, dh/2, 2] = (cos, sin)(pos * inv_freq[i])

@@ -176,7 +176,8 @@ class F5HipEngine:
         return out
 
     def sample(self, cond: torch.Tensor, cond_mask: torch.Tensor, text: torch.Tensor, duration: torch.Tensor, use_mask: bool,
-               y0: torch.Tensor, t: torch.Tensor, cfg_strength: float, precision: str = "fp32", want_trajectory: bool = True):
+               y0: torch.Tensor, t: torch.Tensor, cfg_strength: float, precision: str = "fp32", want_trajectory: bool = True,
+               ode_method: str = "euler"):
         b, n, mel = cond.shape
         cond = cond.to(device=self.device, dtype=torch.float32).contiguous()
         y0 = y0.to(device=self.device, dtype=torch.float32).contiguous()
@@ -189,7 +190,8 @@ class F5HipEngine:
         traj = torch.empty((steps + 1, b, n, mel), device=self.device, dtype=torch.float32) if want_trajectory else None
         with torch.cuda.device(self.device):
             self._chk(self.lib.f5hip_sample(self._ctx, b, n, _ptr(cond), _ptr(cm), _ptr(tx), tx.shape[1], _ptr(du), int(use_mask),
-                                            _ptr(y0), _ptr(tt), steps, float(cfg_strength), PRECISIONS[precision], _ptr(out),
+                                            _ptr(y0), _ptr(tt), steps, {"euler": 0, "midpoint": 1}[ode_method], float(cfg_strength),
+                                            PRECISIONS[precision], _ptr(out),
                                             _ptr(traj), self._stream()))
         return out, traj
 
@@ -250,8 +252,9 @@ class F5HipCFM:
 
     def __init__(self, engine: F5HipEngine, vocab_char_map: Optional[Dict[str, int]] = None, ode_method: str = "euler",
                  precision: str = "fp32"):
-        if ode_method != "euler":
-            raise ValueError("only the euler solver is built (reference default, utils_infer.py:60)")
+        if ode_method not in ("euler", "midpoint"):
+            raise ValueError("only the fixed-grid euler / midpoint solvers are built (reference utils_infer.py:60, eval_infer_batch.py:47)")
+        self.ode_method = ode_method
         self.engine = engine
         self.vocab_char_map = vocab_char_map
         self.precision = precision
@@ -318,7 +321,7 @@ class F5HipCFM:
         if sway_sampling_coef is not None:
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
         out, trajectory = self.engine.sample(cond, cond_mask, text, duration, use_mask, y0, t, cfg_strength,
-                                             precision=self.precision, want_trajectory=True)
+                                             precision=self.precision, want_trajectory=True, ode_method=self.ode_method)
         if vocoder is not None:  # cfm.py:225-227
             out = vocoder(out.permute(0, 2, 1))
         return out, trajectory

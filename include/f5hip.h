@@ -118,13 +118,15 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t n_samples, fl
  *                   use_mask != 0 <=> the reference passes mask = lens_to_mask(duration) (batch > 1, cfm.py:155-158)
  *   y0              device fp32 [batch, n, mel]: initial noise (cfm.py:196-201), zero on padding rows
  *   t               host fp32 [steps + 1]: the time grid (cfm.py:211-216)
- *   cfg_strength    classifier-free guidance strength (>= 1e-5; the no-CFG branch is F5HIP_ERR_UNSUPPORTED)
+ *   ode_method      0 = euler (reference default, utils_infer.py:60), 1 = midpoint — torchdiffeq fixed-grid solvers on exactly the
+ *                   supplied grid (odeint_kwargs["method"], cfm.py:218); NFE = steps (euler) / 2*steps (midpoint)
+ *   cfg_strength    classifier-free guidance strength; < 1e-5 evaluates the conditional branch only (cfm.py:166-177)
  *   precision       F5HIP_PREC_*
  *   out             device fp32 [batch, n, mel]: where(cond_mask, cond, y_final)
  *   trajectory      device fp32 [steps + 1, batch, n, mel] or NULL: every ODE state (cfm.py:218 return value)
  */
 int f5hip_sample(f5hip_ctx* ctx, int batch, int n, const float* cond, const uint8_t* cond_mask, const int64_t* text,
-                 int nt, const int64_t* duration, int use_mask, const float* y0, const float* t, int steps,
+                 int nt, const int64_t* duration, int use_mask, const float* y0, const float* t, int steps, int ode_method,
                  float cfg_strength, int precision, float* out, float* trajectory, void* stream);
 
 /* Debug/parity taps (tests only): copies of internal tensors of the LAST f5hip_sample call.

@@ -359,8 +359,8 @@ def make_noise(duration: Tensor, mel_dim: int, seed: Optional[int]) -> Tensor:
 def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optional[Tensor] = None, steps: int = 32,
                cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None, seed: Optional[int] = None,
                max_duration: int = 65536, use_epss: bool = True, edit_mask: Optional[Tensor] = None,
-               return_steps: bool = False):
-    """src/f5_tts/model/cfm.py:83-229 with a DiT or UNetT backbone (cfg.backbone), CFG on (cfg_strength >= 1e-5), euler.
+               return_steps: bool = False, method: str = "euler"):
+    """src/f5_tts/model/cfm.py:83-229 with a DiT or UNetT backbone (cfg.backbone), with or without CFG, fixed-grid euler / midpoint.
     cond: wave [b, nw] or mel [b, n, mel]; text: int64 [b, nt] (already tokenised, -1 padded)."""
     if cond.ndim == 2:
         cond = vocos_mel(cond).permute(0, 2, 1)
@@ -396,11 +396,23 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
     t = time_grid(steps, sway_sampling_coef, use_epss)
     traj = [y]
     vel = []
-    for i in range(steps):  # torchdiffeq euler on the supplied grid (cfm.py:218)
-        pred_cfg = forward_cfg(sd, cfg, y, step_cond, text_cond, text_uncond, t[i], mask)
+    def fn(ti, x):  # cfm.py:162-191
+        pred_cfg = forward_cfg(sd, cfg, x, step_cond, text_cond, text_uncond, ti, mask)
         pred, null = torch.chunk(pred_cfg, 2, dim=0)
-        v = pred + (pred - null) * cfg_strength  # cfm.py:190-191
-        y = y + (t[i + 1] - t[i]) * v
+        if cfg_strength < 1e-5:  # single conditional branch (cfm.py:166-177); rows are independent, so the packed cond half is it
+            return pred
+        return pred + (pred - null) * cfg_strength  # cfm.py:190-191
+
+    for i in range(steps):  # torchdiffeq fixed-grid solvers on the supplied grid (cfm.py:218)
+        dt = t[i + 1] - t[i]
+        if method == "euler":
+            v = fn(t[i], y)
+        elif method == "midpoint":  # y_mid = y + f(t, y) dt/2;  y += dt f(t + dt/2, y_mid)
+            half = 0.5 * dt
+            v = fn(t[i] + half, y + fn(t[i], y) * half)
+        else:
+            raise ValueError(method)
+        y = y + dt * v
         traj.append(y)
         if return_steps:
             vel.append(v)

@@ -53,6 +53,11 @@ CASES = {
                             kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
     "tiny_unett_ragged_b2": dict(preset="tiny_unett", wseed=3, nw=256 * 50, wavseed=6, batch=2, nt=30, tseed=4, duration=[140, 111],
                                  lens=[51, 40], pad_from=22, kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
+    # solver / guidance variants of the sampler itself (cfm.py:166-177 single branch; odeint_kwargs method="midpoint")
+    "tiny_v1_midpoint": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=1, nt=24, tseed=8, duration=120, lens=None, method="midpoint",
+                             kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)),
+    "tiny_v1_nocfg_b2": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=2, nt=24, tseed=8, duration=[120, 97], lens=[41, 33],
+                             pad_from=18, kw=dict(steps=6, cfg_strength=0.0, sway_sampling_coef=None, seed=9)),
     "tiny_v1_b3_fixed": dict(preset="tiny", wseed=1, nw=256 * 30, wavseed=9, batch=3, nt=20, tseed=6, duration=96, lens=None,
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
@@ -74,10 +79,10 @@ def case_inputs(c):
     return cfg, wav, text, duration, lens
 
 
-def build_reference(cfg, sd):
+def build_reference(cfg, sd, method="euler"):
     CFM, DiT, UNetT = ref_shims.reference_classes()
     backbone = UNetT if cfg.backbone == "UNetT" else DiT
-    model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method="euler"))
+    model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method=method))
     model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
     return model.eval()
 
@@ -85,12 +90,13 @@ def build_reference(cfg, sd):
 def run_case(name, c, pins):
     cfg, wav, text, duration, lens = case_inputs(c)
     sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
-    model = build_reference(cfg, sd)
+    method = c.get("method", "euler")
+    model = build_reference(cfg, sd, method)
     t0 = time.time()
     with torch.no_grad():
         out, traj = model.sample(wav, text, duration, lens=lens, **c["kw"])
     t_ref = time.time() - t0
-    out_o, traj_o = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+    out_o, traj_o = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, method=method, **c["kw"])
     d = (out - out_o).abs().max().item()
     dt = (traj - traj_o).abs().max().item()
     print(f"{name}: reference {t_ref:.1f}s  out {tuple(out.shape)}  oracle-vs-reference out {d:.2e} traj {dt:.2e}")

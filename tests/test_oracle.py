@@ -28,7 +28,7 @@ def test_oracle_matches_reference_golden(name):
     c = MG.CASES[name]
     cfg, wav, text, duration, lens = MG.case_inputs(c)
     sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
-    out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+    out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, method=c.get("method", "euler"), **c["kw"])
     g = gold(name)
     steps = c["kw"]["steps"]
     assert np.abs(out.numpy() - g["out"]).max() < TOL
