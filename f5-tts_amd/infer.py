@@ -1,0 +1,339 @@
+"""Host-side mirror of the reference's inference glue around the hot path.
+
+Same names, argument meaning and call-site behaviour as ``src/f5_tts/infer/utils_infer.py`` so that ``api.F5TTS`` / the CLI keep
+working when ``load_model`` / ``load_vocoder`` hand back the HIP adapters:
+
+* ``load_model`` / ``load_checkpoint`` / ``load_vocoder`` / ``get_tokenizer`` — reference ``utils_infer.py:106-145,190-276``,
+  ``model/utils.py:112-142``: checkpoint files (.safetensors / .pt, EMA key mapping) -> packed device blob.
+* ``chunk_text`` (``utils_infer.py:73-102``), ``convert_char_to_pinyin`` (``model/utils.py:148-185``).
+* ``infer_process`` / ``infer_batch_process`` (``utils_infer.py:384-593``): RMS normalisation, resampling, per-chunk duration
+  heuristic, ``sample`` -> slice at ``ref_audio_len = n_samples // hop`` -> ``vocoder.decode`` -> RMS restore, thread-pool fan-out,
+  cross-fade, streaming generator.
+
+No numerics of the hot path live here: every ``sample`` / ``decode`` call goes to ``libf5hip.so`` through ``engine.py``.
+Not built (host-only, needs packages that are absent offline): ``preprocess_ref_audio_text`` (pydub silence trimming, whisper ASR).
+"""
+from __future__ import annotations
+
+import math
+import os
+import re
+import wave
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .config import HOP_LENGTH, PRESETS, TARGET_SAMPLE_RATE, VOCOS_MEL_24K, DiTConfig, VocosConfig
+from .engine import F5HipCFM, F5HipEngine, F5HipVocos, filter_vocos_keys, map_checkpoint_keys
+
+# defaults of the reference module (utils_infer.py:52-65)
+target_sample_rate = TARGET_SAMPLE_RATE
+hop_length = HOP_LENGTH
+target_rms = 0.1
+cross_fade_duration = 0.15
+ode_method = "euler"
+nfe_step = 32
+cfg_strength = 2.0
+sway_sampling_coef = -1.0
+speed = 1.0
+fix_duration = None
+
+
+# ---- text ---------------------------------------------------------------------------------------------------------------------
+_SENTENCE_SPLIT = re.compile(r"(?<=[;:,.!?])\s+|(?<=[；：，。！？])")
+
+
+def _nbytes(s: str) -> int:
+    return len(s.encode("utf-8"))
+
+
+def chunk_text(text: str, max_chars: int = 135) -> List[str]:
+    """Greedy sentence packing by UTF-8 byte budget (reference utils_infer.py:73-102): split after ;:,.!? + whitespace or after a
+    full-width punctuation mark; a piece ending in a single-byte character gets a trailing space."""
+    chunks: List[str] = []
+    cur = ""
+    for sent in _SENTENCE_SPLIT.split(text):
+        if not sent:
+            continue
+        piece = sent + " " if _nbytes(sent[-1]) == 1 else sent
+        if _nbytes(cur) + _nbytes(sent) <= max_chars:
+            cur += piece
+        else:
+            if cur:
+                chunks.append(cur.strip())
+            cur = piece
+    if cur:
+        chunks.append(cur.strip())
+    return chunks
+
+
+_OOV_TRANS = str.maketrans({";": ",", "“": '"', "”": '"', "‘": "'", "’": "'"})
+_ASCII_TOKENS = re.compile(r"[A-Za-z0-9]+|.", re.S)
+
+
+def convert_char_to_pinyin(text_list: Sequence[str], polyphone: bool = True) -> List[List[str]]:
+    """reference model/utils.py:148-185.  Pure single-byte text needs no G2P: segments are character runs, and a multi-character
+    segment that follows anything but space/colon/quote gets a separating space.  East-asian text needs ``rjieba`` + ``pypinyin``
+    (absent offline): used when importable, otherwise a ValueError says so."""
+    try:  # pragma: no cover - optional dependencies
+        import rjieba
+        from pypinyin import Style, lazy_pinyin
+    except Exception:
+        rjieba = None
+    out: List[List[str]] = []
+    for text in text_list:
+        text = text.translate(_OOV_TRANS)
+        chars: List[str] = []
+        if rjieba is None:
+            if _nbytes(text) != len(text):
+                raise ValueError("non-single-byte text needs the rjieba and pypinyin packages (text front-end, SURVEY.md 8f rank 4)")
+            segs: Iterable[str] = _ASCII_TOKENS.findall(text)
+        else:  # pragma: no cover
+            segs = rjieba.cut(text)
+        for seg in segs:
+            nb = _nbytes(seg)
+            if nb == len(seg):  # single-byte characters only
+                if chars and nb > 1 and chars[-1] not in " :'\"":
+                    chars.append(" ")
+                chars.extend(seg)
+            elif polyphone and nb == 3 * len(seg):  # pragma: no cover
+                py = lazy_pinyin(seg, style=Style.TONE3, tone_sandhi=True)
+                for i, c in enumerate(seg):
+                    if "㄀" <= c <= "鿿":
+                        chars.append(" ")
+                    chars.append(py[i])
+            else:  # pragma: no cover
+                for c in seg:
+                    if ord(c) < 256:
+                        chars.extend(c)
+                    elif "㄀" <= c <= "鿿":
+                        chars.append(" ")
+                        chars.extend(lazy_pinyin(c, style=Style.TONE3, tone_sandhi=True))
+                    else:
+                        chars.append(c)
+        out.append(chars)
+    return out
+
+
+def get_tokenizer(vocab_file: str, tokenizer: str = "custom") -> Tuple[Optional[Dict[str, int]], int]:
+    """reference model/utils.py:112-142 ("custom": path to vocab.txt, one token per line, line index = id; "byte": 256)."""
+    if tokenizer == "byte":
+        return None, 256
+    if tokenizer != "custom":
+        raise ValueError("pass the vocab.txt path with tokenizer='custom' (the packaged dataset vocabularies are not shipped here)")
+    with open(vocab_file, "r", encoding="utf-8") as f:
+        vocab = {line[:-1]: i for i, line in enumerate(f)}
+    return vocab, len(vocab)
+
+
+# ---- weights ------------------------------------------------------------------------------------------------------------------
+def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+
+        return load_file(path, device="cpu")
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_checkpoint(engine: F5HipEngine, ckpt_path: str, use_ema: bool = True, finalize: bool = False) -> F5HipEngine:
+    """reference utils_infer.py:190-232: .safetensors or .pt; EMA checkpoints carry ``ema_model.``-prefixed keys plus ``initted`` /
+    ``step``; legacy mel-STFT buffers are dropped.  Only ``transformer.*`` tensors exist in the engine (the mel front-end has no
+    learned state)."""
+    ckpt = _read_checkpoint(ckpt_path)
+    if ckpt_path.endswith(".safetensors") and use_ema:
+        ckpt = {"ema_model_state_dict": ckpt}
+    elif ckpt_path.endswith(".safetensors"):
+        ckpt = {"model_state_dict": ckpt}
+    sd = map_checkpoint_keys(ckpt, use_ema=use_ema)
+    sd = {k: v for k, v in sd.items() if k.startswith("transformer.")}
+    engine.load_state_dict(sd, strict=True, finalize=finalize)
+    return engine
+
+
+def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos", vocab_file: str = "", ode_method: str = ode_method,
+               use_ema: bool = True, device=0, precision: str = "fp16x3", vocos_cfg: Optional[VocosConfig] = VOCOS_MEL_24K,
+               state_dict: Optional[Dict[str, torch.Tensor]] = None) -> F5HipCFM:
+    """reference utils_infer.py:238-276.  ``model_cfg``: a preset name ("F5TTS_v1_Base", "F5TTS_Base", "E2TTS_Base"), a ``DiTConfig``
+    or the reference's ``model.arch`` dict.  The returned object quacks like the reference's ``CFM`` on the inference path; its
+    engine also hosts the vocoder (``load_vocoder(engine=model.engine, ...)``)."""
+    if mel_spec_type != "vocos":
+        raise ValueError("only the vocos mel front-end / vocoder is built (BigVGAN's source is absent upstream of the reference tree)")
+    vocab_char_map, vocab_size = (get_tokenizer(vocab_file, "custom") if vocab_file else (None, None))
+    if isinstance(model_cfg, str):
+        cfg = PRESETS[model_cfg]
+    elif isinstance(model_cfg, DiTConfig):
+        cfg = model_cfg
+    else:
+        fields = DiTConfig.__dataclass_fields__
+        cfg = DiTConfig(**{k: v for k, v in dict(model_cfg).items() if k in fields})
+    if vocab_size is not None and vocab_size != cfg.text_num_embeds:
+        from dataclasses import replace
+
+        cfg = replace(cfg, text_num_embeds=vocab_size)
+    engine = F5HipEngine(cfg, vocos_cfg, device=device)
+    if state_dict is not None:
+        engine.load_state_dict({k: v for k, v in state_dict.items() if k.startswith("transformer.")}, finalize=False)
+    elif ckpt_path:
+        load_checkpoint(engine, ckpt_path, use_ema=use_ema)
+    if vocos_cfg is None:
+        engine.finalize()
+    return F5HipCFM(engine, vocab_char_map=vocab_char_map, ode_method=ode_method, precision=precision)
+
+
+def load_vocoder(vocoder_name: str = "vocos", is_local: bool = True, local_path: str = "", engine: Optional[F5HipEngine] = None,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, **_ignored) -> F5HipVocos:
+    """reference utils_infer.py:106-129 (vocos branch): ``<local_path>/pytorch_model.bin`` (config.yaml is the fixed
+    charactr/vocos-mel-24khz architecture = ``VOCOS_MEL_24K``).  The vocoder lives in the same context as the backbone: pass
+    ``engine=model.engine``; loading its tensors finalises the context."""
+    if vocoder_name != "vocos":
+        raise ValueError("only vocos is built")
+    if engine is None:
+        raise ValueError("pass engine=model.engine (one HIP context hosts backbone + vocoder)")
+    if state_dict is None:
+        if not is_local:
+            raise ValueError("no network here: pass is_local=True and local_path")
+        state_dict = torch.load(os.path.join(local_path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    engine.load_state_dict(filter_vocos_keys(state_dict), strict=False, finalize=True)
+    return F5HipVocos(engine)
+
+
+# ---- audio helpers ------------------------------------------------------------------------------------------------------------
+def load_wav(path: str) -> Tuple[torch.Tensor, int]:
+    """16-bit / 32-bit PCM .wav -> float32 [channels, samples] in [-1, 1) (what torchaudio.load returns, utils_infer.py:403)."""
+    with wave.open(path, "rb") as w:
+        sr, ch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    else:
+        raise ValueError(f"unsupported sample width {width}")
+    return torch.from_numpy(a.reshape(-1, ch).T.copy()), sr
+
+
+def resample(wave_: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> torch.Tensor:
+    """Windowed-sinc polyphase resampling with torchaudio's defaults (``transforms.Resample``: sinc_interp_hann, width 6, rolloff
+    0.99; call site utils_infer.py:466-468).  Restated from the published algorithm — unpinned here (torchaudio is absent)."""
+    if orig_freq == new_freq:
+        return wave_
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    kernel = kernel.to(torch.float32)
+    shape = wave_.shape
+    x = wave_.reshape(-1, shape[-1])
+    x = torch.nn.functional.pad(x, (width, width + orig))
+    y = torch.nn.functional.conv1d(x[:, None], kernel, stride=orig)
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)
+    target = math.ceil(new * shape[-1] / orig)
+    return y[..., :target].reshape(shape[:-1] + (target,))
+
+
+def cross_fade_concat(waves: Sequence[np.ndarray], fade_seconds: float, sr: int = TARGET_SAMPLE_RATE) -> np.ndarray:
+    """Linear cross-fade of consecutive chunks (reference utils_infer.py:549-586)."""
+    if fade_seconds <= 0:
+        return np.concatenate(waves)
+    final = waves[0]
+    for nxt in waves[1:]:
+        k = min(int(fade_seconds * sr), len(final), len(nxt))
+        if k <= 0:
+            final = np.concatenate([final, nxt])
+            continue
+        mixed = final[-k:] * np.linspace(1, 0, k) + nxt[:k] * np.linspace(0, 1, k)
+        final = np.concatenate([final[:-k], mixed, nxt[k:]])
+    return final
+
+
+# ---- inference ----------------------------------------------------------------------------------------------------------------
+def infer_batch_process(ref_audio, ref_text: str, gen_text_batches: Sequence[str], model_obj, vocoder, mel_spec_type: str = "vocos",
+                        progress=None, target_rms: float = target_rms, cross_fade_duration: float = cross_fade_duration,
+                        nfe_step: int = nfe_step, cfg_strength: float = cfg_strength, sway_sampling_coef: Optional[float] = sway_sampling_coef,
+                        speed: float = speed, fix_duration: Optional[float] = None, device=None, streaming: bool = False,
+                        chunk_size: int = 2048, seed: Optional[int] = None):
+    """Generator with the contract of reference utils_infer.py:440-593.  ``seed`` is an extension: the reference seeds torch globally
+    in ``api.F5TTS.infer`` (``seed_everything``, api.py:117-120) and ``sample`` then draws from that stream; passing it here makes a
+    multi-chunk request deterministic under the thread pool."""
+    audio, sr = ref_audio
+    audio = torch.as_tensor(audio, dtype=torch.float32)
+    if audio.ndim == 1:
+        audio = audio[None]
+    if audio.shape[0] > 1:
+        audio = audio.mean(dim=0, keepdim=True)
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < target_rms:
+        audio = audio * target_rms / rms
+    if sr != target_sample_rate:
+        audio = resample(audio, sr, target_sample_rate)
+    audio = audio.to(model_obj.device)
+    if len(ref_text[-1].encode("utf-8")) == 1:
+        ref_text = ref_text + " "
+
+    def _infer_basic(gen_text: str):
+        local_speed = 0.3 if len(gen_text.encode("utf-8")) < 10 else speed
+        final_text_list = convert_char_to_pinyin([ref_text + gen_text])
+        ref_audio_len = audio.shape[-1] // hop_length
+        if fix_duration is not None:
+            duration = int(fix_duration * target_sample_rate / hop_length)
+        else:
+            ref_text_len, gen_text_len = len(ref_text.encode("utf-8")), len(gen_text.encode("utf-8"))
+            duration = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / local_speed)
+        generated, _ = model_obj.sample(cond=audio, text=final_text_list, duration=duration, steps=nfe_step, cfg_strength=cfg_strength,
+                                        sway_sampling_coef=sway_sampling_coef, seed=seed)
+        generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
+        if mel_spec_type != "vocos":
+            raise ValueError("only the vocos vocoder is built")
+        wave_out = vocoder.decode(generated)
+        if rms < target_rms:
+            wave_out = wave_out * rms / target_rms
+        return wave_out.squeeze().cpu().numpy(), generated
+
+    seq = progress.tqdm(gen_text_batches) if progress is not None else gen_text_batches
+    if streaming:
+        for gen_text in seq:
+            w, _ = _infer_basic(gen_text)
+            for j in range(0, len(w), chunk_size):
+                yield w[j:j + chunk_size], target_sample_rate
+        return
+    waves, specs = [], []
+    with ThreadPoolExecutor() as ex:  # the context serialises its entry points; the pool only overlaps host work
+        futures = [ex.submit(_infer_basic, g) for g in gen_text_batches]
+        for fut in (progress.tqdm(futures) if progress is not None else futures):
+            w, spec = fut.result()
+            waves.append(w)
+            specs.append(spec[0].cpu().numpy())
+    if not waves:
+        yield None, target_sample_rate, None
+        return
+    yield cross_fade_concat(waves, cross_fade_duration), target_sample_rate, np.concatenate(specs, axis=1)
+
+
+def infer_process(ref_audio, ref_text: str, gen_text: str, model_obj, vocoder, mel_spec_type: str = "vocos", show_info=print, progress=None,
+                  target_rms: float = target_rms, cross_fade_duration: float = cross_fade_duration, nfe_step: int = nfe_step,
+                  cfg_strength: float = cfg_strength, sway_sampling_coef: Optional[float] = sway_sampling_coef, speed: float = speed,
+                  fix_duration: Optional[float] = None, device=None, seed: Optional[int] = None):
+    """reference utils_infer.py:384-434: ``ref_audio`` is a .wav path or an ``(audio[channels, n], sr)`` pair."""
+    audio, sr = load_wav(ref_audio) if isinstance(ref_audio, str) else ref_audio
+    audio = torch.as_tensor(audio, dtype=torch.float32)
+    if audio.ndim == 1:
+        audio = audio[None]
+    seconds = audio.shape[-1] / sr
+    max_chars = int(len(ref_text.encode("utf-8")) / seconds * (22 - seconds) * speed)
+    batches = chunk_text(gen_text, max_chars=max_chars)
+    show_info(f"Generating audio in {len(batches)} batches...")
+    if not batches:
+        show_info("No text batches to generate.")
+        return None, target_sample_rate, None
+    return next(infer_batch_process((audio, sr), ref_text, batches, model_obj, vocoder, mel_spec_type=mel_spec_type, progress=progress,
+                                    target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
+                                    cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed,
+                                    fix_duration=fix_duration, device=device, seed=seed))

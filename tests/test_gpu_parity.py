@@ -295,3 +295,94 @@ def test_invalid_arguments_raise(engines):
     bad[0, 0] = 10_000
     with pytest.raises(ValueError):
         model.sample(wav.cuda(), bad, 40, steps=4, cfg_strength=2.0)
+
+
+# ---- L4 glue (f5-tts_amd/infer.py): checkpoint formats and infer_process -------------------------------------------------------
+VOCAB = [" "] + [chr(c) for c in range(33, 127)]  # id 0 = space (unknown), printable ASCII after it
+
+
+def _write_vocab(tmp_path):
+    p = tmp_path / "vocab.txt"
+    p.write_text("".join(v + "\n" for v in VOCAB), encoding="utf-8")
+    return str(p)
+
+
+def test_checkpoint_formats_load_like_the_reference(tmp_path):
+    """EMA .pt ({'ema_model_state_dict': {'ema_model.<key>', 'initted', 'step'}}), plain .pt and EMA .safetensors checkpoints
+    (reference load_checkpoint, utils_infer.py:201-227) all give the engine the same weights as loading the state dict directly."""
+    from dataclasses import replace
+
+    from safetensors.torch import save_file
+
+    from f5_tts_amd import infer as I
+
+    cfg = replace(config.DIT_TINY, text_num_embeds=len(VOCAB))
+    sd = synth.synth_dit_state_dict(cfg, seed=5)
+    vocab = _write_vocab(tmp_path)
+    ema = {"ema_model." + k: v for k, v in sd.items()}
+    ema.update({"initted": torch.tensor(True), "step": torch.tensor(123),
+                "ema_model.mel_spec.mel_stft.mel_scale.fb": torch.zeros(3), "ema_model.mel_spec.mel_stft.spectrogram.window": torch.zeros(3)})
+    torch.save({"ema_model_state_dict": ema}, tmp_path / "ema.pt")
+    torch.save({"model_state_dict": dict(sd)}, tmp_path / "plain.pt")
+    save_file({k: v.contiguous() for k, v in ema.items() if k not in ("initted", "step")}, str(tmp_path / "ema.safetensors"))
+
+    wav = synth.synth_wave(256 * 30, seed=2)
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    text = ["hello world. this is a test"]
+    outs = []
+    for path, use_ema in ((None, True), ("ema.pt", True), ("plain.pt", False), ("ema.safetensors", True)):
+        model = I.load_model(cfg, str(tmp_path / path) if path else None, vocab_file=vocab, use_ema=use_ema, device=0, precision="fp32",
+                             vocos_cfg=None, state_dict=sd if path is None else None)
+        out, _ = model.sample(wav.cuda(), text, 80, **kw)
+        outs.append(out.cpu())
+        model.engine.close()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ids = torch.tensor([[VOCAB.index(ch) for ch in text[0]]])
+    ref, _ = O.cfm_sample(sd, cfg, wav, ids, 80, **kw)
+    assert maxerr(outs[0], ref) < TIGHT
+
+
+def test_infer_process_matches_oracle_glue(tmp_path):
+    """infer_process (chunking, per-chunk duration heuristic, 468-vs-469 slice, vocoder, RMS restore, cross-fade) against the oracle
+    restatement of _infer_basic (utils_infer.py:477-520) per chunk."""
+    from dataclasses import replace
+
+    from f5_tts_amd import infer as I
+
+    cfg = replace(config.DIT_TINY, text_num_embeds=len(VOCAB))
+    vcfg = config.VOCOS_TINY
+    sd, vsd = synth.synth_dit_state_dict(cfg, seed=6), synth.synth_vocos_state_dict(vcfg, seed=2)
+    model = I.load_model(cfg, None, vocab_file=_write_vocab(tmp_path), device=0, precision="fp32", vocos_cfg=vcfg, state_dict=sd)
+    voc = I.load_vocoder("vocos", engine=model.engine, state_dict=vsd)
+    try:
+        audio = 0.5 * synth.synth_wave(24000 * 2, seed=4)  # rms 0.05 < target 0.1: exercises the normalise / restore branch
+        ref_text = "some call me nature."
+        gen_text = ("others call me mother nature. i have been here for ages, and i will be here after. respect me; or not. "
+                    "i have fed species greater than you, and i have starved species greater than you. my oceans, my soil, "
+                    "my flowing streams, my forests: they all can take you, or leave you. ok.")
+        kw = dict(nfe_step=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=11)
+        wave_out, sr, spec = I.infer_process((audio, 24000), ref_text, gen_text, model, voc, show_info=lambda *_: None, **kw)
+        # oracle side: same chunking + heuristic, CPU numerics
+        rms = float(torch.sqrt(torch.mean(audio ** 2)))
+        a = audio * 0.1 / rms
+        rt = ref_text + " "
+        seconds = audio.shape[-1] / 24000
+        chunks = I.chunk_text(gen_text, max_chars=int(len(ref_text.encode()) / seconds * (22 - seconds) * 1.0))
+        assert len(chunks) >= 2
+        waves, specs = [], []
+        for g in chunks:
+            chars = I.convert_char_to_pinyin([rt + g])[0]
+            ids = torch.tensor([[VOCAB.index(ch) if ch in VOCAB else 0 for ch in chars]])
+            ref_len = a.shape[-1] // 256
+            speed = 0.3 if len(g.encode()) < 10 else 1.0
+            duration = ref_len + int(ref_len / len(rt.encode()) * len(g.encode()) / speed)
+            w, out = O.infer_basic(sd, cfg, vsd, vcfg.num_layers, a, ids, duration, steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=11)
+            waves.append((w * rms / 0.1).squeeze().numpy())
+            specs.append(out[0, ref_len:].T.numpy())
+        ref_wave = I.cross_fade_concat(waves, 0.15)
+        assert sr == 24000 and wave_out.shape == ref_wave.shape and spec.shape == np.concatenate(specs, axis=1).shape
+        assert np.abs(spec - np.concatenate(specs, axis=1)).max() < TIGHT
+        assert np.abs(wave_out - ref_wave).max() < 1e-4 * max(1.0, np.abs(ref_wave).max())
+    finally:
+        model.engine.close()

@@ -1,0 +1,100 @@
+"""Host-side glue (f5-tts_amd/infer.py) against the reference's own functions where they can be lifted out of its modules
+(pure-Python helpers: extracted from the reference source with ast when /root/reference exists) and by properties otherwise."""
+import ast
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import f5_tts_amd  # noqa: F401
+from f5_tts_amd import infer as I
+
+REF = "/root/reference/src/f5_tts"
+TEXTS = [
+    "Some call me nature, others call me mother nature.",
+    "I don't really care what you call me. I've been a silent spectator, watching species evolve, empires rise and fall. "
+    "But always remember, I am mighty and enduring. Respect me and I'll nurture you; ignore me and you shall face the consequences.",
+    "Short.",
+    "no punctuation at all just words going on and on and on " * 6,
+    "A;B:C,D.E!F? G",
+    "",
+]
+
+
+def lift(path, name, env):
+    """exec one top-level function of a reference module without importing the module (its imports are not installable here)"""
+    src = open(path, encoding="utf-8").read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == name)
+    code = compile(ast.Module(body=[fn], type_ignores=[]), path, "exec")
+    exec(code, env)
+    return env[name]
+
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+@needs_ref
+@pytest.mark.parametrize("max_chars", [20, 60, 135, 400])
+def test_chunk_text_matches_reference(max_chars):
+    ref = lift(os.path.join(REF, "infer", "utils_infer.py"), "chunk_text", {"re": re})
+    for t in TEXTS:
+        assert I.chunk_text(t, max_chars) == ref(t, max_chars)
+
+
+@needs_ref
+def test_convert_char_to_pinyin_single_byte_rule_matches_reference():
+    import types
+
+    rj = types.SimpleNamespace(cut=lambda s: I._ASCII_TOKENS.findall(s))  # stand-in segmenter: the rule under test is what follows it
+    ref = lift(os.path.join(REF, "model", "utils.py"), "convert_char_to_pinyin",
+               {"rjieba": rj, "lazy_pinyin": None, "Style": None})
+    for t in TEXTS + ["hello,world (x-ray) it's \"quoted\": yes;no"]:
+        assert I.convert_char_to_pinyin([t]) == ref([t])
+    with pytest.raises(ValueError):
+        I.convert_char_to_pinyin(["你好"])  # needs rjieba/pypinyin
+
+
+def test_cross_fade_concat_properties():
+    a, b, c = np.ones(5000, np.float32), 2 * np.ones(4000, np.float32), 3 * np.ones(100, np.float32)
+    out = I.cross_fade_concat([a, b, c], 0.15)
+    k1, k2 = int(0.15 * 24000), 100
+    assert len(out) == 5000 + 4000 + 100 - k1 - k2
+    assert out[0] == 1 and out[-1] == 3
+    mid = out[5000 - k1:5000]
+    assert np.all(np.diff(mid) >= -1e-6) and abs(mid[0] - 1) < 1e-6 and abs(mid[-1] - 2) < 1e-6
+    assert np.array_equal(I.cross_fade_concat([a, b], 0.0), np.concatenate([a, b]))
+
+
+def test_resample_preserves_a_tone():
+    sr0, sr1, f = 16000, 24000, 440.0
+    t0 = torch.arange(16000) / sr0
+    x = torch.sin(2 * math.pi * f * t0)[None]
+    y = I.resample(x, sr0, sr1)
+    assert y.shape == (1, 24000)
+    t1 = torch.arange(24000) / sr1
+    ref = torch.sin(2 * math.pi * f * t1)
+    assert (y[0, 200:-200] - ref[200:-200]).abs().max() < 2e-3
+    assert torch.equal(I.resample(x, sr0, sr0), x)
+
+
+def test_load_wav_roundtrip(tmp_path):
+    import wave
+
+    pcm = (np.random.RandomState(0).randn(2400) * 3000).astype("<i2")
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes(pcm.tobytes())
+    audio, sr = I.load_wav(str(p))
+    assert sr == 24000 and audio.shape == (1, 2400)
+    assert np.array_equal((audio[0].numpy() * 32768).astype(np.int16), pcm)
+
+
+def test_get_tokenizer(tmp_path):
+    p = tmp_path / "vocab.txt"
+    p.write_text(" \na\nb\nzh1\n", encoding="utf-8")
+    vocab, n = I.get_tokenizer(str(p))
+    assert n == 4 and vocab[" "] == 0 and vocab["zh1"] == 3
+    assert I.get_tokenizer("", "byte") == (None, 256)
