@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="F5TTS_v1_Base")
+    ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
     return ap.parse_args()
 
 
@@ -127,6 +128,7 @@ def main():
     fdist.broadcast_engine_weights(eng, src=0)
     if not a.no_graph:
         eng.set_option("use_graph", 1)
+    eng.set_option("branch_streams", a.branch_streams)
     model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
 
     B, nw, nt, duration = a.batch, 120000, 220, 1406

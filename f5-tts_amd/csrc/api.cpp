@@ -579,23 +579,26 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
 
 
 // ---- attention over [2B * H] (batch', head) slabs of ns tokens: q/k/v were written by the QKV epilogue -------------------------------
-int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
+// S sequences starting at sequence s0 of the packed [cond | uncond] batch (o32/o_hi/o_lo/kvlen are already offset by the caller)
+int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
                   int64_t ldO, hipStream_t st) {
   const auto& c = ctx->cfg;
   const int H = c.heads, dh = c.dim_head, inner = H * dh;
-  const int S = ctx->nb * B;  // packed sequences: cond (+ uncond with CFG)
+  const int64_t qoff = (int64_t)s0 * H * n * dh;                      // q/k slabs [seq*H, n, dh]
   {
       Prof pr(ctx, st, KC_ATTN, 4.0 * (double)S * H * (double)n * n * dh, 0);
       if (exact_attn) {
         // materialised-score attention in fp32: S = QK^T (batched GEMM), row softmax, O = PV (batched GEMM)
         const int np = (n + 3) & ~3;
-        GemmCore g = core(ctx->q32.p, dh, ctx->k32.p, dh, n, np, dh);
+        float* sc = ctx->scores.as<float>() + (int64_t)s0 * H * n * np;
+        const float* vt = ctx->vt32.as<float>() + (int64_t)s0 * inner * np;
+        GemmCore g = core(ctx->q32.as<float>() + qoff, dh, ctx->k32.as<float>() + qoff, dh, n, np, dh);
         g.w_rows = n; g.strideA = (int64_t)n * dh; g.strideW = (int64_t)n * dh;
-        EpiStore e = epi_store(ctx->scores.as<float>(), np, nullptr);
+        EpiStore e = epi_store(sc, np, nullptr);
         e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
         HIPCHK(launch_gemm_store(OP_F32, g, e, S * H, st));
-        HIPCHK(launch_softmax_rows(ctx->scores.as<float>(), (int64_t)S * H * n, np, n, H, kvlen, n, st));
-        g = core(ctx->scores.p, np, ctx->vt32.p, np, n, dh, np);
+        HIPCHK(launch_softmax_rows(sc, (int64_t)S * H * n, np, n, H, kvlen, n, st));
+        g = core(sc, np, vt, np, n, dh, np);
         g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
         EpiStore e2 = epi_store(o32, inner, nullptr);
         e2.zdiv = H; e2.so1 = (int64_t)n * inner; e2.so2 = dh;
@@ -608,25 +611,34 @@ int run_attention(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn, const i
         // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
         // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
         const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
-        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>(), x3 ? ctx->q16_lo.as<f16>() : nullptr, ctx->k16.as<f16>(),
-                                 x3 ? ctx->k16_lo.as<f16>() : nullptr, ctx->vt16.as<f16>(), x3 ? ctx->vt16_lo.as<f16>() : nullptr,
-                                 (n + 7) & ~7, S, H, n, kvlen, o_hi, o_lo, st, pk));
+        const int ldv = (n + 7) & ~7;
+        const int64_t voff = (int64_t)s0 * inner * ldv;
+        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
+                                 ctx->k16.as<f16>() + qoff, x3 ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
+                                 x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk));
       }
     }
   return F5HIP_OK;
 }
 
 // ---- one ODE function evaluation + Euler update ---------------------------------------------------
-int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st) {
+// br < 0: the packed batch (cond rows, then uncond rows with CFG) followed by the CFG/ODE update.  br = 0 / 1: only the cond / uncond
+// branch (B sequences) and NO update — the two branches never interact inside the backbone, so enqueue_steps may run them on two
+// streams and join before the update.
+int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st, int br = -1) {
   const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
   const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
   const int64_t BN = (int64_t)B * n;
-  const int M = (int)(nb * BN);
+  const int S = br < 0 ? nb * B : B, s0 = br < 0 ? 0 : br * B;  // sequences handled here, first sequence
+  const int64_t r0 = (int64_t)s0 * n;                            // first row
+  const int M = S * n;
   const std::string p = "transformer.";
-  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;
-  float* x = ctx->x.as<float>();
-  float* h = ctx->h.as<float>();
+  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() + r0 : nullptr;
+  float* x = ctx->x.as<float>() + r0 * D;
+  float* h = ctx->h.as<float>() + r0 * D;
+  float* c1 = ctx->c1.as<float>() + r0 * D;
+  const float* cconst = ctx->cconst.as<float>() + r0 * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int npl = op == OP_F16X3 ? 3 : 1;
 
@@ -634,34 +646,35 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
     GemmCore g = core(sg.yin, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
     EpiStore e = epi_store(h, D, nullptr);
-    e.res = ctx->cconst.as<float>(); e.ldres = D;
-    if (nb == 2) { e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D; }  // uncond rows: same x columns, uncond constant part
+    e.res = cconst; e.ldres = D;
+    if (br < 0 && nb == 2) { e.out2 = h + BN * D; e.res2 = cconst + BN * D; }  // uncond rows: same x columns, uncond constant part
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
   }
   {  // ConvPositionEmbedding + residual (dit.py:163, modules.py:187-201)
     const int cpg = D / c.conv_pos_groups;
     Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops(M, D, (int64_t)cpg * c.conv_pos_kernel) * (npl == 3 ? 1 : 1), 0);
     HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
-                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, nb * B, n, D, c.conv_pos_groups,
-                          c.conv_pos_kernel, ctx->c1.as<float>(), st));
-    HIPCHK(launch_convpos(op, ctx->c1.as<float>(), ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
-                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, nb * B, n, D, c.conv_pos_groups,
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, S, n, D, c.conv_pos_groups,
+                          c.conv_pos_kernel, c1, st));
+    HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
+                          W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, S, n, D, c.conv_pos_groups,
                           c.conv_pos_kernel, x, st));
   }
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
-  float* a32 = op == OP_F32 ? ctx->a32.as<float>() : nullptr;
-  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() : nullptr;
   const int pk = op == OP_F16X3 ? 1 : 0;      // fp16x3 operands are packed hi/lo rows: lo plane = hi + 32 halves, row stride 2K
+  const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
+  float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
+  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() + r0 * ldA : nullptr;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
   const void* A = op == OP_F32 ? (const void*)a32 : (const void*)a_hi;
-  float* o32 = op == OP_F32 ? ctx->o32.as<float>() : nullptr;
-  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() : nullptr;
+  float* o32 = op == OP_F32 ? ctx->o32.as<float>() + r0 * inner : nullptr;
+  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() + r0 * ldO : nullptr;
   f16* o_lo = pk ? o_hi + 32 : nullptr;
-  float* f32 = op == OP_F32 ? ctx->f32.as<float>() : nullptr;
-  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() : nullptr;
+  float* f32 = op == OP_F32 ? ctx->f32.as<float>() + r0 * F : nullptr;
+  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() + r0 * ldF : nullptr;
   f16* f_lo = pk ? f_hi + 32 : nullptr;
-  const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
-  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() : nullptr;
+  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() + s0 : nullptr;
+  const int64_t qoff = (int64_t)s0 * H * n * dh;
   const double ln_bytes = (double)M * D * (4 + wbytes * (op == OP_F16X3 ? 2 : 1));
 
   for (int i = 0; i < c.depth; ++i) {
@@ -677,17 +690,21 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       EpiQKV e{};
       e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = n; e.heads = H; e.dh = dh;
       e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
-      if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (n + 3) & ~3; }
-      else {
-        e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (n + 7) & ~7;
+      if (exact_attn) {
+        e.ldvt = (n + 3) & ~3;
+        e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
+      } else {
+        e.ldvt = (n + 7) & ~7;
+        const int64_t voff = (int64_t)s0 * inner * e.ldvt;
+        e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
         if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
-          e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
-          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+          e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
+          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
         }
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
-    CHK(run_attention(ctx, B, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
       GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
@@ -722,9 +739,9 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     }
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, mel, D), 0);
     GemmCore g = core(A, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
-    HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias")), 1, st));
+    HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>() + r0 * mel, mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
-  {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
+  if (br < 0) {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
     HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
                             sg.traj, ctx->dbg_vel.as<float>(), st));
@@ -827,7 +844,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
-    CHK(run_attention(ctx, B, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
       GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
@@ -882,7 +899,28 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int method, int op, b
   const int64_t slab = (int64_t)B * n * ctx->cfg.mel_dim;
   float* y = ctx->y.as<float>();
   float* ymid = ctx->ymid.as<float>();
-  auto eval = [&](const Stage& sg) { return unett ? run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, st) : run_step(ctx, B, n, sg, op, exact_attn, use_mask, st); };
+  // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
+  // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
+  // graph capture the side stream becomes a parallel branch of the graph).
+  const bool split = !unett && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 4096));
+  if (split && !ctx->side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  auto eval = [&](const Stage& sg) -> int {
+    if (unett) return run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, st);
+    if (!split) return run_step(ctx, B, n, sg, op, exact_attn, use_mask, st);
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    CHK(run_step(ctx, B, n, sg, op, exact_attn, use_mask, st, 0));
+    CHK(run_step(ctx, B, n, sg, op, exact_attn, use_mask, ctx->side_stream, 1));
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), slab, 1, ctx->dt_dev.as<float>() + sg.eidx, ctx->cfg_dev.as<float>(), sg.traj,
+                            ctx->dbg_vel.as<float>(), st));
+    return F5HIP_OK;
+  };
   for (int s = 0; s < steps; ++s) {
     float* tr = traj ? traj + (int64_t)(s + 1) * slab : nullptr;
     if (method == 0) {
@@ -944,6 +982,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   (void)hipDeviceSynchronize();
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+  if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
@@ -1012,6 +1051,7 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   if (k == "use_graph") ctx->use_graph = value != 0;
   else if (k == "profile") ctx->profile = value != 0;
   else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
+  else if (k == "branch_streams") { ctx->branch_streams = (int)value; ctx->ws_epoch++; }
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
   return F5HIP_OK;
 }

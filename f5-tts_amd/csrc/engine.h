@@ -160,4 +160,8 @@ struct f5hip_ctx {
   } graph_key;
   uint64_t ws_epoch = 0;
   hipStream_t cap_stream = nullptr;
+  // cond / uncond branches on two streams (small batches): -1 auto, 0 off, 1 on
+  int branch_streams = -1;
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };

@@ -145,7 +145,8 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* mel, int batch, int frames, 
 
 /* ---- engine options / measurement ---------------------------------------------------------------- */
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel
- * class with hipEvents on the launch stream; forces eager launches). */
+ * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
+ * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
 /* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
  * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */
