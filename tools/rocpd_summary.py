@@ -16,10 +16,10 @@ def demangle(names):
 
 def demangle_local(name: str) -> str:
     """llvm-cxxfilt is not in the image and binutils' c++filt does not know _Float16 (DF16_): decode our own kernels."""
-    m = re.match(r"_Z11gemm_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)E\d+(Epi[A-Za-z]+)Li(\d)ELi(\d)ELi(\d)E", name)
+    m = re.match(r"_Z\d+(gemm_kernel|gemm_glds_kernel)I(DF16_|f)Li(\d)ELi(\d)ELi(\d)E\d+(Epi[A-Za-z]+)Li(\d)ELi(\d)ELi(\d)E", name)
     if m:
-        t = "_Float16" if m.group(1) == "DF16_" else "float"
-        return f"gemm_kernel<{t}, {m.group(2)}, {m.group(3)}, {m.group(4)}, {m.group(5)}, {m.group(6)}, {m.group(7)}, {m.group(8)}>("
+        t = "_Float16" if m.group(2) == "DF16_" else "float"
+        return f"{m.group(1)}<{t}, {m.group(3)}, {m.group(4)}, {m.group(5)}, {m.group(6)}, {m.group(7)}, {m.group(8)}, {m.group(9)}>("
     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)(\w+?)I(.*?)EEv", name)
     if m:
         n = int(m.group(1))
