@@ -751,36 +751,41 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
 
 
 // ---- one ODE function evaluation + Euler update, UNetT backbone (reference src/f5_tts/model/backbones/unett.py:244-307) -------------
-int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st) {
+int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st, int br = -1) {
   const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
   const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
-  const int ns = n + 1, S = nb * B;
+  const int ns = n + 1;
+  const int S = br < 0 ? nb * B : B, s0 = br < 0 ? 0 : br * B;  // sequences handled here (br: see run_step)
   const int64_t BN = (int64_t)B * n;
-  const int M = S * ns;
+  const int64_t r0 = (int64_t)s0 * ns, r0n = (int64_t)s0 * n;   // first token row / first frame row
+  const int M = S * ns, Mall = nb * B * ns;
   const std::string p = "transformer.";
-  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;  // [S, ns], time token valid (unett.py:273-274)
-  float* x = ctx->x.as<float>();
-  float* h = ctx->h.as<float>();
+  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() + r0 : nullptr;  // [S, ns], time token valid (unett.py:273-274)
+  float* x = ctx->x.as<float>() + r0 * D;
+  float* h = ctx->h.as<float>() + r0n * D;
+  float* c1 = ctx->c1.as<float>() + r0n * D;
+  const float* cconst = ctx->cconst.as<float>() + r0n * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int pk = op == OP_F16X3 ? 1 : 0;
   const int64_t pl = pk ? 2 : 1;
   const int64_t ldA = D * pl, ldO = inner * pl, ldF = F * pl, ldC = 2 * D * pl;  // operand row strides (elements)
-  float* a32 = op == OP_F32 ? ctx->a32.as<float>() : nullptr;
-  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() : nullptr;
+  float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
+  f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() + r0 * ldA : nullptr;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
   const void* A = op == OP_F32 ? (const void*)a32 : (const void*)a_hi;
-  float* o32 = op == OP_F32 ? ctx->o32.as<float>() : nullptr;
-  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() : nullptr;
+  float* o32 = op == OP_F32 ? ctx->o32.as<float>() + r0 * inner : nullptr;
+  f16* o_hi = op != OP_F32 ? ctx->o_hi.as<f16>() + r0 * ldO : nullptr;
   f16* o_lo = pk ? o_hi + 32 : nullptr;
-  float* f32 = op == OP_F32 ? ctx->f32.as<float>() : nullptr;
-  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() : nullptr;
+  float* f32 = op == OP_F32 ? ctx->f32.as<float>() + r0 * F : nullptr;
+  f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() + r0 * ldF : nullptr;
   f16* f_lo = pk ? f_hi + 32 : nullptr;
-  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() : nullptr;
+  const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() + s0 : nullptr;
+  const int64_t qoff = (int64_t)s0 * H * ns * dh;
   const double ln_bytes = (double)M * D * (4 + wbytes * pl);
   // concat buffer of skip level l: [M, 2D] in the operand layout; columns [0, D) = current x, [D, 2D) = the saved skip
   const int64_t cat_elem_bytes = op == OP_F16 ? 2 : 4;  // fp32: 4 B; fp16: 2 B; packed hi/lo: 2 x 2 B per logical element
-  auto cat_ptr = [&](int level) { return ctx->skipcat.as<char>() + (int64_t)level * M * 2 * D * cat_elem_bytes; };
+  auto cat_ptr = [&](int level) { return ctx->skipcat.as<char>() + ((int64_t)level * Mall + r0) * 2 * D * cat_elem_bytes; };
   // write an operand copy of x (mode 2 = no normalisation) into columns [col0, col0 + D) of a concat buffer
   auto emit_cat = [&](int level, int col0) -> hipError_t {
     char* base = cat_ptr(level);
@@ -793,8 +798,8 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
     GemmCore g = core(sg.yin, mel, W(ctx, p + "input_embed.proj.weight"), 2 * mel + c.text_dim, (int)BN, D, mel);
     EpiStore e = epi_store(h, D, nullptr);
-    e.res = ctx->cconst.as<float>(); e.ldres = D;
-    if (nb == 2) { e.out2 = h + BN * D; e.res2 = ctx->cconst.as<float>() + BN * D; }
+    e.res = cconst; e.ldres = D;
+    if (br < 0 && nb == 2) { e.out2 = h + BN * D; e.res2 = cconst + BN * D; }
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
   }
   {  // ConvPositionEmbedding WITHOUT a mask (unett.py:101) + residual, written behind the time token of each sequence
@@ -802,8 +807,8 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops((int64_t)S * n, D, (int64_t)cpg * c.conv_pos_kernel), 0);
     HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), nullptr, nullptr, S, n, D, c.conv_pos_groups, c.conv_pos_kernel,
-                          ctx->c1.as<float>(), st));
-    HIPCHK(launch_convpos(op, ctx->c1.as<float>(), ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
+                          c1, st));
+    HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), nullptr, h, S, n, D, c.conv_pos_groups, c.conv_pos_kernel, x, st,
                           ns, 1));
     HIPCHK(launch_set_token_rows(x, ctx->temb.as<float>() + (int64_t)step * D, S, ns, D, st));  // unett.py:272
@@ -834,17 +839,21 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
       EpiQKV e{};
       e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
       e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
-      if (exact_attn) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); e.vt32 = ctx->vt32.as<float>(); e.ldvt = (ns + 3) & ~3; }
-      else {
-        e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>(); e.ldvt = (ns + 7) & ~7;
+      if (exact_attn) {
+        e.ldvt = (ns + 3) & ~3;
+        e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
+      } else {
+        e.ldvt = (ns + 7) & ~7;
+        const int64_t voff = (int64_t)s0 * inner * e.ldvt;
+        e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
         if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
-          e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
-          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+          e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
+          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
         }
       }
       HIPCHK(launch_gemm_qkv(op, g, e, st));
     }
-    CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
       GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
@@ -880,11 +889,11 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     const char* Arow1 = reinterpret_cast<const char*>(A) + ldA * (op == OP_F32 ? 4 : 2);  // skip the time token of sequence 0
     GemmCore g = core(Arow1, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, n, mel, D);
     g.strideA = (int64_t)ns * ldA;
-    EpiStore e = epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias"));
+    EpiStore e = epi_store(ctx->vel.as<float>() + r0n * mel, mel, W(ctx, p + "proj_out.bias"));
     e.zdiv = 1; e.so1 = (int64_t)n * mel; e.so2 = 0;
     HIPCHK(launch_gemm_store(op, g, e, S, st));
   }
-  {
+  if (br < 0) {
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
     HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
                             sg.traj, ctx->dbg_vel.as<float>(), st));
@@ -902,19 +911,21 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int method, int op, b
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = !unett && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 4096));
+  const bool split = ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 4096));
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   }
   auto eval = [&](const Stage& sg) -> int {
-    if (unett) return run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, st);
-    if (!split) return run_step(ctx, B, n, sg, op, exact_attn, use_mask, st);
+    auto one = [&](hipStream_t s_, int br) {
+      return unett ? run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, s_, br) : run_step(ctx, B, n, sg, op, exact_attn, use_mask, s_, br);
+    };
+    if (!split) return one(st, -1);
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-    CHK(run_step(ctx, B, n, sg, op, exact_attn, use_mask, st, 0));
-    CHK(run_step(ctx, B, n, sg, op, exact_attn, use_mask, ctx->side_stream, 1));
+    CHK(one(st, 0));
+    CHK(one(ctx->side_stream, 1));
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->side_stream));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), slab, 1, ctx->dt_dev.as<float>() + sg.eidx, ctx->cfg_dev.as<float>(), sg.traj,
