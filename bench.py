@@ -125,6 +125,7 @@ def main():
     if rank == 0:  # rank 0 "reads the checkpoint"; the packed blob travels over RCCL/xGMI
         sd, vsd = synth.synth_dit_state_dict(cfg, seed=0), synth.synth_vocos_state_dict(vcfg, seed=0)
         eng.load_state_dict({**sd, **vsd}, finalize=False)
+    weights_via = "rccl broadcast of the packed blob from rank 0" if world > 1 else "local (single rank)"
     fdist.broadcast_engine_weights(eng, src=0)
     if not a.no_graph:
         eng.set_option("use_graph", 1)

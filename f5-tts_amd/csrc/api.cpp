@@ -997,7 +997,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
-                    &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
+                    &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->traj_buf, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
@@ -1187,22 +1187,33 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   bool done = false;
   if (ctx->use_graph && !ctx->profile) {
     auto& k = ctx->graph_key;
+    // The captured loop writes the trajectory into a context-owned buffer (copied out below), so the graph does not depend on any
+    // caller pointer and is replayed for every call of the same shape.
+    float* tbuf = nullptr;
+    if (trajectory) {
+      bool moved = false;
+      HIPCHK(ctx->traj_buf.ensure((size_t)(steps + 1) * BN * mel * sizeof(float), &moved));
+      if (moved) ctx->ws_epoch++;
+      tbuf = ctx->traj_buf.as<float>();
+    }
     const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
-                     k.method == ode_method && k.traj == trajectory && k.ws_epoch == ctx->ws_epoch;
+                     k.method == ode_method && k.traj == tbuf && k.ws_epoch == ctx->ws_epoch;
     if (!hit) {
       if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
       if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
-      int r = enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, trajectory, ctx->cap_stream);
+      int r = enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, tbuf, ctx->cap_stream);
       hipError_t ce = hipStreamEndCapture(ctx->cap_stream, &graph);
       if (r != F5HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
       HIPCHK(ce);
       HIPCHK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = trajectory; k.ws_epoch = ctx->ws_epoch;
+      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = tbuf; k.ws_epoch = ctx->ws_epoch;
     }
     HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
+    if (trajectory)  // states 1..steps (state 0 = y0 was copied above)
+      HIPCHK(hipMemcpyAsync(trajectory + BN * mel, tbuf + BN * mel, (size_t)steps * BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
     done = true;
   }
   if (!done) CHK(enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, trajectory, st));

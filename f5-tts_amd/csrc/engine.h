@@ -135,6 +135,7 @@ struct f5hip_ctx {
   DevBuf step_cond, cconst, y, h, c1, x;
   DevBuf a32, a_hi, o32, o_hi, f32, f_hi;  // *_hi: plain fp16 rows, or packed hi/lo rows (twice the size) in fp16x3 mode
   DevBuf q32, k32, vt32, scores, q16, k16, vt16, q16_lo, k16_lo, vt16_lo;
+  DevBuf traj_buf;                     // trajectory slots written by the captured graph (copied to the caller's buffer)
   DevBuf vel, rope, dbg_vel, ymid;     // ymid: scratch ODE state of the midpoint solver
   int nb = 2;                          // packed branches per utterance: 2 = cond + uncond (CFG), 1 = cond only (cfg_strength < 1e-5)
   // vocos workspace
