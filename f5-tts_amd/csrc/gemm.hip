@@ -28,6 +28,7 @@ F5_VARIANT(3, 2, 2, 4, 2);
 F5_VARIANT(4, 2, 2, 2, 4);
 F5_VARIANT(5, 2, 2, 4, 4);
 F5_VARIANT(8, 1, 1, 2, 2);  // 64x64
+F5_VARIANT(10, 2, 3, 2, 2);  // 128x192
 #undef F5_VARIANT
 
 template <typename T, int NSPLIT, int ID, typename Epi>
@@ -49,6 +50,7 @@ hipError_t set_attrs_op() {
   if ((e = set_attr<T, NSPLIT, 4, Epi>()) != hipSuccess) return e;
   if ((e = set_attr<T, NSPLIT, 5, Epi>()) != hipSuccess) return e;
   if ((e = set_attr<T, NSPLIT, 8, Epi>()) != hipSuccess) return e;
+  if ((e = set_attr<T, NSPLIT, 10, Epi>()) != hipSuccess) return e;
   return hipSuccess;
 }
 
@@ -76,8 +78,14 @@ hipError_t launch_one(const GemmCore& g, const Epi& e, int batch, hipStream_t s)
 }
 
 int pick_variant(const GemmCore& g, int batch) {
-  static const int forced = [] { const char* e = getenv("F5HIP_GEMM_VARIANT"); return e ? atoi(e) : -1; }();  // tuning / test knob
+  static const int forced = [] { const char* e = getenv("F5HIP_GEMM_VARIANT"); return e ? atoi(e) : -1; }();  // tuning / test knobs
   if (forced >= 0) return forced;
+  static const int f3072 = [] { const char* e = getenv("F5HIP_GEMM_VARIANT_N3072"); return e ? atoi(e) : -1; }();
+  static const int f2048 = [] { const char* e = getenv("F5HIP_GEMM_VARIANT_N2048"); return e ? atoi(e) : -1; }();
+  static const int f1024 = [] { const char* e = getenv("F5HIP_GEMM_VARIANT_N1024"); return e ? atoi(e) : -1; }();
+  if (g.M > 256 && g.N == 3072 && f3072 >= 0) return f3072;
+  if (g.M > 256 && g.N == 2048 && f2048 >= 0) return f2048;
+  if (g.M > 256 && g.N == 1024 && f1024 >= 0) return f1024;
   if (g.M <= 64) return 0;
   // 128x64 tiles (3 workgroups per CU) until the grid is several waves deep, then 128x128 (higher FLOP per byte staged):
   // measured crossover between M = 2812 (B=1: 128x64 wins on all four block GEMMs) and M = 22496 (B=8: 128x128 wins).
@@ -133,6 +141,7 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 6: return launch_glds<T, NSPLIT, 2, 1, Epi>(g, e, batch, s);
     case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
+    case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);
     default: break;
   }
   if constexpr (std::is_same<Epi, EpiStore>::value && !std::is_same<T, float>::value) {
