@@ -175,7 +175,7 @@ def main():
         "config": {"workload": f"{a.model} + Vocos, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
                                f"sway -1, CFG 2.0, euler (BASELINE.json configs[{1 if B == 1 else 2}])",
                    "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
-                   "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective"},
+                   "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via},
     }
     # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager pass -------
     eng.set_option("profile", 1)
@@ -197,6 +197,13 @@ def main():
                                    "traffic = HBM bytes per launch from the committed rocprofv3 PMC pass of the same command "
                                    "(profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null if none matches"}
     res["kernel_classes_ms"] = {k: round(v["ms"], 3) for k, v in stats.items() if v["calls"]}
+    # per kernel class: HIP-event time of the profiled pass with the algorithmic FLOPs / bytes the launch sites declare:
+    # TFLOP/s for the MFMA-bound classes, GB/s (ideal-fusion bytes) for the HBM-bound ones
+    res["kernel_classes"] = {
+        k: {"calls": v["calls"], "ms": round(v["ms"], 3),
+            **({"tflops": round(v["flops"] / (1e-3 * v["ms"]) / 1e12, 1)} if v["flops"] else {}),
+            **({"gbps": round(v["bytes"] / (1e-3 * v["ms"]) / 1e9, 1)} if v["bytes"] and k not in ("gemm_block",) else {})}
+        for k, v in stats.items() if v["calls"] and v["ms"] > 0}
     if not a.no_cpu_baseline and world == 1:
         try:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen)

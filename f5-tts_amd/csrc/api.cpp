@@ -555,7 +555,10 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
   HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BN, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->textkeep.p, keep.data(), M, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
-  Prof pr(ctx, st, KC_TEXT, 0, 0);
+  // algorithmic traffic of the text encoder (per ConvNeXtV2 block read x + write out + write h + read h, h = 2x) and
+  // its pointwise-GEMM FLOPs, all inside this one scope
+  const double x_elems = (double)M * T;
+  Prof pr(ctx, st, KC_TEXT, c.conv_layers * 2.0 * gemm_flops(M, 2 * T, T), x_elems * 4.0 + c.conv_layers * 6.0 * x_elems * 4.0);
   float* tx = ctx->tx.as<float>();
   HIPCHK(launch_text_embed(ctx->tok.as<int32_t>(), ctx->valid.as<uint8_t>(), W(ctx, "transformer.text_embed.text_embed.weight"),
                            ctx->freqs_cis.as<float>(), B, n, T, c.text_mask_padding, c.conv_layers > 0, tx, st));

