@@ -140,6 +140,8 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 5: return launch_one<T, NSPLIT, 5, Epi>(g, e, batch, s);
     case 6: return launch_glds<T, NSPLIT, 2, 1, Epi>(g, e, batch, s);
     case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
+    case 13: return launch_glds<T, NSPLIT, 4, 2, Epi>(g, e, batch, s);  // 256x128, 4 waves of 128x64
+    case 14: return launch_glds<T, NSPLIT, 2, 4, Epi>(g, e, batch, s);  // 128x256, 4 waves of 64x128
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);
     default: break;
