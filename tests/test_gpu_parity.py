@@ -386,3 +386,59 @@ def test_infer_process_matches_oracle_glue(tmp_path):
         assert np.abs(wave_out - ref_wave).max() < 1e-4 * max(1.0, np.abs(ref_wave).max())
     finally:
         model.engine.close()
+
+
+# ---- size-independent properties at BASELINE.json's full sizes, long sequences, degenerate text --------------------------------
+def test_full_size_batch_rows_equal_single_utterance():
+    """F5-TTS Base at full size: a fixed-length batch of identical utterances (packed cond+uncond launches, M = 2*B*N rows) must give
+    every row the result of the B=1 call (cond / uncond branches on two streams, M = N rows per launch) — same arithmetic, different
+    schedules and tile heuristics."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["base_v1_cfg1"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    try:
+        model = F5HipCFM(eng, precision="fp16x3")
+        kw = dict(c["kw"], steps=4)
+        one, _ = model.sample(wav.cuda(), text, duration, **kw)
+        many, _ = model.sample(wav.repeat(4, 1).cuda(), text.repeat(4, 1), duration, **kw)
+        assert many.shape[0] == 4
+        for b in range(4):
+            assert maxerr(many[b], one[0].cpu()) < 2e-4
+        assert torch.equal(many[0], many[3])
+    finally:
+        eng.close()
+
+
+def test_long_sequence_matches_oracle(engines):
+    """4000 frames (42 s): more than 31 query blocks / 62 key tiles per head, offsets well past 2^16 rows."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1)
+    sd = synth.synth_dit_state_dict(cfg, seed=1)
+    wav = synth.synth_wave(256 * 300, seed=12)
+    text = synth.synth_text_ids(1, 400, cfg.text_num_embeds, seed=13)
+    kw = dict(steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=2)
+    out, _ = F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, 4000, **kw)
+    ref, _ = O.cfm_sample(sd, cfg, wav, text, 4000, **kw)
+    assert out.shape == ref.shape == (1, 4000, 100)
+    assert maxerr(out, ref) < X3TOL
+
+
+def test_all_padding_text_and_single_frame_prompt(engines):
+    """text made only of batch padding (-1): every position is the filler token; prompt of the minimum length the mel front-end takes."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1)
+    sd = synth.synth_dit_state_dict(cfg, seed=1)
+    wav = synth.synth_wave(513, seed=14)  # 3 mel frames
+    text = torch.full((1, 6), -1, dtype=torch.long)
+    kw = dict(steps=3, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=4)
+    out, _ = F5HipCFM(eng).sample(wav.cuda(), text, 50, **kw)
+    ref, _ = O.cfm_sample(sd, cfg, wav, text, 50, **kw)
+    assert out.shape == ref.shape == (1, 50, 100)
+    assert maxerr(out, ref) < TIGHT
