@@ -62,6 +62,9 @@ CASES = {
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
 FULL_CASES = {
+    # BASELINE.json configs[4] backbone at full size: E2-TTS Base (UNetT, depth 24, ff_mult 4), same prompt/duration as config 1
+    "e2_base_cfg5": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
+                         kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[0]/[1]: F5-TTS Base, 5 s ref + 10 s gen, NFE 16, sway, CFG 2
     "base_v1_cfg1": dict(preset="F5TTS_v1_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
@@ -158,7 +161,8 @@ def golden_vocos(pins):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--full", action="store_true", help="also mint the full-size F5-TTS Base golden (~1 min of CPU)")
+    ap.add_argument("--full", action="store_true", help="also mint the full-size goldens (~1 min of CPU each)")
+    ap.add_argument("--only", default="", help="comma-separated case names (full-size ones included) to mint, leaving the others alone")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     pins_path = os.path.join(GOLD, "pins.json")
@@ -167,10 +171,12 @@ def main():
     pin_stft(pins)
     pin_mel(pins)
     golden_vocos(pins)
+    only = set(filter(None, args.only.split(",")))
     for name, c in CASES.items():
-        run_case(name, c, pins)
-    if args.full:
-        for name, c in FULL_CASES.items():
+        if not only or name in only:
+            run_case(name, c, pins)
+    for name, c in FULL_CASES.items():
+        if (args.full and not only) or name in only:
             run_case(name, c, pins)
     pins["_meta"] = dict(torch=torch.__version__, reference="/root/reference (SWivid/F5-TTS v1.1.20)", generated_by="oracle/make_golden.py")
     json.dump(pins, open(pins_path, "w"), indent=1, sort_keys=True)

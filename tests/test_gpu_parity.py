@@ -282,6 +282,27 @@ def test_full_size_base_config1_golden():
         eng.close()
 
 
+def test_full_size_e2_unett_golden():
+    """BASELINE.json configs[4] backbone: E2-TTS Base (UNetT, 333 M parameters) at full size against the golden minted by running the
+    reference's own UNetT through CFM.sample on CPU (54 s there)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["e2_base_cfg5"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    g = gold("e2_base_cfg5")
+    try:
+        for prec in ("fp16x3", "fp32"):
+            out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
+            e = maxerr(out[:, 468:], g["out"][:, 468:])
+            print(f"full-size E2 {prec}: generated-mel max-abs {e:.2e}")
+            assert e < MEL_TOL
+            assert maxerr(traj[1], g["traj_1"]) < MEL_TOL
+    finally:
+        eng.close()
+
+
 def test_invalid_arguments_raise(engines):
     from f5_tts_amd.engine import F5HipCFM
 
