@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Utterance-sharded batch inference on N GPUs of one node — the reference's only multi-GPU inference pattern
+(``accelerate launch src/f5_tts/eval/eval_infer_batch.py``, eval_infer_batch.py:178-214: one process per GPU, a disjoint slice of the
+utterance list each, barriers around the loop), on the HIP engine:
+
+    python tools/infer_batch.py --list utts.lst --out out_dir --ckpt model.safetensors --vocab vocab.txt --vocos vocos_dir
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/infer_batch.py ...
+
+``utts.lst``: one utterance per line, ``utt_id|ref_wav_path|ref_text|gen_text`` (the layout of the reference's LibriSpeech-PC test
+list, data/librispeech_pc_test_clean_cross_sentence.lst, minus the duration columns).  Rank 0 reads the checkpoint; the packed weight
+blob travels once over RCCL; utterances are dealt longest-first to balance the ranks; every rank writes its own ``<utt_id>.wav``.
+Without ``--ckpt`` seeded synthetic weights are used (smoke / throughput runs; ``--synthetic N`` makes N utterances up as well).
+"""
+import argparse
+import os
+import sys
+import time
+import wave
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import f5_tts_amd  # noqa: E402,F401
+from f5_tts_amd import config, synth  # noqa: E402
+from f5_tts_amd import dist as fdist  # noqa: E402
+from f5_tts_amd import infer as I  # noqa: E402
+from f5_tts_amd.engine import F5HipCFM, F5HipEngine, F5HipVocos, filter_vocos_keys, map_checkpoint_keys  # noqa: E402
+
+
+def write_wav(path, samples, sr=24000):
+    pcm = (np.clip(samples, -1.0, 1.0) * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--list"); ap.add_argument("--out", default="infer_out")
+    ap.add_argument("--model", default="F5TTS_v1_Base"); ap.add_argument("--ckpt"); ap.add_argument("--vocab"); ap.add_argument("--vocos")
+    ap.add_argument("--synthetic", type=int, default=0); ap.add_argument("--nfe", type=int, default=16)
+    ap.add_argument("--precision", default="fp16x3"); ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rank, local, world = fdist.init_distributed()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    cfg, vcfg = config.PRESETS[a.model], config.VOCOS_MEL_24K
+    vocab = None
+    if a.vocab:
+        vocab, vsize = I.get_tokenizer(a.vocab)
+        from dataclasses import replace
+        cfg = replace(cfg, text_num_embeds=vsize)
+    if vocab is None:  # smoke / throughput runs without a vocab.txt: printable ASCII, id 0 = space (the reference's unknown id)
+        vocab = {" ": 0, **{chr(c): c - 32 for c in range(33, 127)}}
+    eng = F5HipEngine(cfg, vcfg, device=dev)
+    if rank == 0:  # rank 0 owns the checkpoint files
+        sd = I._read_checkpoint(a.ckpt) if a.ckpt else None
+        if sd is not None:
+            sd = map_checkpoint_keys({"ema_model_state_dict": sd} if a.ckpt.endswith(".safetensors") else sd)
+            sd = {k: v for k, v in sd.items() if k.startswith("transformer.")}
+        else:
+            sd = synth.synth_dit_state_dict(cfg, seed=0)
+        vsd = (filter_vocos_keys(torch.load(os.path.join(a.vocos, "pytorch_model.bin"), map_location="cpu", weights_only=True)) if a.vocos
+               else synth.synth_vocos_state_dict(vcfg, seed=0))
+        eng.load_state_dict({**sd, **vsd}, strict=False, finalize=False)
+    fdist.broadcast_engine_weights(eng, src=0)
+    model, voc = F5HipCFM(eng, vocab_char_map=vocab, precision=a.precision), F5HipVocos(eng)
+
+    if a.synthetic:
+        utts = [(f"syn{i:04d}", (synth.synth_wave(24000 * (3 + i % 4), seed=i), 24000), "some call me nature, others call me mother nature.",
+                 "i have been here for over four and a half billion years. " * (1 + i % 3)) for i in range(a.synthetic)]
+    else:
+        utts = []
+        for line in open(a.list, encoding="utf-8"):
+            uid, ref_wav, ref_text, gen_text = line.rstrip("\n").split("|")[:4]
+            utts.append((uid, ref_wav, ref_text, gen_text))
+    costs = [len(u[3].encode()) + len(u[2].encode()) for u in utts]  # text bytes ~ frames to generate
+    mine = fdist.shard_balanced(costs, world)[rank]
+    os.makedirs(a.out, exist_ok=True)
+    if world > 1:
+        torch.distributed.barrier()  # eval_infer_batch.py:178
+    t0 = time.perf_counter()
+    audio_s = 0.0
+    for i in mine:
+        uid, ref, ref_text, gen_text = utts[i]
+        wav, sr, _ = I.infer_process(ref, ref_text, gen_text, model, voc, show_info=lambda *_: None, nfe_step=a.nfe, seed=a.seed)
+        write_wav(os.path.join(a.out, uid + ".wav"), wav, sr)
+        audio_s += len(wav) / sr
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        torch.distributed.barrier()  # eval_infer_batch.py:214
+    dt = fdist.barrier_max_seconds(time.perf_counter() - t0, dev)
+    tot = torch.tensor([audio_s], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tot)
+    if rank == 0:
+        print(f"{len(utts)} utterances, {float(tot):.1f} s of audio in {dt:.2f} s on {world} GPU(s): RTF {dt / max(float(tot), 1e-9):.4f}")
+
+
+if __name__ == "__main__":
+    main()
