@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
   constexpr int TILE_A = BM * GEMM_KTB, TILE_W = BN * GEMM_KTB;
   constexpr int STAGE = TILE_A + TILE_W;
   static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
-  static_assert(NS == 3, "ring depth 3: two tiles in flight");
+  static_assert(NS == 3 || NS == 2, "ring depth 3 (two tiles in flight) or 2 (one tile in flight, for tiles whose stage is 64 KB)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -498,18 +498,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
   };
 
   const int nkt = (kbytes + GEMM_KTB - 1) / GEMM_KTB;
-  issue(0, 0);
-  issue(1, 1);
-  wait_vmcnt<LPT>();  // tile 0 landed (this wave's pieces); tile 1 in flight
-  wg_barrier();
-  int st = 0;  // stage of tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int st2 = st == 0 ? 2 : st - 1;  // (st + 2) % 3: the stage phase kt-1 finished reading before the last barrier
-    issue(kt + 2, st2);                    // past the end: zeros, never read
-    compute(st);
-    wait_vmcnt<LPT>();                     // tile kt+1 landed; tile kt+2 stays in flight across the barrier
+  if constexpr (NS == 3) {
+    issue(0, 0);
+    issue(1, 1);
+    wait_vmcnt<LPT>();  // tile 0 landed (this wave's pieces); tile 1 in flight
     wg_barrier();
-    st = st == 2 ? 0 : st + 1;
+    int st = 0;  // stage of tile kt
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int st2 = st == 0 ? 2 : st - 1;  // (st + 2) % 3: the stage phase kt-1 finished reading before the last barrier
+      issue(kt + 2, st2);                    // past the end: zeros, never read
+      compute(st);
+      wait_vmcnt<LPT>();                     // tile kt+1 landed; tile kt+2 stays in flight across the barrier
+      wg_barrier();
+      st = st == 2 ? 0 : st + 1;
+    }
+  } else {  // two stages: the phase is long enough (>= 48 MFMAs per wave) to cover one tile's flight
+    issue(0, 0);
+    wait_vmcnt<0>();
+    wg_barrier();
+    for (int kt = 0; kt < nkt; ++kt) {
+      issue(kt + 1, (kt + 1) & 1);  // the stage phase kt-1 finished reading before the last barrier
+      compute(kt & 1);
+      wait_vmcnt<0>();              // tile kt+1 landed
+      wg_barrier();
+    }
   }
   wait_vmcnt<0>();  // drain the two dummy tiles before the workgroup's LDS is released
 

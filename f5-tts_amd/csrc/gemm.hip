@@ -90,6 +90,9 @@ int pick_variant(const GemmCore& g, int batch) {
   // 128x64 tiles (3 workgroups per CU) until the grid is several waves deep, then 128x128 (higher FLOP per byte staged):
   // measured crossover between M = 2812 (B=1: 128x64 wins on all four block GEMMs) and M = 22496 (B=8: 128x128 wins).
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
+  // many waves of tiles: the 256x256 / 8-wave LDS-DMA tile (128x64 per wave) stages and reads the fewest LDS bytes per MFMA —
+  // the LDS pipe, not the matrix pipe, is what the 128x128 tile saturates first (+10-16 % at M >= 22k in both fp16 modes)
+  if (big >= 1024 && g.M >= 16384 && g.N >= 1024 && batch == 1 && g.K % 32 == 0) return 21;
   if (big >= 1024) return 2;
   // small grids: the direct-to-LDS ring (variant 6) wins where the tile count is lowest (N <= 1024: out-projection, FF2: -10 %),
   // the register-staged kernel elsewhere (tools/kernel_bench.py, B=1)
@@ -97,10 +100,10 @@ int pick_variant(const GemmCore& g, int batch) {
 }
 
 // direct-to-LDS ring variants (variant ids 6 = 128x64, 7 = 128x128, 3-stage ring)
-template <typename T, int NSPLIT, int TM, int TN, typename Epi>
+template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3>
 hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
-  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, TM, TN>();
-  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi>;
+  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, TM, TN, WGM, WGN, NS>();
+  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi, WGM, WGN, NS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -109,9 +112,9 @@ hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s
   }
   if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
     return hipErrorInvalidValue;
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, e);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, s, g, e);
   return hipGetLastError();
 }
 
@@ -142,6 +145,8 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
     case 13: return launch_glds<T, NSPLIT, 4, 2, Epi>(g, e, batch, s);  // 256x128, 4 waves of 128x64
     case 14: return launch_glds<T, NSPLIT, 2, 4, Epi>(g, e, batch, s);  // 128x256, 4 waves of 64x128
+    case 21: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2>(g, e, batch, s);  // 256x256, 8 waves of 128x64, 2-stage ring
+    case 22: return launch_glds<T, NSPLIT, 2, 4, Epi, 4, 2, 2>(g, e, batch, s);  // 256x256, 8 waves of 64x128, 2-stage ring
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);
     default: break;
