@@ -13,6 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
 
+ABI_VERSION = 3  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 
@@ -20,7 +21,8 @@ PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 class DitConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "dim", "depth", "heads", "dim_head", "ff_inner", "mel_dim", "text_num_embeds", "text_dim", "conv_layers",
-        "text_mask_padding", "pe_attn_head", "attn_mask_enabled", "conv_pos_kernel", "conv_pos_groups", "backbone")]
+        "text_mask_padding", "pe_attn_head", "attn_mask_enabled", "conv_pos_kernel", "conv_pos_groups", "backbone",
+        "qk_norm", "long_skip_connection", "text_average_upsampling", "skip_connect_type")]
 
 
 class VocosConfigC(C.Structure):
@@ -40,7 +42,7 @@ SYMBOLS = {
     "f5hip_weight_blob": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "f5hip_mark_all_loaded": (C.c_int, [_P]),
     "f5hip_finalize_weights": (C.c_int, [_P]),
-    "f5hip_mel": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int, _P]),
+    "f5hip_mel": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, _P]),
     "f5hip_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float,
                                C.c_int, _P, _P, _P]),
     "f5hip_debug_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
@@ -74,7 +76,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if lib.f5hip_abi_version() != 2:
+    if lib.f5hip_abi_version() != ABI_VERSION:
         raise F5HipError("libf5hip ABI version mismatch")
     if path == LIB_PATH:
         _lib = lib

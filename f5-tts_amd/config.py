@@ -35,6 +35,11 @@ class DiTConfig:
     conv_pos_kernel: int = 31
     conv_pos_groups: int = 16
     backbone: str = "DiT"
+    # optional DiT variants no shipped yaml turns on, but the constructor accepts (reference dit.py:181-189)
+    qk_norm: Optional[str] = None                    # "rms_norm": per-head RMSNorm(eps 1e-6) on q and k before rope (modules.py:402-409,493-496)
+    long_skip_connection: bool = False               # Linear(2D -> D, no bias) over cat(x_out, x_in) after the blocks (dit.py:228,354-365)
+    text_embedding_average_upsampling: bool = False  # zipvoice-style late upsampling of the text tokens over the frames (dit.py:55-84,131-137)
+    skip_connect_type: str = "concat"                # UNetT only: "concat" | "add" | "none" (unett.py:127,289-295)
 
     @property
     def ff_inner(self) -> int:
@@ -46,12 +51,14 @@ class DiTConfig:
             return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_mult=self.ff_mult,
                         text_dim=self.text_dim, text_mask_padding=self.text_mask_padding, conv_layers=self.conv_layers,
                         pe_attn_head=self.pe_attn_head, attn_mask_enabled=self.attn_mask_enabled, mel_dim=self.mel_dim,
-                        text_num_embeds=self.text_num_embeds)
+                        text_num_embeds=self.text_num_embeds, qk_norm=self.qk_norm, skip_connect_type=self.skip_connect_type)
         return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head,
                     ff_mult=self.ff_mult, text_dim=self.text_dim, text_mask_padding=self.text_mask_padding,
                     conv_layers=self.conv_layers, pe_attn_head=self.pe_attn_head,
                     attn_mask_enabled=self.attn_mask_enabled, mel_dim=self.mel_dim,
-                    text_num_embeds=self.text_num_embeds)
+                    text_num_embeds=self.text_num_embeds, qk_norm=self.qk_norm,
+                    long_skip_connection=self.long_skip_connection,
+                    text_embedding_average_upsampling=self.text_embedding_average_upsampling)
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -80,6 +87,9 @@ DIT_TINY = DiTConfig(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, text_dim
 DIT_TINY_V0 = replace(DIT_TINY, text_mask_padding=False, pe_attn_head=1)
 UNETT_TINY = DiTConfig(dim=256, depth=4, heads=4, dim_head=64, ff_mult=4, text_dim=N_MEL_CHANNELS, conv_layers=0,
                        text_mask_padding=False, pe_attn_head=1, text_num_embeds=255, backbone="UNetT")
+# every optional DiT switch at once (qk RMSNorm, long skip, average upsampling, key-padding mask)
+DIT_TINY_FLAGS = replace(DIT_TINY, qk_norm="rms_norm", long_skip_connection=True, text_embedding_average_upsampling=True,
+                         attn_mask_enabled=True)
 VOCOS_MEL_24K = VocosConfig()
 VOCOS_TINY = VocosConfig(dim=128, intermediate_dim=384, num_layers=2)
 
@@ -90,4 +100,10 @@ PRESETS = {
     "tiny_v0": DIT_TINY_V0,
     "E2TTS_Base": E2TTS_BASE,
     "tiny_unett": UNETT_TINY,
+    "tiny_flags": DIT_TINY_FLAGS,
+    "tiny_qknorm": replace(DIT_TINY, qk_norm="rms_norm"),
+    "tiny_longskip": replace(DIT_TINY, long_skip_connection=True),
+    "tiny_avgup": replace(DIT_TINY, text_embedding_average_upsampling=True),
+    "tiny_unett_add": replace(UNETT_TINY, skip_connect_type="add", qk_norm="rms_norm", attn_mask_enabled=True),
+    "tiny_unett_noskip": replace(UNETT_TINY, skip_connect_type="none"),
 }

@@ -91,7 +91,7 @@ void build_slots(f5hip_ctx* ctx) {
   if (c.backbone == 1) {  // UNetT: reference unett.py:147-186 -> keys layers.{i}.{0: skip_proj, 1: attn_norm, 2: attn, 3: ff_norm, 4: ff}
     for (int i = 0; i < c.depth; ++i) {
       const std::string b = p + "layers." + std::to_string(i) + ".";
-      if (i >= c.depth / 2) add_slot(ctx, b + "0.weight", D * 2 * D);
+      if (i >= c.depth / 2 && c.skip_connect_type == 0) add_slot(ctx, b + "0.weight", D * 2 * D);
       add_slot(ctx, b + "1.g", D);
       add_slot(ctx, b + "2.to_q.weight", inner * D);
       add_slot(ctx, b + "2.to_k.weight", inner * D);
@@ -101,6 +101,10 @@ void build_slots(f5hip_ctx* ctx) {
       add_slot(ctx, b + "2.to_v.bias", inner);
       add_slot(ctx, b + "2.to_out.0.weight", D * inner);
       add_slot(ctx, b + "2.to_out.0.bias", D);
+      if (c.qk_norm) {
+        add_slot(ctx, b + "2.q_norm.weight", c.dim_head);
+        add_slot(ctx, b + "2.k_norm.weight", c.dim_head);
+      }
       add_slot(ctx, b + "3.g", D);
       add_slot(ctx, b + "4.ff.0.0.weight", F * D);
       add_slot(ctx, b + "4.ff.0.0.bias", F);
@@ -124,12 +128,17 @@ void build_slots(f5hip_ctx* ctx) {
     add_slot(ctx, b + "attn.to_v.bias", inner);
     add_slot(ctx, b + "attn.to_out.0.weight", D * inner);
     add_slot(ctx, b + "attn.to_out.0.bias", D);
+    if (c.qk_norm) {
+      add_slot(ctx, b + "attn.q_norm.weight", c.dim_head);
+      add_slot(ctx, b + "attn.k_norm.weight", c.dim_head);
+    }
     add_slot(ctx, b + "ff.ff.0.0.weight", F * D);
     add_slot(ctx, b + "ff.ff.0.0.bias", F);
     add_slot(ctx, b + "ff.ff.2.weight", D * F);
     add_slot(ctx, b + "ff.ff.2.bias", D);
   }
   if (c.backbone != 1) {
+    if (c.long_skip_connection) add_slot(ctx, p + "long_skip_connection.weight", D * 2 * D);
     add_slot(ctx, p + "norm_out.linear.weight", 2 * D * D);
     add_slot(ctx, p + "norm_out.linear.bias", 2 * D);
     add_slot(ctx, p + "proj_out.weight", mel * D);
@@ -264,7 +273,8 @@ int finalize_impl(f5hip_ctx* ctx) {
   const int64_t per_block = 3 * inner * D + D * inner + F * D + D * F;
   if (D % 32 || inner % 32 || F % 32) FAIL(F5HIP_ERR_UNSUPPORTED, "dim, heads*dim_head and ff_inner must be multiples of 32 (packed fp16x3 operand rows)");
   const bool unett = c.backbone == 1;
-  const int64_t skip_elems = unett ? (int64_t)(c.depth / 2) * D * 2 * D : 0;
+  const bool skip_concat = unett && c.skip_connect_type == 0;
+  const int64_t skip_elems = skip_concat ? (int64_t)(c.depth / 2) * D * 2 * D : (!unett && c.long_skip_connection) ? D * 2 * D : 0;
   HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
   f16* hp = ctx->half_pool.as<f16>();
   ctx->blocks.assign(c.depth, BlockW{});
@@ -283,7 +293,11 @@ int finalize_impl(f5hip_ctx* ctx) {
     if (unett) {
       bw.g_attn = W(ctx, b + "1.g");
       bw.g_ff = W(ctx, b + "3.g");
-      bw.wskip = i >= c.depth / 2 ? W(ctx, b + "0.weight") : nullptr;
+      bw.wskip = (skip_concat && i >= c.depth / 2) ? W(ctx, b + "0.weight") : nullptr;
+    }
+    if (c.qk_norm) {
+      bw.qn = W(ctx, ba + "q_norm.weight");
+      bw.kn = W(ctx, ba + "k_norm.weight");
     }
     auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk) -> hipError_t {
       hi = hp; hp += rows * K;
@@ -297,6 +311,10 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk));
     HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk));
     if (bw.wskip) HIPCHK(carve(bw.wskip, D, 2 * D, bw.wskip_hi, bw.wskip_pk));
+    if (!unett && c.long_skip_connection && i == c.depth - 1) {
+      ctx->wlong = W(ctx, p + "long_skip_connection.weight");
+      HIPCHK(carve(ctx->wlong, D, 2 * D, ctx->wlong_hi, ctx->wlong_pk));
+    }
   }
   if (unett) {
     ctx->norm_out_g = W(ctx, p + "norm_out.g");
@@ -395,6 +413,33 @@ int finalize_impl(f5hip_ctx* ctx) {
         fb[(size_t)k * nmel + m] = (float)v;
       }
     }
+    // BigVGAN-type mel (modules.py:50): librosa.filters.mel defaults = Slaney mel scale (linear to 1 kHz at 200/3 Hz per mel, then
+    // log with step ln(6.4)/27), triangles on the FFT bin centres, each scaled by 2 / bandwidth; float32 table, float64 arithmetic
+    std::vector<float> fbs((size_t)nbin * nmel);
+    {
+      const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+      auto hz2mel_s = [&](double f) { return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp; };
+      const double lo = hz2mel_s(fmin), hi = hz2mel_s(fmax);
+      std::vector<double> mel_f(nmel + 2);
+      for (int i = 0; i < nmel + 2; ++i) {
+        // numpy.linspace: start + i * step, the last point set to stop exactly
+        const double m = i == nmel + 1 ? hi : lo + (double)i * ((hi - lo) / (double)(nmel + 1));
+        mel_f[i] = m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+      }
+      const double d = (double)nfft * (1.0 / sr);
+      for (int m = 0; m < nmel; ++m) {
+        const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+        for (int k = 0; k < nbin; ++k) {
+          const double fr = (double)k / d;
+          const double lower = (fr - mel_f[m]) / (mel_f[m + 1] - mel_f[m]);
+          const double upper = (mel_f[m + 2] - fr) / (mel_f[m + 2] - mel_f[m + 1]);
+          const float w = (float)std::max(0.0, std::min(lower, upper));  // weights[] is float32 before the normalisation
+          fbs[(size_t)k * nmel + m] = (float)((double)w * enorm);
+        }
+      }
+    }
+    HIPCHK(ctx->melfb_slaney.ensure(fbs.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(ctx->melfb_slaney.p, fbs.data(), fbs.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx->twiddle.ensure(tw.size() * sizeof(float)));
     HIPCHK(ctx->window.ensure(win.size() * sizeof(float)));
     HIPCHK(ctx->melfb.ensure(fb.size() * sizeof(float)));
@@ -496,7 +541,10 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
   ENS(step_cond, BN * mel * 4); ENS(cconst, M * D * 4); ENS(y, BN * mel * 4);
   ENS(h, M * D * 4); ENS(c1, M * D * 4); ENS(x, M * D * 4);
   ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)ns * c.dim_head * 4);
-  if (unett) ENS(skipcat, (int64_t)(c.depth / 2) * M * 2 * D * (op == OP_F16 ? 2 : 4));
+  if (unett && c.skip_connect_type != 2) ENS(skipcat, (int64_t)(c.depth / 2) * M * 2 * D * (op == OP_F16 ? 2 : 4));
+  if (!unett && c.long_skip_connection) ENS(skipcat, M * 2 * D * (op == OP_F16 ? 2 : 4));
+  if (c.text_average_upsampling) ENS(avgidx, BN * 4);
+  if (c.qk_norm && !exact_attn) { ENS(q32, M * inner * 4); ENS(k32, M * inner * 4); }  // raw q/k rows between the GEMM and the norm kernel
   if (op == OP_F32) {
     ENS(a32, M * D * 4); ENS(o32, M * inner * 4); ENS(f32, M * F * 4);
   } else {
@@ -534,8 +582,9 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
   const auto& c = ctx->cfg;
   const int T = c.text_dim;
   const int64_t BN = (int64_t)B * n, M = 2 * BN;
-  std::vector<int32_t> tok(BN);
+  std::vector<int32_t> tok(BN), avg(c.text_average_upsampling ? BN : 0, -1);
   std::vector<uint8_t> valid(BN), keep(M);
+  std::vector<int32_t> vpos;
   for (int b = 0; b < B; ++b) {
     // DiT: per-sample valid length when a mask is passed (dit.py:295-298); UNetT: the padded frame count for every sample (unett.py:218-228)
     const int64_t sl = (use_mask && c.backbone != 1) ? std::min<int64_t>(duration[b], n) : n;
@@ -550,7 +599,22 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
       keep[(int64_t)b * n + pos] = k;
       keep[BN + (int64_t)b * n + pos] = k;
     }
+    if (c.text_average_upsampling) {
+      // average_upsample_text_by_mask (dit.py:55-84): the tl valid tokens are spread over the first sl frames, token j repeated
+      // sl / tl times and the last sl % tl tokens once more; frames behind stay zero
+      vpos.clear();
+      for (int pos = 0; pos < n; ++pos)
+        if (tok[(int64_t)b * n + pos] != 0) vpos.push_back(pos);
+      const int64_t tl = (int64_t)vpos.size(), al = sl;
+      if (tl > 0 && al > 0) {
+        const int64_t base = al / tl, rem = al % tl;
+        int64_t o = 0;
+        for (int64_t j = 0; j < tl && o < al; ++j)
+          for (int64_t r = base + (j >= tl - rem ? 1 : 0); r > 0 && o < al; --r) avg[(int64_t)b * n + o++] = vpos[j];
+      }
+    }
   }
+  if (c.text_average_upsampling) HIPCHK(hipMemcpyAsync(ctx->avgidx.p, avg.data(), BN * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->tok.p, tok.data(), BN * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BN, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(ctx->textkeep.p, keep.data(), M, hipMemcpyHostToDevice, st));
@@ -576,6 +640,10 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
     e.res = tx; e.ldres = T;
     e.rowmask = keepd; e.mask_mode = 2;  // masked_fill after the residual add (dit.py:127)
     HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  if (c.text_average_upsampling) {  // dit.py:131-137, after the text encoder; the cond and uncond halves share the token mask (dit.py:104-108)
+    HIPCHK(launch_gather_seq_rows(tx, ctx->avgidx.as<int32_t>(), 2 * B, B, n, T, ctx->ta.as<float>(), st));
+    HIPCHK(hipMemcpyAsync(tx, ctx->ta.p, (size_t)M * T * 4, hipMemcpyDeviceToDevice, st));
   }
   return F5HIP_OK;
 }
@@ -624,6 +692,44 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
   return F5HIP_OK;
 }
 
+// ---- fused to_q|to_k|to_v GEMM of one block: bias + rope + 1/sqrt(dh) + head split in the epilogue (modules.py:481-509; SDPA default
+// scale).  M rows = sequences [s0, s0 + M/ns) of ns tokens.  With qk_norm the epilogue leaves q and k raw (fp32, bias only) and
+// qk_norm_rope_kernel applies RMSNorm(dim_head) -> rope -> scale and writes what the attention kernels read (modules.py:493-509).
+int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M, int ns, int s0, int op, bool exact_attn, int wbytes,
+            hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int D = c.dim, H = c.heads, dh = c.dim_head, inner = H * dh;
+  const int64_t qoff = (int64_t)s0 * H * ns * dh;
+  EpiQKV e{};
+  e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
+  e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
+  e.qk_raw = c.qk_norm ? 1 : 0;
+  if (exact_attn || c.qk_norm) { e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; }
+  if (exact_attn) {
+    e.ldvt = (ns + 3) & ~3;
+    e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
+  } else {
+    e.ldvt = (ns + 7) & ~7;
+    const int64_t voff = (int64_t)s0 * inner * e.ldvt;
+    e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
+    if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
+      e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
+      if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
+    }
+  }
+  {
+    Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
+    GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
+    HIPCHK(launch_gemm_qkv(op, g, e, st));
+  }
+  if (c.qk_norm) {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 2.0 * M * inner * (4.0 + (exact_attn ? 4.0 : 2.0 * (e.q16_lo ? 2 : 1))));
+    HIPCHK(launch_qk_norm_rope(e.q32, e.k32, bw.qn, bw.kn, e.rope_cs, (int64_t)(M / ns) * H * ns, ns, H, dh, c.pe_attn_head, e.qscale, 1e-6f,
+                               e.q16, e.q16_lo, e.k16, e.k16_lo, st));
+  }
+  return F5HIP_OK;
+}
+
 // ---- one ODE function evaluation + Euler update ---------------------------------------------------
 // br < 0: the packed batch (cond rows, then uncond rows with CFG) followed by the CFG/ODE update.  br = 0 / 1: only the cond / uncond
 // branch (B sequences) and NO update — the two branches never interact inside the backbone, so enqueue_steps may run them on two
@@ -631,7 +737,7 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
 int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st, int br = -1) {
   const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
-  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner;
   const int64_t BN = (int64_t)B * n;
   const int S = br < 0 ? nb * B : B, s0 = br < 0 ? 0 : br * B;  // sequences handled here, first sequence
   const int64_t r0 = (int64_t)s0 * n;                            // first row
@@ -677,8 +783,20 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() + r0 * ldF : nullptr;
   f16* f_lo = pk ? f_hi + 32 : nullptr;
   const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() + s0 : nullptr;
-  const int64_t qoff = (int64_t)s0 * H * n * dh;
   const double ln_bytes = (double)M * D * (4 + wbytes * (op == OP_F16X3 ? 2 : 1));
+  // long_skip_connection (dit.py:228,354-365): cat(x_after_blocks, x_before_blocks) is ONE [M, 2D] operand in the mode's layout, its
+  // right half written here, its left half after the last block; the Linear(2D -> D, no bias) is then a single K = 2D GEMM
+  const int64_t ldC = 2 * ldA;
+  char* catbuf = c.long_skip_connection ? ctx->skipcat.as<char>() + r0 * 2 * D * (op == OP_F16 ? 2 : 4) : nullptr;
+  auto emit_cat = [&](int col0) -> hipError_t {  // operand copy of x (layernorm mode 2 = no normalisation) into columns [col0, col0 + D)
+    if (op == OP_F32) return launch_layernorm(x, D, M, D, 0.f, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<float*>(catbuf) + col0, nullptr, nullptr, 2 * D, st, 0, 0, 2);
+    f16* hi = reinterpret_cast<f16*>(catbuf) + pk_off(col0, pk);
+    return launch_layernorm(x, D, M, D, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, hi, pk ? hi + 32 : nullptr, 0, st, pk, ldC, 2);
+  };
+  if (catbuf) {
+    Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+    HIPCHK(emit_cat(D));
+  }
 
   for (int i = 0; i < c.depth; ++i) {
     const BlockW& bw = ctx->blocks[i];
@@ -687,26 +805,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st, pk, ldA));
     }
-    {  // fused to_q|to_k|to_v + rope + 1/sqrt(dh) (modules.py:481-509; SDPA default scale)
-      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-      GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
-      EpiQKV e{};
-      e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = n; e.heads = H; e.dh = dh;
-      e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
-      if (exact_attn) {
-        e.ldvt = (n + 3) & ~3;
-        e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
-      } else {
-        e.ldvt = (n + 7) & ~7;
-        const int64_t voff = (int64_t)s0 * inner * e.ldvt;
-        e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-        if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
-          e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
-          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
-        }
-      }
-      HIPCHK(launch_gemm_qkv(op, g, e, st));
-    }
+    CHK(run_qkv(ctx, bw, A, ldA, M, n, s0, op, exact_attn, wbytes, st));
     CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
@@ -734,6 +833,15 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
   }
+  if (catbuf) {  // x = long_skip_connection(cat(x, residual)) (dit.py:364-365)
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(emit_cat(0));
+    }
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, D, 2 * D), 0);
+    GemmCore g = core(catbuf, ldC, wsel(op, ctx->wlong, ctx->wlong_hi, ctx->wlong_pk), ldC, M, D, 2 * D);
+    HIPCHK(launch_gemm_store(op, g, epi_store(x, D, nullptr), 1, st));
+  }
   {  // AdaLayerNorm_Final: chunk order is (scale, shift) (modules.py:344) + proj_out (dit.py:367-368)
     const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
     {
@@ -757,7 +865,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
 int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st, int br = -1) {
   const int step = sg.eidx, nb = ctx->nb;
   const auto& c = ctx->cfg;
-  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner;
   const int ns = n + 1;
   const int S = br < 0 ? nb * B : B, s0 = br < 0 ? 0 : br * B;  // sequences handled here (br: see run_step)
   const int64_t BN = (int64_t)B * n;
@@ -784,7 +892,6 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
   f16* f_hi = op != OP_F32 ? ctx->f_hi.as<f16>() + r0 * ldF : nullptr;
   f16* f_lo = pk ? f_hi + 32 : nullptr;
   const int32_t* kvlen = (c.attn_mask_enabled && use_mask) ? ctx->kvlen.as<int32_t>() + s0 : nullptr;
-  const int64_t qoff = (int64_t)s0 * H * ns * dh;
   const double ln_bytes = (double)M * D * (4 + wbytes * pl);
   // concat buffer of skip level l: [M, 2D] in the operand layout; columns [0, D) = current x, [D, 2D) = the saved skip
   const int64_t cat_elem_bytes = op == OP_F16 ? 2 : 4;  // fp32: 4 B; fp16: 2 B; packed hi/lo: 2 x 2 B per logical element
@@ -819,7 +926,13 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
 
   for (int i = 0; i < c.depth; ++i) {
     const BlockW& bw = ctx->blocks[i];
-    if (i < c.depth / 2) {  // skips.append(x) (unett.py:286-287): kept as the right half of that level's concat operand
+    if (c.skip_connect_type == 2) {  // "none": no skip connections at all (unett.py:289-295)
+    } else if (c.skip_connect_type == 1) {  // "add": x = x + skips.pop() (unett.py:294-295); the level's slab holds an fp32 [M, D] copy
+      float* slab = reinterpret_cast<float*>(cat_ptr(i < c.depth / 2 ? i : c.depth - 1 - i));
+      Prof pr(ctx, st, KC_ELEMWISE, 0, (double)M * D * 4 * (i < c.depth / 2 ? 2 : 3));
+      if (i < c.depth / 2) HIPCHK(hipMemcpyAsync(slab, x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+      else HIPCHK(launch_add_inplace(x, slab, (int64_t)M * D, st));
+    } else if (i < c.depth / 2) {  // skips.append(x) (unett.py:286-287): kept as the right half of that level's concat operand
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(emit_cat(i, D));
     } else {  // x = skip_proj(cat(x, skips.pop())) (unett.py:289-293)
@@ -836,26 +949,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_attn, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
     }
-    {
-      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), 0);
-      GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
-      EpiQKV e{};
-      e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
-      e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
-      if (exact_attn) {
-        e.ldvt = (ns + 3) & ~3;
-        e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
-      } else {
-        e.ldvt = (ns + 7) & ~7;
-        const int64_t voff = (int64_t)s0 * inner * e.ldvt;
-        e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-        if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
-          e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
-          if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
-        }
-      }
-      HIPCHK(launch_gemm_qkv(op, g, e, st));
-    }
+    CHK(run_qkv(ctx, bw, A, ldA, M, ns, s0, op, exact_attn, wbytes, st));
     CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
@@ -969,6 +1063,12 @@ int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int d
   if (dc->mel_dim > 256) return bad("mel_dim must be <= 256");
   if (dc->backbone != 0 && dc->backbone != 1) return bad("backbone must be 0 (DiT) or 1 (UNetT)");
   if (dc->backbone == 1 && (dc->conv_layers != 0 || (dc->depth & 1))) return bad("UNetT: conv_layers must be 0 and depth even (unett.py:130)");
+  if (dc->qk_norm != 0 && dc->qk_norm != 1) return bad("Unimplemented qk_norm (modules.py:409): 0 = None, 1 = rms_norm");
+  if (dc->qk_norm && (dc->dim_head % 4 || dc->dim_head > 256 || (dc->dim_head & (dc->dim_head - 1)))) return bad("qk_norm: dim_head must be a power of two <= 256");
+  if (dc->text_average_upsampling && !dc->text_mask_padding) return bad("text_embedding_average_upsampling requires text_mask_padding to be True (dit.py:43)");
+  if (dc->backbone == 1 && (dc->long_skip_connection || dc->text_average_upsampling)) return bad("long_skip_connection / average upsampling are DiT options (dit.py:181-189)");
+  if (dc->skip_connect_type < 0 || dc->skip_connect_type > 2) return bad("skip_connect_type: 0 = concat, 1 = add, 2 = none (unett.py:127)");
+  if (dc->backbone != 1 && dc->skip_connect_type != 0) return bad("skip_connect_type is a UNetT option (unett.py:127)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
     g_create_err = "no such HIP device (libf5hip has no CPU fallback)";
@@ -1088,18 +1188,23 @@ int f5hip_reset_kernel_stats(f5hip_ctx* ctx) {
 }
 
 // ---- mel -----------------------------------------------------------------------------------------
-int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float* out, int frame_major, void* stream) {
+int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float* out, int frame_major, int mel_type, void* stream) {
   if (!ctx || !wav || !out || batch <= 0) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
-  if (nsamp < 513) FAIL(F5HIP_ERR_INVALID, "reflect padding needs more than n_fft/2 samples (got %lld)", (long long)nsamp);
+  if (mel_type != 0 && mel_type != 1) FAIL(F5HIP_ERR_INVALID, "mel_type %d: only vocos (0) and bigvgan (1) exist (modules.py:127)", mel_type);
+  // vocos type: centred frames, n_fft/2 reflect padding; bigvgan type: (n_fft - hop)/2 padding, frames that fit (modules.py:59-72)
+  const int pad = mel_type == 1 ? (1024 - 256) / 2 : 512;
+  if (nsamp < pad + 1) FAIL(F5HIP_ERR_INVALID, "reflect padding needs more than %d samples (got %lld)", pad, (long long)nsamp);
+  const int frames = mel_type == 1 ? (int)((nsamp + 2 * pad - 1024) / 256) + 1 : 1 + (int)(nsamp / 256);
+  if (frames <= 0) FAIL(F5HIP_ERR_INVALID, "wave of %lld samples is shorter than one frame", (long long)nsamp);
   HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  const int frames = 1 + (int)(nsamp / 256);
   {
     Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
-    HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->melfb.as<float>(), ctx->cfg.mel_dim,
-                      frame_major, out, st));
+    HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(),
+                      mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(), ctx->cfg.mel_dim, frame_major, pad,
+                      mel_type == 1 ? 1e-9f : 0.f, out, st));
   }
   collect_prof(ctx, st);
   return F5HIP_OK;

@@ -1,5 +1,6 @@
 // audio.hip — Vocos mel front-end and iSTFT head as LDS-resident 1024-point FFT kernels.
-//   mel   : reference model/modules.py:80-109 (torchaudio MelSpectrogram power=1, center=True, HTK, norm=None) -> log(clamp 1e-5)
+//   mel   : reference model/modules.py:80-109 (torchaudio MelSpectrogram power=1, center=True, HTK, norm=None) -> log(clamp 1e-5),
+//           and the BigVGAN-type variant model/modules.py:35-77 (no centring, 384-sample reflect pad, +1e-9, slaney filterbank)
 //   istft : vocos ISTFTHead (exp, clip 1e2, mag*(cos p + i sin p)) + torch.istft(n_fft=1024, hop=256, hann, center=True);
 //           head math restated in-repo at runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:45-59
 // One workgroup per frame: the 1024-point radix-2 FFT runs entirely in LDS (8 KiB), 256 threads = 2 butterflies
@@ -39,15 +40,18 @@ __device__ __forceinline__ void fft1024(float* re, float* im, const float* __res
   __syncthreads();
 }
 
+// pad = samples of reflect padding in front of frame 0: n_fft/2 for the centred Vocos-type STFT, (n_fft-hop)/2 for the BigVGAN-type
+// one (reference model/modules.py:59-60); mag_eps = 1e-9 inside the square root for the BigVGAN type (modules.py:74), 0 otherwise.
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int64_t nsamp, int frames,
                                                    const float* __restrict__ tw, const float* __restrict__ window,
-                                                   const float* __restrict__ melfb, int nmel, int frame_major, float* out) {
+                                                   const float* __restrict__ melfb, int nmel, int frame_major, int pad, float mag_eps,
+                                                   float* out) {
   __shared__ float re[NFFT];
   __shared__ float im[NFFT];
   const int tid = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
   const float* w = wav + (int64_t)b * nsamp;
   for (int i = tid; i < NFFT; i += 256) {
-    int64_t idx = (int64_t)f * HOP + i - NFFT / 2;  // center=True, pad_mode="reflect"
+    int64_t idx = (int64_t)f * HOP + i - pad;  // pad_mode="reflect"
     if (idx < 0) idx = -idx;
     if (idx >= nsamp) idx = 2 * (nsamp - 1) - idx;
     const int br = bitrev10(i);
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int k = tid + r * 256;
-    mag[r] = k < NBIN ? sqrtf(re[k] * re[k] + im[k] * im[k]) : 0.f;
+    mag[r] = k < NBIN ? sqrtf(re[k] * re[k] + im[k] * im[k] + mag_eps) : 0.f;
   }
   __syncthreads();
 #pragma unroll
@@ -126,9 +130,10 @@ __global__ void istft_ola_kernel(const float* __restrict__ frames, const float* 
 }  // namespace
 
 hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
-                      const float* melfb, int nmel, int frame_major, float* out, hipStream_t s) {
-  if (nmel > 256 || nsamp < NFFT / 2 + 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(mel_kernel, dim3(frames, B), dim3(256), 0, s, wav, nsamp, frames, twiddle, window, melfb, nmel, frame_major, out);
+                      const float* melfb, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s) {
+  if (nmel > 256 || nsamp < pad + 1 || frames <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mel_kernel, dim3(frames, B), dim3(256), 0, s, wav, nsamp, frames, twiddle, window, melfb, nmel, frame_major, pad,
+                     mag_eps, out);
   return hipGetLastError();
 }
 hipError_t launch_istft_frames(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window,

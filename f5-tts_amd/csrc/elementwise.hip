@@ -474,3 +474,92 @@ hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_m
   hipLaunchKernelGGL(im2col7_kernel, dim3(grid_1d((int64_t)B * T * ldc)), dim3(256), 0, s, mel, B, T, Cin, channel_major, col, ldc);
   return hipGetLastError();
 }
+
+// ---- optional DiT variants (no shipped config enables them; reference dit.py:181-189) ----------------------------------------------
+namespace {
+// q/k RMSNorm over dim_head (reference modules.py:286-305 with eps 1e-6, applied modules.py:493-496) -> rope on the first pe_heads
+// heads (modules.py:498-509) -> SDPA scale on q.  The QKV GEMM left q and k as fp32 rows [BH, n, dh] holding only Wx + b.
+// One thread owns 4 consecutive channels of one row; the dh/4 threads of a row sit in one wavefront and reduce with shuffles.
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(float* q32, float* k32, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                           const float* __restrict__ rope_cs, int64_t rows, int nseq, int heads, int dh,
+                                                           int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo) {
+  const int tpr = dh >> 2;                                     // threads per row (power of two, <= 64)
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = t / tpr;
+  const bool live = row < rows;
+  const int d = (int)(t - row * tpr) << 2;
+  const int which = blockIdx.y;                                // 0 = q, 1 = k
+  float* src = which ? k32 : q32;
+  float4 v = live ? *reinterpret_cast<const float4*>(src + row * dh + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  for (int o = tpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  if (!live) return;
+  const float r = rsqrtf(ss / (float)dh + eps);
+  const float4 g = *reinterpret_cast<const float4*>((which ? wk : wq) + d);
+  float x[4] = {v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w};
+  const int64_t bh = row / nseq;
+  const int pos = (int)(row - bh * nseq), hh = (int)(bh % heads);
+  if (pe_heads < 0 || hh < pe_heads) {
+    const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((int64_t)pos * (dh / 2) + d / 2) * 2);
+    const float a0 = x[0] * cs.x - x[1] * cs.y, a1 = x[1] * cs.x + x[0] * cs.y;
+    const float a2 = x[2] * cs.z - x[3] * cs.w, a3 = x[3] * cs.z + x[2] * cs.w;
+    x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
+  }
+  if (which == 0) { x[0] *= qscale; x[1] *= qscale; x[2] *= qscale; x[3] *= qscale; }
+  f16* o16 = which ? k16 : q16;
+  if (o16) {
+    f16* o16l = which ? k16_lo : q16_lo;
+    f16x4 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hv[e] = h; lv[e] = l; }
+    *reinterpret_cast<f16x4*>(o16 + row * dh + d) = hv;
+    if (o16l) *reinterpret_cast<f16x4*>(o16l + row * dh + d) = lv;
+  } else {
+    *reinterpret_cast<float4*>(src + row * dh + d) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+// out[s, pos, :] = idx[s % B, pos] >= 0 ? src[s, idx[s % B, pos], :] : 0   (average upsampling of the text tokens, dit.py:55-84)
+__global__ void gather_seq_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int S, int B, int n, int C4, float* out) {
+  const int64_t total = (int64_t)S * n * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / C4;
+    const int c = (int)(i - row * C4);
+    const int s = (int)(row / n), pos = (int)(row - (int64_t)s * n);
+    const int j = idx[(int64_t)(s % B) * n + pos];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j >= 0) v = reinterpret_cast<const float4*>(src + ((int64_t)s * n + j) * C4 * 4)[c];
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+__global__ void add_inplace_kernel(float* x, const float* __restrict__ y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(y)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    reinterpret_cast<float4*>(x)[i] = a;
+  }
+}
+}  // namespace
+
+hipError_t launch_qk_norm_rope(float* q32, float* k32, const float* wq, const float* wk, const float* rope_cs, int64_t rows, int nseq,
+                               int heads, int dh, int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo,
+                               hipStream_t s) {
+  const int tpr = dh / 4;
+  if (dh % 4 || tpr < 1 || tpr > 64 || (tpr & (tpr - 1))) return hipErrorInvalidValue;
+  const int64_t threads = rows * tpr;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s, q32, k32, wq, wk, rope_cs, rows, nseq,
+                     heads, dh, pe_heads, qscale, eps, q16, q16_lo, k16, k16_lo);
+  return hipGetLastError();
+}
+hipError_t launch_gather_seq_rows(const float* src, const int32_t* idx, int S, int B, int n, int C, float* out, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_seq_rows_kernel, dim3(grid_1d((int64_t)S * n * (C / 4))), dim3(256), 0, s, src, idx, S, B, n, C / 4, out);
+  return hipGetLastError();
+}
+hipError_t launch_add_inplace(float* x, const float* y, int64_t n, hipStream_t s) {
+  if (n % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_1d(n / 4)), dim3(256), 0, s, x, y, n / 4);
+  return hipGetLastError();
+}

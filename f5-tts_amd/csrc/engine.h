@@ -55,6 +55,7 @@ struct BlockW {  // per DiT block
   // UNetT only: RMSNorm gains and the later-half skip projection Linear(2D -> D, no bias)
   const float *g_attn = nullptr, *g_ff = nullptr, *wskip = nullptr;
   f16 *wskip_hi = nullptr, *wskip_pk = nullptr;
+  const float *qn = nullptr, *kn = nullptr;  // qk_norm == rms_norm: RMSNorm gains over dim_head (modules.py:402-409)
 };
 struct TextBlockW {
   const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *gamma, *beta, *pw2_w, *pw2_b;
@@ -118,7 +119,7 @@ struct f5hip_ctx {
   DevBuf freqs_cis;                    // [8192, text_dim]
   DevBuf inv_freq;                     // [dh/2]
   DevBuf vhead_w, vhead_b;             // padded vocos head [1028, C], [1028]
-  DevBuf twiddle, window, melfb;       // audio tables
+  DevBuf twiddle, window, melfb, melfb_slaney;  // audio tables (HTK filterbank of the Vocos-type mel, slaney one of the BigVGAN type)
   const float *adaln_w = nullptr, *adaln_b = nullptr;  // [depth*6D, D], [depth*6D]
 
   // time-grid dependent tables (cached on the last grid)
@@ -126,7 +127,11 @@ struct f5hip_ctx {
   DevBuf t_dev, dt_dev, cfg_dev, tsin, th1, tsilu, mods, fmods;
   DevBuf temb;                         // UNetT: raw time embedding per step [steps, D] (the time token)
   const float* norm_out_g = nullptr;   // UNetT final RMSNorm gain
-  DevBuf skipcat;                      // UNetT: depth/2 concat buffers [2B*(n+1), 2D] in the mode's operand layout
+  DevBuf skipcat;                      // UNetT: depth/2 concat buffers [2B*(n+1), 2D] in the mode's operand layout (skip type "add": the
+                                       // same slabs hold fp32 [rows, D] copies); DiT long_skip_connection: one such buffer
+  const float* wlong = nullptr;        // DiT long_skip_connection.weight [D, 2D] (dit.py:228) and its fp16 operand copies
+  f16 *wlong_hi = nullptr, *wlong_pk = nullptr;
+  DevBuf avgidx;                       // text average upsampling: source token position per frame [B, n] int32, -1 = zero row
 
   // workspace (grow-only)
   int ws_B = 0, ws_n = 0;

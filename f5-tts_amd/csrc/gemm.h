@@ -115,6 +115,7 @@ struct EpiQKV {
   f16 *q16_lo, *k16_lo, *vt16_lo;
   float *q32, *k32, *vt32;
   int64_t ldvt;
+  int qk_raw;           // qk_norm variant: q and k leave as fp32 rows holding Wx + b only (q32/k32); qk_norm_rope_kernel finishes them
 
   __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
     const int inner = heads * dh;
@@ -124,6 +125,11 @@ struct EpiQKV {
     const int bp = m / nseq, pos = m - bp * nseq;
     const float4 b = *reinterpret_cast<const float4*>(bias + n);
     float x[4] = {v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w};
+    if (qk_raw && which < 2) {
+      float* dst = (which == 0 ? q32 : k32) + (((int64_t)bp * heads + hh) * nseq + pos) * dh + d;
+      *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
+      return;
+    }
     if (which < 2 && (pe_heads < 0 || hh < pe_heads)) {
       const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((int64_t)pos * (dh / 2) + d / 2) * 2);
       const float a0 = x[0] * cs.x - x[1] * cs.y, a1 = x[1] * cs.x + x[0] * cs.y;
@@ -362,7 +368,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3>
+template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3, int PRIO = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, Epi epi) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
@@ -468,6 +474,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
     }
   };
   auto mma_step = [&](const Frag (&fa)[NPL][TM], const Frag (&fw)[NPL][TN]) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);  // favour the wave that is feeding the matrix pipe over its SIMD partner's loads
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -478,6 +485,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
           Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);
         }
       }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   };
   auto compute = [&](int stage) {
     const uint32_t sA = lds0 + stage * STAGE + (wm * 32 * TM) * GEMM_KTB;

@@ -100,10 +100,10 @@ int pick_variant(const GemmCore& g, int batch) {
 }
 
 // direct-to-LDS ring variants (variant ids 6 = 128x64, 7 = 128x128, 3-stage ring)
-template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3>
+template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3, int PRIO = 0>
 hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
   constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, TM, TN, WGM, WGN, NS>();
-  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi, WGM, WGN, NS>;
+  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi, WGM, WGN, NS, PRIO>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -147,6 +147,7 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 14: return launch_glds<T, NSPLIT, 2, 4, Epi>(g, e, batch, s);  // 128x256, 4 waves of 64x128
     case 21: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2>(g, e, batch, s);  // 256x256, 8 waves of 128x64, 2-stage ring
     case 22: return launch_glds<T, NSPLIT, 2, 4, Epi, 4, 2, 2>(g, e, batch, s);  // 256x256, 8 waves of 64x128, 2-stage ring
+    case 23: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 1>(g, e, batch, s);  // variant 21 + s_setprio around the MFMA clusters
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);
     default: break;

@@ -50,6 +50,13 @@ hipError_t launch_where_rows(const uint8_t* mask, const float* a, const float* b
 //   g = has_uncond ? vc + (vc - vu) * cfg : vc;   dst = base + coef * g;   optional copies of dst (trajectory) and g (debug tap)
 hipError_t launch_cfg_euler(const float* base, float* dst, const float* v, int64_t half_elems, int has_uncond, const float* coef_ptr,
                             const float* cfg_ptr, float* traj_next, float* vel_dbg, hipStream_t s);
+// optional variants: q/k RMSNorm(dh) + rope + q scale over raw fp32 q/k rows [BH, n, dh] (in place when q16 == null, else to the fp16
+// (hi/lo) planes); gather of text rows per sequence (idx [B, n], -1 = zero row; cond and uncond halves share it); x += y
+hipError_t launch_qk_norm_rope(float* q32, float* k32, const float* wq, const float* wk, const float* rope_cs, int64_t rows, int nseq,
+                               int heads, int dh, int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo,
+                               hipStream_t s);
+hipError_t launch_gather_seq_rows(const float* src, const int32_t* idx, int S, int B, int n, int C, float* out, hipStream_t s);
+hipError_t launch_add_inplace(float* x, const float* y, int64_t n, hipStream_t s);
 // sinusoidal time embedding (reference model/modules.py:157-169): t [S] -> out [S, 256]
 hipError_t launch_time_sinus(const float* t, int S, int dim, float* out, hipStream_t s);
 // rope table: out [n, dh/2, 2] = (cos, sin)(pos * inv_freq[i])
@@ -95,7 +102,7 @@ struct AudioTables {
   const float* env_inv;   // unused (envelope computed per call)
 };
 hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
-                      const float* melfb, int nmel, int frame_major, float* out, hipStream_t s);
+                      const float* melfb, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s);
 // head logits [B*T, ld] (log-mag | phase) -> windowed time frames [B, T, 1024]
 hipError_t launch_istft_frames(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window,
                                float* frames, hipStream_t s);

@@ -81,7 +81,11 @@ class F5HipEngine:
                        text_mask_padding=int(dit_cfg.text_mask_padding),
                        pe_attn_head=-1 if dit_cfg.pe_attn_head is None else int(dit_cfg.pe_attn_head),
                        attn_mask_enabled=int(dit_cfg.attn_mask_enabled), conv_pos_kernel=dit_cfg.conv_pos_kernel,
-                       conv_pos_groups=dit_cfg.conv_pos_groups, backbone=1 if dit_cfg.backbone == "UNetT" else 0)
+                       conv_pos_groups=dit_cfg.conv_pos_groups, backbone=1 if dit_cfg.backbone == "UNetT" else 0,
+                       qk_norm={None: 0, "rms_norm": 1}[dit_cfg.qk_norm],  # KeyError == the reference's ValueError (modules.py:409)
+                       long_skip_connection=int(dit_cfg.long_skip_connection),
+                       text_average_upsampling=int(dit_cfg.text_embedding_average_upsampling),
+                       skip_connect_type={"concat": 0, "add": 1, "none": 2}[dit_cfg.skip_connect_type])
         v = None
         if vocos_cfg is not None:
             v = VocosConfigC(input_channels=vocos_cfg.input_channels, dim=vocos_cfg.dim,
@@ -162,17 +166,20 @@ class F5HipEngine:
         self._chk(self.lib.f5hip_reset_kernel_stats(self._ctx))
 
     # -- compute -------------------------------------------------------------------------------
-    def mel(self, wav: torch.Tensor, frame_major: bool = False) -> torch.Tensor:
+    def mel(self, wav: torch.Tensor, frame_major: bool = False, mel_spec_type: str = "vocos") -> torch.Tensor:
+        if mel_spec_type not in ("vocos", "bigvgan"):
+            raise AssertionError('We only support two extract mel backend: vocos or bigvgan')  # modules.py:127
         wav = wav.to(device=self.device, dtype=torch.float32).contiguous()
         if wav.ndim == 3:
             wav = wav.squeeze(1)
         assert wav.ndim == 2
         b, nw = wav.shape
-        frames = 1 + nw // 256
+        big = mel_spec_type == "bigvgan"
+        frames = nw // 256 if big else 1 + nw // 256  # bigvgan: no centring, (1024-256)/2 reflect padding (modules.py:59-60)
         mel = self.dit_cfg.mel_dim
         out = torch.empty((b, frames, mel) if frame_major else (b, mel, frames), device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
-            self._chk(self.lib.f5hip_mel(self._ctx, _ptr(wav), b, nw, _ptr(out), int(frame_major), self._stream()))
+            self._chk(self.lib.f5hip_mel(self._ctx, _ptr(wav), b, nw, _ptr(out), int(frame_major), int(big), self._stream()))
         return out
 
     def sample(self, cond: torch.Tensor, cond_mask: torch.Tensor, text: torch.Tensor, duration: torch.Tensor, use_mask: bool,
@@ -226,14 +233,15 @@ def _as_tensor(ptr: int, numel: int, device: torch.device) -> torch.Tensor:
 class _MelSpecAdapter:
     """``model.mel_spec`` (reference model/modules.py:112-151): callable + the attributes callers read."""
 
-    def __init__(self, engine: F5HipEngine):
+    def __init__(self, engine: F5HipEngine, mel_spec_type: str = "vocos"):
         self._e = engine
         self.n_fft, self.hop_length, self.win_length = 1024, 256, 1024
         self.n_mel_channels = engine.dit_cfg.mel_dim
         self.target_sample_rate = 24000
+        self.mel_spec_type = mel_spec_type
 
     def __call__(self, wav: torch.Tensor) -> torch.Tensor:
-        return self._e.mel(wav, frame_major=False)  # [b, 100, T] like MelSpec.forward
+        return self._e.mel(wav, frame_major=False, mel_spec_type=self.mel_spec_type)  # [b, 100, T] like MelSpec.forward
 
 
 class _TransformerAdapter:
@@ -251,7 +259,7 @@ class F5HipCFM:
     """Drop-in for the ``CFM`` object on the inference path (reference src/f5_tts/model/cfm.py:34-229)."""
 
     def __init__(self, engine: F5HipEngine, vocab_char_map: Optional[Dict[str, int]] = None, ode_method: str = "euler",
-                 precision: str = "fp32"):
+                 precision: str = "fp32", mel_spec_type: str = "vocos"):
         if ode_method not in ("euler", "midpoint"):
             raise ValueError("only the fixed-grid euler / midpoint solvers are built (reference utils_infer.py:60, eval_infer_batch.py:47)")
         self.ode_method = ode_method
@@ -259,7 +267,7 @@ class F5HipCFM:
         self.vocab_char_map = vocab_char_map
         self.precision = precision
         self.num_channels = engine.dit_cfg.mel_dim
-        self.mel_spec = _MelSpecAdapter(engine)
+        self.mel_spec = _MelSpecAdapter(engine, mel_spec_type)
         self.transformer = _TransformerAdapter(engine.dit_cfg)
         self.dim = engine.dit_cfg.dim
 
@@ -279,10 +287,8 @@ class F5HipCFM:
                duplicate_test=False, t_inter=0.1, edit_mask=None):
         """Same contract as ``CFM.sample`` (cfm.py:83-229): returns ``(out, trajectory)``."""
         dev = self.device
-        if duplicate_test:
-            raise ValueError("duplicate_test (a debugging corner of the reference, cfm.py:141-143,206-209) is not built")
         if cond.ndim == 2:  # raw wave -> mel (cfm.py:106-109)
-            cond = self.engine.mel(cond, frame_major=True)
+            cond = self.engine.mel(cond, frame_major=True, mel_spec_type=self.mel_spec.mel_spec_type)
             assert cond.shape[-1] == self.num_channels
         cond = cond.to(device=dev, dtype=torch.float32)
         batch, cond_seq_len = cond.shape[:2]
@@ -302,6 +308,8 @@ class F5HipCFM:
         duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)  # cfm.py:135-137
         duration = duration.clamp(max=max_duration)
         n = int(duration.amax())
+        if duplicate_test:  # cfm.py:141-143: a copy of the prompt placed right behind it
+            test_cond = torch.nn.functional.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
         cond = torch.nn.functional.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)  # cfm.py:145
         if no_ref_audio:
             cond = torch.zeros_like(cond)
@@ -314,10 +322,15 @@ class F5HipCFM:
                 torch.manual_seed(seed)
             y0.append(torch.randn(int(dur), self.num_channels, dtype=torch.float32))
         y0 = torch.nn.utils.rnn.pad_sequence(y0, padding_value=0, batch_first=True)
-        if use_epss:  # cfm.py:211-216 (t_start == 0)
+        t_start = 0
+        if duplicate_test:  # cfm.py:205-209: start the solve at t_inter from a noised copy of the prompt
+            t_start = t_inter
+            y0 = (1 - t_start) * y0.to(dev) + t_start * test_cond
+            steps = int(steps * (1 - t_start))
+        if t_start == 0 and use_epss:  # cfm.py:211-214
             t = get_epss_timesteps(steps)
         else:
-            t = torch.linspace(0, 1, steps + 1, dtype=torch.float32)
+            t = torch.linspace(t_start, 1, steps + 1, dtype=torch.float32)
         if sway_sampling_coef is not None:
             t = t + sway_sampling_coef * (torch.cos(torch.pi / 2 * t) - 1 + t)
         out, trajectory = self.engine.sample(cond, cond_mask, text, duration, use_mask, y0, t, cfg_strength,

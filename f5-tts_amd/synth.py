@@ -60,7 +60,7 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
     if cfg.backbone == "UNetT":  # reference src/f5_tts/model/backbones/unett.py:147-186 key layout: layers.{i}.{0..4}
         for i in range(cfg.depth):
             b = f"layers.{i}."
-            if i >= cfg.depth // 2:
+            if i >= cfg.depth // 2 and cfg.skip_connect_type == "concat":
                 sd[p + b + "0.weight"] = _normal(g, (D, 2 * D), 1.0 / math.sqrt(2 * D))  # skip_proj, no bias
             sd[p + b + "1.g"] = 1.0 + _normal(g, (D,), 0.05)
             linear(b + "2.to_q", inner, D)
@@ -72,6 +72,10 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
             linear(b + "4.ff.2", D, cfg.ff_inner, w_std=0.3 / math.sqrt(cfg.ff_inner))
         sd[p + "norm_out.g"] = 1.0 + _normal(g, (D,), 0.05)
         linear("proj_out", mel, D, w_std=0.04, b_std=0.02)
+        if cfg.qk_norm == "rms_norm":  # drawn last: the tensors above do not depend on the switch
+            for i in range(cfg.depth):
+                sd[p + f"layers.{i}.2.q_norm.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
+                sd[p + f"layers.{i}.2.k_norm.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
         return sd
     for i in range(cfg.depth):
         b = f"transformer_blocks.{i}."
@@ -84,6 +88,13 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
         linear(b + "ff.ff.2", D, cfg.ff_inner)
     linear("norm_out.linear", 2 * D, D, w_std=0.02, b_std=0.05)  # zero-init in the reference
     linear("proj_out", mel, D, w_std=0.04, b_std=0.02)  # zero-init in the reference
+    # optional variants: drawn last so the tensors above are bit-identical with or without them
+    if cfg.qk_norm == "rms_norm":
+        for i in range(cfg.depth):
+            sd[p + f"transformer_blocks.{i}.attn.q_norm.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
+            sd[p + f"transformer_blocks.{i}.attn.k_norm.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
+    if cfg.long_skip_connection:
+        sd[p + "long_skip_connection.weight"] = _normal(g, (D, 2 * D), 1.0 / math.sqrt(2 * D))
     return sd
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 2
+#define F5HIP_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -56,6 +56,14 @@ typedef struct f5hip_dit_config {
   int32_t conv_pos_kernel, conv_pos_groups;
   int32_t backbone;            /* 0 = DiT (F5-TTS, dit.py), 1 = UNetT (E2-TTS, reference src/f5_tts/model/backbones/unett.py:108-307:
                                   time embedding as a prepended token, x_transformers RMSNorm pre-norm, concat skip connections) */
+  /* optional constructor switches no shipped yaml enables (dit.py:181-189, unett.py:120-127); all 0 for the released models.
+   * qk_norm applies to both backbones (UNetT keys: layers.{i}.2.q_norm.weight). */
+  int32_t qk_norm;               /* 0 = None, 1 = "rms_norm": RMSNorm(dim_head, eps 1e-6) on q and k before rope (modules.py:402-409,493-496);
+                                    adds tensors ...attn.q_norm.weight / k_norm.weight [dim_head] per block */
+  int32_t long_skip_connection;  /* bool: x = Linear(2*dim -> dim, no bias)(cat(x_after_blocks, x_before_blocks)) (dit.py:228,354-365);
+                                    adds transformer.long_skip_connection.weight [dim, 2*dim] */
+  int32_t text_average_upsampling; /* bool: text_embedding_average_upsampling (dit.py:55-84,131-137); requires text_mask_padding */
+  int32_t skip_connect_type;     /* UNetT only (unett.py:127,289-295): 0 = "concat" (skip_proj Linear(2*dim -> dim)), 1 = "add", 2 = "none" */
 } f5hip_dit_config;
 
 /* Vocos (charactr/vocos-mel-24khz config.yaml; loader reference utils_infer.py:106-129). */
@@ -97,12 +105,16 @@ int f5hip_mark_all_loaded(f5hip_ctx* ctx);
 int f5hip_finalize_weights(f5hip_ctx* ctx);
 
 /* ---- mel front-end ---------------------------------------------------------------------------- */
-/* replaces: MelSpec.forward -> get_vocos_mel_spectrogram (reference src/f5_tts/model/modules.py:80-109,138-151):
- * reflect-pad n_fft/2, STFT(1024, hop 256, periodic hann), |.|, HTK mel filterbank [513->100], log(clamp 1e-5).
- * wav: device fp32 [batch, n_samples]; out: device fp32, frames = 1 + n_samples/256;
+/* replaces: MelSpec.forward (reference src/f5_tts/model/modules.py:138-151) for both mel_spec_type values:
+ *   mel_type 0 "vocos"   get_vocos_mel_spectrogram (modules.py:80-109): reflect-pad n_fft/2, STFT(1024, hop 256, periodic hann), |.|,
+ *                        HTK mel filterbank [513->100] (torchaudio, norm=None), log(clamp 1e-5); frames = 1 + n_samples/256
+ *   mel_type 1 "bigvgan" get_bigvgan_mel_spectrogram (modules.py:35-77): reflect-pad (n_fft-hop)/2 = 384, STFT without centring,
+ *                        sqrt(re^2+im^2+1e-9), slaney-scale slaney-normalised filterbank (librosa.filters.mel), log(clamp 1e-5);
+ *                        frames = n_samples/256 (n_samples >= 640)
+ * wav: device fp32 [batch, n_samples]; out: device fp32;
  * frame_major != 0 -> out[batch, frames, 100] (what CFM.sample consumes after its permute, cfm.py:107-108),
  * else out[batch, 100, frames] (what MelSpec.forward returns). */
-int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t n_samples, float* out, int frame_major, void* stream);
+int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t n_samples, float* out, int frame_major, int mel_type, void* stream);
 
 /* ---- sampler ----------------------------------------------------------------------------------- */
 /* replaces: CFM.sample from "duration" onwards (reference src/f5_tts/model/cfm.py:128-223) including the

@@ -92,6 +92,45 @@ def vocos_mel(wav: Tensor, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000) 
     return mel.clamp(min=1e-5).log()
 
 
+def slaney_mel_basis(sr=24000, n_fft=1024, n_mels=100, fmin=0.0, fmax=None) -> Tensor:
+    """``librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)`` with its defaults (htk=False, norm="slaney", float32) -> [n_mels, 1+n_fft/2].
+    librosa is a third-party dependency that is absent here and un-vendored in the reference (call site model/modules.py:50):
+    restated from its published algorithm — Slaney's Auditory-Toolbox mel scale (linear below 1 kHz at 200/3 Hz per mel,
+    logarithmic above with step ln(6.4)/27), triangular filters on the FFT bin centres, each scaled by 2 / (its bandwidth in Hz).
+    PARITY UNPINNED for this table: nothing in the reference tree holds its values."""
+    import numpy as np
+
+    if fmax is None:
+        fmax = sr / 2.0
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    mels = np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2)
+    mel_f = np.where(mels >= min_log_mel, min_log_hz * np.exp(logstep * (mels - min_log_mel)), f_sp * mels)
+    fftfreqs = np.arange(0, n_fft // 2 + 1) / (n_fft * (1.0 / sr))  # np.fft.rfftfreq(n_fft, 1 / sr)
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    w = np.zeros((n_mels, n_fft // 2 + 1), dtype=np.float32)
+    for i in range(n_mels):
+        w[i] = np.maximum(0, np.minimum(-ramps[i] / fdiff[i], ramps[i + 2] / fdiff[i + 1]))
+    w *= (2.0 / (mel_f[2: n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return torch.from_numpy(w)
+
+
+def bigvgan_mel(wav: Tensor, n_fft=1024, hop=256, win=1024, n_mels=100, sr=24000) -> Tensor:
+    """src/f5_tts/model/modules.py:35-77 (``mel_spec_type="bigvgan"``): reflect-pad (n_fft-hop)/2 on both sides, STFT without centring,
+    sqrt(re^2 + im^2 + 1e-9), slaney mel basis, log(clamp 1e-5).  wav [b, nw] -> [b, n_mels, nw // hop]."""
+    pad = (n_fft - hop) // 2
+    x = F.pad(wav.unsqueeze(1), (pad, pad), mode="reflect").squeeze(1)
+    spec = torch.stft(x, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=False, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True)
+    spec = torch.sqrt(torch.view_as_real(spec).pow(2).sum(-1) + 1e-9)
+    return torch.log(torch.clamp(torch.matmul(slaney_mel_basis(sr, n_fft, n_mels), spec), min=1e-5))
+
+
 # ---------------------------------------------------------------------------------------------
 # modules
 # ---------------------------------------------------------------------------------------------
@@ -140,8 +179,24 @@ def convnext_v2_block(sd: SD, pfx: str, x: Tensor) -> Tensor:
     return res + h
 
 
+def average_upsample_text_by_mask(text: Tensor, text_mask: Tensor, target_lens: Tensor) -> Tensor:
+    """src/f5_tts/model/backbones/dit.py:55-84 — spread the valid text tokens over the first ``target_lens[b]`` frames: token j is
+    repeated ``base`` times, the last ``remainder`` tokens ``base + 1`` times; everything behind is zero."""
+    out = torch.zeros_like(text)
+    for b in range(text.shape[0]):
+        valid = torch.nonzero(text_mask[b]).flatten()
+        tl, al = int(valid.numel()), int(target_lens[b])
+        if tl == 0 or al <= 0:
+            continue
+        base, rem = al // tl, al % tl
+        reps = torch.tensor([base + (1 if j >= tl - rem else 0) for j in range(tl)], dtype=torch.long)
+        idx = torch.repeat_interleave(torch.arange(tl), reps)[:al]
+        out[b, :al] = text[b, valid[idx]]
+    return out
+
+
 def text_embedding(sd: SD, cfg, text: Tensor, seq_len, drop_text: bool) -> Tensor:
-    """src/f5_tts/model/backbones/dit.py:86-139 (average_upsampling=False).
+    """src/f5_tts/model/backbones/dit.py:86-139.
     ``seq_len``: int (no mask, batch==1) or int64 [b] (per-sample valid length)."""
     text = text + 1
     valid = None
@@ -174,6 +229,9 @@ def text_embedding(sd: SD, cfg, text: Tensor, seq_len, drop_text: bool) -> Tenso
         else:
             for i in range(cfg.conv_layers):
                 h = convnext_v2_block(sd, f"transformer.text_embed.text_blocks.{i}.", h)
+    if getattr(cfg, "text_embedding_average_upsampling", False):  # dit.py:131-137 (requires text_mask_padding, dit.py:42-43)
+        tl = seq_len.long() if torch.is_tensor(seq_len) else torch.full((text.shape[0],), int(seq_len), dtype=torch.long)
+        h = average_upsample_text_by_mask(h, ~text_mask, tl)
     return h
 
 
@@ -226,12 +284,15 @@ def apply_rope(t: Tensor, freqs: Tensor) -> Tensor:
 
 
 def attention(sd: SD, cfg, pfx: str, x: Tensor, mask: Optional[Tensor], freqs: Tensor) -> Tensor:
-    """src/f5_tts/model/modules.py:471-556 (torch backend, qk_norm=None)."""
+    """src/f5_tts/model/modules.py:471-556 (torch backend; qk_norm None or "rms_norm")."""
     b, n, _ = x.shape
     hds, dh = cfg.heads, cfg.dim_head
     q = F.linear(x, sd[pfx + "to_q.weight"], sd[pfx + "to_q.bias"]).view(b, n, hds, dh).transpose(1, 2)
     k = F.linear(x, sd[pfx + "to_k.weight"], sd[pfx + "to_k.bias"]).view(b, n, hds, dh).transpose(1, 2)
     v = F.linear(x, sd[pfx + "to_v.weight"], sd[pfx + "to_v.bias"]).view(b, n, hds, dh).transpose(1, 2)
+    if getattr(cfg, "qk_norm", None) == "rms_norm":  # modules.py:402-409,493-496; RMSNorm :286-305 with eps 1e-6 over dim_head
+        q = q * torch.rsqrt(q.pow(2).mean(-1, keepdim=True) + 1e-6) * sd[pfx + "q_norm.weight"]
+        k = k * torch.rsqrt(k.pow(2).mean(-1, keepdim=True) + 1e-6) * sd[pfx + "k_norm.weight"]
     if cfg.pe_attn_head is not None:
         pn = cfg.pe_attn_head
         q = torch.cat((apply_rope(q[:, :pn], freqs), q[:, pn:]), dim=1)
@@ -279,10 +340,13 @@ def dit_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, tex
     m2 = torch.cat((mask, mask), dim=0) if mask is not None else None
     freqs = rotary_freqs(cfg.dim_head, n)
     hidden = [h]
+    residual = h  # dit.py:354-355
     for i in range(cfg.depth):
         h = dit_block(sd, cfg, i, h, t, m2, freqs)
         if return_hidden:
             hidden.append(h)
+    if getattr(cfg, "long_skip_connection", False):  # dit.py:228,364-365
+        h = F.linear(torch.cat((h, residual), dim=-1), sd["transformer.long_skip_connection.weight"])
     emb = F.linear(F.silu(t), sd["transformer.norm_out.linear.weight"], sd["transformer.norm_out.linear.bias"])
     scale, shift = torch.chunk(emb, 2, dim=1)  # NOTE (scale, shift) order: modules.py:344
     h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
@@ -330,10 +394,15 @@ def unett_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, t
     skips = []
     for i in range(cfg.depth):
         pfx = f"transformer.layers.{i}."
+        sct = getattr(cfg, "skip_connect_type", "concat")  # unett.py:127,289-295
         if i < cfg.depth // 2:
             skips.append(h)
         else:
-            h = F.linear(torch.cat((h, skips.pop()), dim=-1), sd[pfx + "0.weight"])
+            skip = skips.pop()
+            if sct == "concat":
+                h = F.linear(torch.cat((h, skip), dim=-1), sd[pfx + "0.weight"])
+            elif sct == "add":
+                h = h + skip
         h = attention(sd, cfg, pfx + "2.", x_rmsnorm(h, sd[pfx + "1.g"]), m2, freqs) + h
         f = F.linear(x_rmsnorm(h, sd[pfx + "3.g"]), sd[pfx + "4.ff.0.0.weight"], sd[pfx + "4.ff.0.0.bias"])
         f = F.linear(F.gelu(f, approximate="tanh"), sd[pfx + "4.ff.2.weight"], sd[pfx + "4.ff.2.bias"])
@@ -359,11 +428,12 @@ def make_noise(duration: Tensor, mel_dim: int, seed: Optional[int]) -> Tensor:
 def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optional[Tensor] = None, steps: int = 32,
                cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None, seed: Optional[int] = None,
                max_duration: int = 65536, use_epss: bool = True, edit_mask: Optional[Tensor] = None,
-               return_steps: bool = False, method: str = "euler"):
+               return_steps: bool = False, method: str = "euler", no_ref_audio: bool = False, duplicate_test: bool = False,
+               t_inter: float = 0.1, mel_spec_type: str = "vocos"):
     """src/f5_tts/model/cfm.py:83-229 with a DiT or UNetT backbone (cfg.backbone), with or without CFG, fixed-grid euler / midpoint.
     cond: wave [b, nw] or mel [b, n, mel]; text: int64 [b, nt] (already tokenised, -1 padded)."""
     if cond.ndim == 2:
-        cond = vocos_mel(cond).permute(0, 2, 1)
+        cond = (bigvgan_mel(cond) if mel_spec_type == "bigvgan" else vocos_mel(cond)).permute(0, 2, 1)
         assert cond.shape[-1] == cfg.mel_dim
     cond = cond.float()
     batch, cond_seq_len = cond.shape[:2]
@@ -377,7 +447,11 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
     duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration)
     duration = duration.clamp(max=max_duration)
     n = int(duration.amax())
+    if duplicate_test:  # cfm.py:141-143
+        test_cond = F.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
     cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+    if no_ref_audio:  # cfm.py:146-147
+        cond = torch.zeros_like(cond)
     cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False).unsqueeze(-1)
     step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))
     mask = lens_to_mask(duration) if batch > 1 else None
@@ -393,7 +467,12 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
     forward_cfg = unett_forward_cfg if unett else dit_forward_cfg
 
     y = make_noise(duration, cfg.mel_dim, seed)
-    t = time_grid(steps, sway_sampling_coef, use_epss)
+    t_start = 0.0
+    if duplicate_test:  # cfm.py:205-209: start from a noised copy of the prompt placed behind it, at t = t_inter
+        t_start = t_inter
+        y = (1 - t_start) * y + t_start * test_cond
+        steps = int(steps * (1 - t_start))
+    t = time_grid(steps, sway_sampling_coef, use_epss, t_start)
     traj = [y]
     vel = []
     def fn(ti, x):  # cfm.py:162-191

@@ -58,6 +58,25 @@ CASES = {
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)),
     "tiny_v1_nocfg_b2": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=2, nt=24, tseed=8, duration=[120, 97], lens=[41, 33],
                              pad_from=18, kw=dict(steps=6, cfg_strength=0.0, sway_sampling_coef=None, seed=9)),
+    # optional DiT constructor switches (dit.py:181-189), one at a time and all together on a ragged batch with the key-padding mask
+    "tiny_qknorm": dict(preset="tiny_qknorm", wseed=4, nw=256 * 30, wavseed=9, batch=1, nt=20, tseed=6, duration=100, lens=None,
+                        kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)),
+    "tiny_longskip": dict(preset="tiny_longskip", wseed=4, nw=256 * 30, wavseed=9, batch=1, nt=20, tseed=6, duration=100, lens=None,
+                          kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)),
+    "tiny_avgup": dict(preset="tiny_avgup", wseed=4, nw=256 * 30, wavseed=9, batch=1, nt=20, tseed=6, duration=100, lens=None,
+                       kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)),
+    "tiny_flags_ragged_b2": dict(preset="tiny_flags", wseed=4, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
+                                 pad_from=30, kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    # UNetT constructor switches (unett.py:120-127): skip_connect_type "add" / "none", qk_norm, key-padding mask
+    "tiny_unett_add_ragged_b2": dict(preset="tiny_unett_add", wseed=5, nw=256 * 50, wavseed=6, batch=2, nt=30, tseed=4, duration=[140, 111],
+                                     lens=[51, 40], pad_from=22, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
+    "tiny_unett_noskip": dict(preset="tiny_unett_noskip", wseed=5, nw=256 * 30, wavseed=6, batch=1, nt=20, tseed=4, duration=100, lens=None,
+                              kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
+    # corners of CFM.sample itself: duplicate_test / t_inter (cfm.py:141-143,205-209) and no_ref_audio (cfm.py:146-147)
+    "tiny_v1_duptest": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=1, nt=24, tseed=8, duration=120, lens=None,
+                            kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9, duplicate_test=True, t_inter=0.25)),
+    "tiny_v1_noref": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=1, nt=24, tseed=8, duration=120, lens=None,
+                          kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9, no_ref_audio=True)),
     "tiny_v1_b3_fixed": dict(preset="tiny", wseed=1, nw=256 * 30, wavseed=9, batch=3, nt=20, tseed=6, duration=96, lens=None,
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
@@ -103,7 +122,7 @@ def run_case(name, c, pins):
     d = (out - out_o).abs().max().item()
     dt = (traj - traj_o).abs().max().item()
     print(f"{name}: reference {t_ref:.1f}s  out {tuple(out.shape)}  oracle-vs-reference out {d:.2e} traj {dt:.2e}")
-    steps = c["kw"]["steps"]
+    steps = traj.shape[0] - 1  # duplicate_test shortens the solve (cfm.py:209)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), out=out.numpy(), traj_1=traj[1].numpy(),
                         traj_mid=traj[steps // 2].numpy(), traj_last=traj[-1].numpy())
     pins[name] = dict(case={k: v for k, v in c.items()}, oracle_vs_reference_out=d, oracle_vs_reference_traj=dt,
@@ -148,6 +167,21 @@ def pin_mel(pins):
     pins["mel_b2"] = dict(nw=256 * 37 + 100, wavseed=13, batch=2, oracle_vs_reference=d)
 
 
+def pin_mel_bigvgan(pins):
+    """get_bigvgan_mel_spectrogram of the reference (model/modules.py:35-77; librosa's filterbank through the shim) vs the oracle."""
+    ref_shims.install()
+    from f5_tts.model.modules import MelSpec
+
+    wav = synth.synth_wave(256 * 37 + 100, seed=14, batch=2)
+    kw = dict(MEL_KW, mel_spec_type="bigvgan")
+    ref = MelSpec(**kw)(wav)
+    d = (ref - O.bigvgan_mel(wav)).abs().max().item()
+    print(f"bigvgan mel: reference MelSpec (librosa filterbank restated) vs oracle {d:.2e}")
+    np.savez_compressed(os.path.join(GOLD, "mel_bigvgan_b2.npz"), mel=ref.numpy())
+    pins["mel_bigvgan_b2"] = dict(nw=256 * 37 + 100, wavseed=14, batch=2, oracle_vs_reference=d,
+                                  note="librosa absent: slaney filterbank restated (oracle/f5_oracle.py::slaney_mel_basis), table unpinned")
+
+
 def golden_vocos(pins):
     """Vocos has no source in the reference tree: the golden comes from the ORACLE restatement (parity unpinned)."""
     vcfg = config.VOCOS_TINY
@@ -170,6 +204,7 @@ def main():
     torch.manual_seed(0)
     pin_stft(pins)
     pin_mel(pins)
+    pin_mel_bigvgan(pins)
     golden_vocos(pins)
     only = set(filter(None, args.only.split(",")))
     for name, c in CASES.items():

@@ -20,7 +20,9 @@ What the shims restate (un-vendored third-party arithmetic):
                               ``runtime/triton_trtllm/model_repo_f5_tts/f5_tts/1/f5_tts_trtllm.py:232-237``.
 * ``torchaudio.transforms.MelSpectrogram``  torch.stft + HTK triangular filterbank
                               (call site ``model/modules.py:91-101``).
-* ``librosa.filters.mel``, ``rjieba``, ``pypinyin``  import-time stubs only.
+* ``librosa.filters.mel``     slaney-scale, slaney-normalised triangular filterbank (bigvgan-type mel only, call site
+                              ``model/modules.py:50``), delegated to ``oracle/f5_oracle.py::slaney_mel_basis``.
+* ``rjieba``, ``pypinyin``    import-time stubs only.
 
 These restatements have no golden vectors in the reference (it has no tests):
 parity of those pieces is "unpinned by the reference" and anchored on the
@@ -202,10 +204,14 @@ def install():
     if "librosa" not in sys.modules:
         lb = mod("librosa")
 
-        def _no_librosa(*a, **k):  # bigvgan mel only (config 5) — source absent, see DESIGN.md
-            raise NotImplementedError("librosa.filters.mel is not available in this environment")
+        def _slaney_mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, **_k):
+            # bigvgan-type mel only (model/modules.py:50).  librosa is absent: the filterbank comes from the restatement of its published
+            # algorithm in oracle/f5_oracle.py (parity unpinned for the table; everything around it is the reference's own code).
+            from oracle.f5_oracle import slaney_mel_basis
 
-        lf = mod("librosa.filters", mel=_no_librosa)
+            return slaney_mel_basis(sr, n_fft, n_mels, fmin, fmax).numpy()
+
+        lf = mod("librosa.filters", mel=_slaney_mel)
         lb.filters = lf
     if "rjieba" not in sys.modules:
         mod("rjieba", cut=lambda s: [s])

@@ -67,6 +67,8 @@ def test_sample_matches_reference_golden(engines, name, prec, tol):
     out, traj = model.sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
     g = gold(name)
     steps = c["kw"]["steps"]
+    if c["kw"].get("duplicate_test"):  # the solve starts at t_inter with proportionally fewer steps (cfm.py:205-209)
+        steps = int(steps * (1 - c["kw"]["t_inter"]))
     assert tuple(out.shape) == g["out"].shape and traj.shape[0] == steps + 1
     assert tol <= MEL_TOL or prec == "fp16"
     assert maxerr(out, g["out"]) < tol
@@ -82,6 +84,29 @@ def test_mel_matches_reference_golden(engines):
     assert maxerr(m, gold("mel_b2")["mel"]) < 1e-4
     mf = eng.mel(wav.cuda(), frame_major=True)
     assert torch.equal(mf.permute(0, 2, 1), m)
+
+
+def test_bigvgan_mel_matches_reference_golden(engines):
+    """mel_spec_type="bigvgan" (reference modules.py:35-77): no centring, 384-sample reflect padding, sqrt(.+1e-9), slaney filterbank."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    eng = engines("tiny", 1)
+    wav = synth.synth_wave(256 * 37 + 100, seed=14, batch=2)
+    g = gold("mel_bigvgan_b2")["mel"]
+    m = eng.mel(wav.cuda(), mel_spec_type="bigvgan")
+    assert tuple(m.shape) == g.shape == (2, 100, 37)
+    assert maxerr(m, g) < 1e-4
+    assert torch.equal(eng.mel(wav.cuda(), frame_major=True, mel_spec_type="bigvgan").permute(0, 2, 1), m)
+    assert maxerr(F5HipCFM(eng, mel_spec_type="bigvgan").mel_spec(wav.cuda()), g) < 1e-4  # the model.mel_spec callable callers use
+    for nw in (640, 1024, 256 * 20 + 255):
+        w = synth.synth_wave(nw, seed=nw)
+        ref = O.bigvgan_mel(w)
+        out = eng.mel(w.cuda(), mel_spec_type="bigvgan")
+        assert out.shape == ref.shape == (1, 100, nw // 256) and maxerr(out, ref) < 1e-4
+    with pytest.raises(ValueError):
+        eng.mel(torch.zeros(1, 300).cuda(), mel_spec_type="bigvgan")  # shorter than the reflect padding
+    with pytest.raises(AssertionError):
+        eng.mel(wav.cuda(), mel_spec_type="hifigan")  # modules.py:127
 
 
 @pytest.mark.parametrize("nw", [513, 1024, 256 * 20, 256 * 20 + 255, 24000 * 3 + 17])

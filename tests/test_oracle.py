@@ -30,7 +30,7 @@ def test_oracle_matches_reference_golden(name):
     sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
     out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, method=c.get("method", "euler"), **c["kw"])
     g = gold(name)
-    steps = c["kw"]["steps"]
+    steps = traj.shape[0] - 1  # duplicate_test shortens the solve (cfm.py:209)
     assert np.abs(out.numpy() - g["out"]).max() < TOL
     assert np.abs(traj[1].numpy() - g["traj_1"]).max() < TOL
     assert np.abs(traj[steps // 2].numpy() - g["traj_mid"]).max() < TOL
@@ -50,6 +50,18 @@ def test_mel_matches_reference_golden():
     mel = O.vocos_mel(wav)
     assert mel.shape == (2, 100, 1 + (256 * 37 + 100) // 256)
     assert np.abs(mel.numpy() - gold("mel_b2")["mel"]).max() < 1e-5
+
+
+def test_bigvgan_mel_matches_reference_golden():
+    """mel_spec_type="bigvgan" (modules.py:35-77); the golden is the reference's function over the restated slaney filterbank."""
+    wav = synth.synth_wave(256 * 37 + 100, seed=14, batch=2)
+    mel = O.bigvgan_mel(wav)
+    assert mel.shape == (2, 100, 37)
+    assert np.abs(mel.numpy() - gold("mel_bigvgan_b2")["mel"]).max() < 1e-5
+    fb = O.slaney_mel_basis()
+    # slaney normalisation: every triangle has (almost) unit area in Hz, i.e. its weights sum to n_fft / sr
+    assert fb.shape == (100, 513) and float(fb.min()) == 0.0
+    assert np.allclose(fb.sum(1).numpy()[1:-1], 1024 / 24000, rtol=0.12)
 
 
 def test_istft_semantics_vs_reference_conv_istft():
