@@ -47,6 +47,10 @@ class DiTConfig:
 
     def arch_kwargs(self) -> dict:
         """kwargs accepted by the reference ``DiT(**model_cfg, text_num_embeds=..., mel_dim=...)`` / ``UNetT(...)``."""
+        if self.backbone == "MMDiT":  # mmdit.py:94-109: text_dim == dim, no conv text blocks, rope on all heads
+            return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_mult=self.ff_mult,
+                        text_mask_padding=self.text_mask_padding, qk_norm=self.qk_norm, attn_mask_enabled=self.attn_mask_enabled,
+                        mel_dim=self.mel_dim, text_num_embeds=self.text_num_embeds)
         if self.backbone == "UNetT":
             return dict(dim=self.dim, depth=self.depth, heads=self.heads, dim_head=self.dim_head, ff_mult=self.ff_mult,
                         text_dim=self.text_dim, text_mask_padding=self.text_mask_padding, conv_layers=self.conv_layers,
@@ -81,6 +85,12 @@ F5TTS_V1_BASE = DiTConfig()  # api/cli default (reference src/f5_tts/api.py:26)
 E2TTS_BASE = DiTConfig(dim=1024, depth=24, heads=16, dim_head=64, ff_mult=4, text_dim=N_MEL_CHANNELS, conv_layers=0,
                        text_mask_padding=False, pe_attn_head=1, backbone="UNetT")
 F5TTS_BASE = replace(F5TTS_V1_BASE, text_mask_padding=False, pe_attn_head=1)
+# the Small models (configs/F5TTS_v1_Small.yaml:25-36, F5TTS_Small.yaml:25-35, E2TTS_Small.yaml:25-32): dim 768 = 12 heads x 64,
+# i.e. 48 channels per group in the grouped conv-position embedding
+F5TTS_V1_SMALL = DiTConfig(dim=768, depth=18, heads=12, dim_head=64, ff_mult=2, text_dim=512, conv_layers=4)
+F5TTS_SMALL = replace(F5TTS_V1_SMALL, text_mask_padding=False, pe_attn_head=1)
+E2TTS_SMALL = DiTConfig(dim=768, depth=20, heads=12, dim_head=64, ff_mult=4, text_dim=N_MEL_CHANNELS, conv_layers=0,
+                        text_mask_padding=False, pe_attn_head=1, backbone="UNetT")
 # reduced sizes used by the parity tests (same code path, seconds on the CPU oracle)
 DIT_TINY = DiTConfig(dim=256, depth=2, heads=4, dim_head=64, ff_mult=2, text_dim=128, conv_layers=2,
                      text_num_embeds=255)
@@ -90,6 +100,12 @@ UNETT_TINY = DiTConfig(dim=256, depth=4, heads=4, dim_head=64, ff_mult=4, text_d
 # every optional DiT switch at once (qk RMSNorm, long skip, average upsampling, key-padding mask)
 DIT_TINY_FLAGS = replace(DIT_TINY, qk_norm="rms_norm", long_skip_connection=True, text_embedding_average_upsampling=True,
                          attn_mask_enabled=True)
+# MMDiT (reference backbones/mmdit.py; no yaml ships, count_params_gflops.py:19 sketches dim 512 / depth 16 / heads 16 / ff_mult 2):
+# a second token stream for the text, joint attention, text_dim == dim
+MMDIT_TINY = DiTConfig(dim=256, depth=3, heads=4, dim_head=64, ff_mult=2, text_dim=256, conv_layers=0, text_num_embeds=255,
+                       backbone="MMDiT")
+MMDIT_SMALL = DiTConfig(dim=512, depth=16, heads=16, dim_head=32, ff_mult=2, text_dim=512, conv_layers=0, text_num_embeds=2545,
+                        backbone="MMDiT")
 VOCOS_MEL_24K = VocosConfig()
 VOCOS_TINY = VocosConfig(dim=128, intermediate_dim=384, num_layers=2)
 
@@ -100,10 +116,17 @@ PRESETS = {
     "tiny_v0": DIT_TINY_V0,
     "E2TTS_Base": E2TTS_BASE,
     "tiny_unett": UNETT_TINY,
+    "F5TTS_v1_Small": F5TTS_V1_SMALL,
+    "F5TTS_Small": F5TTS_SMALL,
+    "E2TTS_Small": E2TTS_SMALL,
+    "tiny48": replace(DIT_TINY, dim=768, heads=12),  # 48 channels per conv group (768 / 16), like the Small models, at depth 2
     "tiny_flags": DIT_TINY_FLAGS,
     "tiny_qknorm": replace(DIT_TINY, qk_norm="rms_norm"),
     "tiny_longskip": replace(DIT_TINY, long_skip_connection=True),
     "tiny_avgup": replace(DIT_TINY, text_embedding_average_upsampling=True),
     "tiny_unett_add": replace(UNETT_TINY, skip_connect_type="add", qk_norm="rms_norm", attn_mask_enabled=True),
     "tiny_unett_noskip": replace(UNETT_TINY, skip_connect_type="none"),
+    "tiny_mmdit": MMDIT_TINY,
+    "tiny_mmdit_mask": replace(MMDIT_TINY, attn_mask_enabled=True, qk_norm="rms_norm"),
+    "tiny_mmdit_nopad": replace(MMDIT_TINY, text_mask_padding=False),
 }

@@ -1058,7 +1058,7 @@ int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int d
   if (dc->dim % 4 || dc->text_dim % 4 || dc->mel_dim % 4 || dc->ff_inner % 8 || dc->dim % 8) return bad("dim/text_dim/mel_dim/ff_inner alignment");
   if (dc->conv_pos_groups <= 0 || dc->dim % dc->conv_pos_groups) return bad("conv_pos_groups must divide dim");
   const int cpg = dc->dim / dc->conv_pos_groups;
-  if (cpg != 16 && cpg != 32 && cpg != 64) return bad("dim/conv_pos_groups must be 16, 32 or 64");
+  if (cpg != 16 && cpg != 32 && cpg != 48 && cpg != 64) return bad("dim/conv_pos_groups must be 16, 32, 48 or 64");
   if (!(dc->conv_pos_kernel & 1)) return bad("conv_pos_kernel must be odd");
   if (dc->mel_dim > 256) return bad("mel_dim must be <= 256");
   if (dc->backbone != 0 && dc->backbone != 1) return bad("backbone must be 0 (DiT) or 1 (UNetT)");

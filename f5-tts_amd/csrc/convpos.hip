@@ -191,6 +191,7 @@ hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* w
   switch (cpg) {
     case 16: return launch_cpg<16>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
     case 32: return launch_cpg<32>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
+    case 48: return launch_cpg<48>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);  // dim 768 (the Small models)
     case 64: return launch_cpg<64>(op, x, w32, whi, wlo, bias, rowvalid, residual, S, n, D, groups, K, out, s, out_n, out_off);
     default: return hipErrorInvalidValue;
   }
@@ -211,5 +212,6 @@ hipError_t init_convpos_kernels() {
   hipError_t e;
   if ((e = set_attrs_cpg<16>()) != hipSuccess) return e;
   if ((e = set_attrs_cpg<32>()) != hipSuccess) return e;
+  if ((e = set_attrs_cpg<48>()) != hipSuccess) return e;
   return set_attrs_cpg<64>();
 }

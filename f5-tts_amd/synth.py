@@ -36,6 +36,8 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
         sd[p + name + ".weight"] = _normal(g, (out_f, in_f), w_std if w_std is not None else 1.0 / math.sqrt(in_f))
         sd[p + name + ".bias"] = _normal(g, (out_f,), b_std)
 
+    if cfg.backbone == "MMDiT":
+        return _synth_mmdit(cfg, g, sd, linear)
     linear("time_embed.time_mlp.0", D, 256)
     linear("time_embed.time_mlp.2", D, D)
     sd[p + "text_embed.text_embed.weight"] = _normal(g, (cfg.text_num_embeds + 1, T), 1.0)
@@ -95,6 +97,44 @@ def synth_dit_state_dict(cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tenso
             sd[p + f"transformer_blocks.{i}.attn.k_norm.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
     if cfg.long_skip_connection:
         sd[p + "long_skip_connection.weight"] = _normal(g, (D, 2 * D), 1.0 / math.sqrt(2 * D))
+    return sd
+
+
+def _synth_mmdit(cfg: DiTConfig, g: torch.Generator, sd: Dict[str, torch.Tensor], linear) -> Dict[str, torch.Tensor]:
+    """MMDiT key layout (reference src/f5_tts/model/backbones/mmdit.py:112-134, modules.py:773-814): per block attn_norm_c / attn_norm_x,
+    attn.{to_q,to_k,to_v,to_q_c,to_k_c,to_v_c,to_out.0,to_out_c}, ff_c, ff_x; the last block is context_pre_only (AdaLayerNorm_Final for
+    the text stream, no to_out_c / ff_c).  The zero-initialised tensors (mmdit.py:160-171) get non-zero values, as for the DiT."""
+    D, mel, p = cfg.dim, cfg.mel_dim, "transformer."
+    inner = cfg.heads * cfg.dim_head
+    linear("time_embed.time_mlp.0", D, 256)
+    linear("time_embed.time_mlp.2", D, D)
+    sd[p + "text_embed.text_embed.weight"] = _normal(g, (cfg.text_num_embeds + 1, D), 1.0)
+    linear("audio_embed.linear", D, 2 * mel)
+    cpg = D // cfg.conv_pos_groups
+    for j in (0, 2):
+        b = f"audio_embed.conv_pos_embed.conv1d.{j}."
+        sd[p + b + "weight"] = _normal(g, (D, cpg, cfg.conv_pos_kernel), 1.0 / math.sqrt(cpg * cfg.conv_pos_kernel))
+        sd[p + b + "bias"] = _normal(g, (D,), 0.02)
+    sd[p + "rotary_embed.inv_freq"] = 1.0 / (10000.0 ** (torch.arange(0, cfg.dim_head, 2).float() / cfg.dim_head))
+    for i in range(cfg.depth):
+        b = f"transformer_blocks.{i}."
+        last = i == cfg.depth - 1
+        linear(b + "attn_norm_c.linear", (2 if last else 6) * D, D, w_std=0.02, b_std=0.05)
+        linear(b + "attn_norm_x.linear", 6 * D, D, w_std=0.02, b_std=0.05)
+        for name in ("to_q", "to_k", "to_v", "to_q_c", "to_k_c", "to_v_c"):
+            linear(b + "attn." + name, inner, D)
+        linear(b + "attn.to_out.0", D, inner)
+        if not last:
+            linear(b + "attn.to_out_c", D, inner)
+            linear(b + "ff_c.ff.0.0", cfg.ff_inner, D)
+            linear(b + "ff_c.ff.2", D, cfg.ff_inner)
+        linear(b + "ff_x.ff.0.0", cfg.ff_inner, D)
+        linear(b + "ff_x.ff.2", D, cfg.ff_inner)
+        if cfg.qk_norm == "rms_norm":
+            for name in ("q_norm", "k_norm", "c_q_norm", "c_k_norm"):
+                sd[p + b + f"attn.{name}.weight"] = 1.0 + _normal(g, (cfg.dim_head,), 0.1)
+    linear("norm_out.linear", 2 * D, D, w_std=0.02, b_std=0.05)
+    linear("proj_out", mel, D, w_std=0.04, b_std=0.02)
     return sd
 
 

@@ -239,9 +239,9 @@ def mish(x: Tensor) -> Tensor:
     return x * torch.tanh(F.softplus(x))
 
 
-def conv_position_embedding(sd: SD, cfg, x: Tensor, mask: Optional[Tensor]) -> Tensor:
+def conv_position_embedding(sd: SD, cfg, x: Tensor, mask: Optional[Tensor], prefix: str = "transformer.input_embed.conv_pos_embed.") -> Tensor:
     """src/f5_tts/model/modules.py:187-201."""
-    pfx = "transformer.input_embed.conv_pos_embed.conv1d."
+    pfx = prefix + "conv1d."
     k, g = cfg.conv_pos_kernel, cfg.conv_pos_groups
     m = mask.unsqueeze(1) if mask is not None else None
     h = x.permute(0, 2, 1)
@@ -412,6 +412,116 @@ def unett_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, t
 
 
 # ---------------------------------------------------------------------------------------------
+# MMDiT backbone (SD3-style two-stream blocks with joint attention): src/f5_tts/model/backbones/mmdit.py
+# ---------------------------------------------------------------------------------------------
+def mmdit_text_embedding(sd: SD, cfg, text: Tensor, drop_text: bool) -> Tensor:
+    """mmdit.py:43-66: +1, embed (dim = model dim), absolute sinusoid positions 0..nt-1 (clipped to 1023), padding rows zeroed.
+    The text keeps its own length nt — it is a second token stream, not upsampled to the frame count."""
+    text = text + 1
+    text_mask = text == 0
+    if drop_text:
+        text = torch.zeros_like(text)
+    h = F.embedding(text, sd["transformer.text_embed.text_embed.weight"])
+    pos = torch.arange(text.shape[1]).clamp(max=1023)  # get_pos_embed_indices(start 0, max_pos 1024), modules.py:221-230
+    h = h + precompute_freqs_cis(cfg.dim, 1024)[pos]
+    if cfg.text_mask_padding:
+        h = h.masked_fill(text_mask.unsqueeze(-1), 0.0)
+    return h
+
+
+def _ada6(sd: SD, pfx: str, h: Tensor, t: Tensor):
+    """AdaLayerNorm (modules.py:312-326): modulated LayerNorm + the four values the block uses later."""
+    emb = F.linear(F.silu(t), sd[pfx + "linear.weight"], sd[pfx + "linear.bias"])
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = torch.chunk(emb, 6, dim=1)
+    return (F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale_msa[:, None]) + shift_msa[:, None], gate_msa, shift_mlp, scale_mlp,
+            gate_mlp)
+
+
+def _ff(sd: SD, pfx: str, h: Tensor) -> Tensor:
+    """FeedForward (modules.py:353-364), tanh-GELU."""
+    h = F.gelu(F.linear(h, sd[pfx + "ff.0.0.weight"], sd[pfx + "ff.0.0.bias"]), approximate="tanh")
+    return F.linear(h, sd[pfx + "ff.2.weight"], sd[pfx + "ff.2.bias"])
+
+
+def mmdit_joint_attention(sd: SD, cfg, pfx: str, x: Tensor, c: Tensor, mask: Optional[Tensor], c_mask: Tensor, freqs_x: Tensor,
+                          freqs_c: Tensor, last: bool):
+    """JointAttnProcessor.__call__ (modules.py:581-705, torch backend): both streams are projected with their own weights, rotated with
+    their own positions (each from 0), concatenated along the sequence ([audio | text]) for ONE softmax attention, then split again."""
+    b, n, _ = x.shape
+    nt = c.shape[1]
+    hds, dh = cfg.heads, cfg.dim_head
+
+    def proj(h, name, length):
+        return F.linear(h, sd[pfx + name + ".weight"], sd[pfx + name + ".bias"]).view(b, length, hds, dh).transpose(1, 2)
+
+    q, k, v = proj(x, "to_q", n), proj(x, "to_k", n), proj(x, "to_v", n)
+    cq, ck, cv = proj(c, "to_q_c", nt), proj(c, "to_k_c", nt), proj(c, "to_v_c", nt)
+    if getattr(cfg, "qk_norm", None) == "rms_norm":  # modules.py:616-624
+        def rms(h, name):
+            return h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-6) * sd[pfx + name + ".weight"]
+        q, k, cq, ck = rms(q, "q_norm"), rms(k, "k_norm"), rms(cq, "c_q_norm"), rms(ck, "c_k_norm")
+    q, k = apply_rope(q, freqs_x), apply_rope(k, freqs_x)
+    cq, ck = apply_rope(cq, freqs_c), apply_rope(ck, freqs_c)
+    q, k, v = torch.cat((q, cq), dim=2), torch.cat((k, ck), dim=2), torch.cat((v, cv), dim=2)
+    attn_mask = None
+    if cfg.attn_mask_enabled and mask is not None:  # modules.py:643-657: audio key-padding mask + text mask
+        attn_mask = torch.cat((mask, c_mask), dim=1)[:, None, None, :].expand(b, hds, n + nt, n + nt)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, dropout_p=0.0, is_causal=False)
+    o = o.transpose(1, 2).reshape(b, n + nt, hds * dh)
+    ox, oc = o[:, :n], o[:, n:]
+    ox = F.linear(ox, sd[pfx + "to_out.0.weight"], sd[pfx + "to_out.0.bias"])
+    if not last:
+        oc = F.linear(oc, sd[pfx + "to_out_c.weight"], sd[pfx + "to_out_c.bias"])
+    if mask is not None:
+        ox = ox.masked_fill(~mask.unsqueeze(-1), 0.0)
+    oc = oc.masked_fill(~c_mask.unsqueeze(-1), 0.0)
+    return ox, oc
+
+
+def mmdit_forward_cfg(sd: SD, cfg, x: Tensor, cond: Tensor, text_cond: Tensor, text_uncond: Tensor, time: Tensor,
+                      mask: Optional[Tensor], c_mask: Tensor):
+    """mmdit.py:213-262 with cfg_infer=True, cache=True -> [2b, n, mel].  ``c_mask`` = (text + 1) != 0 (mmdit.py:232)."""
+    b, n = x.shape[0], x.shape[1]
+    if time.ndim == 0:
+        time = time.repeat(b)
+    t = timestep_embedding(sd, time)
+
+    def audio_embed(drop_audio_cond):  # AudioEmbedding.forward (mmdit.py:79-85); conv_pos_embed is called WITHOUT a mask
+        cd = torch.zeros_like(cond) if drop_audio_cond else cond
+        h = F.linear(torch.cat((x, cd), dim=-1), sd["transformer.audio_embed.linear.weight"], sd["transformer.audio_embed.linear.bias"])
+        return conv_position_embedding(sd, cfg, h, None, prefix="transformer.audio_embed.conv_pos_embed.") + h
+
+    h = torch.cat((audio_embed(False), audio_embed(True)), dim=0)
+    c = torch.cat((text_cond, text_uncond), dim=0)
+    t = torch.cat((t, t), dim=0)
+    m2 = torch.cat((mask, mask), dim=0) if mask is not None else None
+    cm2 = torch.cat((c_mask, c_mask), dim=0)
+    freqs_x, freqs_c = rotary_freqs(cfg.dim_head, n), rotary_freqs(cfg.dim_head, c.shape[1])
+    for i in range(cfg.depth):  # MMDiTBlock.forward (modules.py:816-845)
+        pfx = f"transformer.transformer_blocks.{i}."
+        last = i == cfg.depth - 1  # context_pre_only (mmdit.py:118)
+        if last:
+            emb = F.linear(F.silu(t), sd[pfx + "attn_norm_c.linear.weight"], sd[pfx + "attn_norm_c.linear.bias"])
+            sc, sh = torch.chunk(emb, 2, dim=1)  # AdaLayerNorm_Final: (scale, shift)
+            norm_c = F.layer_norm(c, (c.shape[-1],), eps=1e-6) * (1 + sc)[:, None, :] + sh[:, None, :]
+        else:
+            norm_c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = _ada6(sd, pfx + "attn_norm_c.", c, t)
+        norm_x, x_gate_msa, x_shift_mlp, x_scale_mlp, x_gate_mlp = _ada6(sd, pfx + "attn_norm_x.", h, t)
+        ox, oc = mmdit_joint_attention(sd, cfg, pfx + "attn.", norm_x, norm_c, m2, cm2, freqs_x, freqs_c, last)
+        if not last:
+            c = c + c_gate_msa.unsqueeze(1) * oc
+            nc = F.layer_norm(c, (c.shape[-1],), eps=1e-6) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+            c = c + c_gate_mlp.unsqueeze(1) * _ff(sd, pfx + "ff_c.", nc)
+        h = h + x_gate_msa.unsqueeze(1) * ox
+        nx = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + x_scale_mlp[:, None]) + x_shift_mlp[:, None]
+        h = h + x_gate_mlp.unsqueeze(1) * _ff(sd, pfx + "ff_x.", nx)
+    emb = F.linear(F.silu(t), sd["transformer.norm_out.linear.weight"], sd["transformer.norm_out.linear.bias"])
+    scale, shift = torch.chunk(emb, 2, dim=1)
+    h = F.layer_norm(h, (h.shape[-1],), eps=1e-6) * (1 + scale)[:, None, :] + shift[:, None, :]
+    return F.linear(h, sd["transformer.proj_out.weight"], sd["transformer.proj_out.bias"])
+
+
+# ---------------------------------------------------------------------------------------------
 # sampler
 # ---------------------------------------------------------------------------------------------
 def make_noise(duration: Tensor, mel_dim: int, seed: Optional[int]) -> Tensor:
@@ -457,7 +567,12 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
     mask = lens_to_mask(duration) if batch > 1 else None
 
     unett = getattr(cfg, "backbone", "DiT") == "UNetT"
-    if unett:  # unett.py:218-228: seq_len is the padded frame count for every sample
+    mmdit = getattr(cfg, "backbone", "DiT") == "MMDiT"
+    if mmdit:  # mmdit.py:190-206: the text stream keeps its own length
+        text_cond = mmdit_text_embedding(sd, cfg, text, drop_text=False)
+        text_uncond = mmdit_text_embedding(sd, cfg, text, drop_text=True)
+        c_mask = (text + 1) != 0  # mmdit.py:232
+    elif unett:  # unett.py:218-228: seq_len is the padded frame count for every sample
         text_cond = unett_text_embedding(sd, cfg, text, n, drop_text=False)
         text_uncond = unett_text_embedding(sd, cfg, text, n, drop_text=True)
     else:
@@ -465,6 +580,9 @@ def cfm_sample(sd: SD, cfg, cond: Tensor, text: Tensor, duration, *, lens: Optio
         text_cond = text_embedding(sd, cfg, text, seq_len, drop_text=False)
         text_uncond = text_embedding(sd, cfg, text, seq_len, drop_text=True)
     forward_cfg = unett_forward_cfg if unett else dit_forward_cfg
+    if mmdit:
+        def forward_cfg(sd_, cfg_, x_, sc_, tc_, tu_, ti_, mask_):
+            return mmdit_forward_cfg(sd_, cfg_, x_, sc_, tc_, tu_, ti_, mask_, c_mask)
 
     y = make_noise(duration, cfg.mel_dim, seed)
     t_start = 0.0

@@ -72,6 +72,18 @@ CASES = {
                                      lens=[51, 40], pad_from=22, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
     "tiny_unett_noskip": dict(preset="tiny_unett_noskip", wseed=5, nw=256 * 30, wavseed=6, batch=1, nt=20, tseed=4, duration=100, lens=None,
                               kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)),
+    # MMDiT backbone (reference backbones/mmdit.py): two token streams with joint attention
+    "tiny_mmdit_nfe6": dict(preset="tiny_mmdit", wseed=6, nw=256 * 40, wavseed=7, batch=1, nt=24, tseed=8, duration=120, lens=None,
+                            kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)),
+    "tiny_mmdit_ragged_b2": dict(preset="tiny_mmdit", wseed=6, nw=256 * 40, wavseed=7, batch=2, nt=24, tseed=8, duration=[120, 97], lens=[41, 33],
+                                 pad_from=18, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)),
+    "tiny_mmdit_mask_ragged_b2": dict(preset="tiny_mmdit_mask", wseed=6, nw=256 * 40, wavseed=7, batch=2, nt=24, tseed=8, duration=[120, 97],
+                                      lens=[41, 33], pad_from=18, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9)),
+    "tiny_mmdit_nopad_nocfg_b2": dict(preset="tiny_mmdit_nopad", wseed=6, nw=256 * 40, wavseed=7, batch=2, nt=24, tseed=8, duration=[120, 97],
+                                      lens=[41, 33], pad_from=18, kw=dict(steps=4, cfg_strength=0.0, sway_sampling_coef=None, seed=9)),
+    # 48 channels per conv-position group (dim 768 / 16 groups in the Small models)
+    "tiny48_ragged_b2": dict(preset="tiny48", wseed=7, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
+                             pad_from=30, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
     # corners of CFM.sample itself: duplicate_test / t_inter (cfm.py:141-143,205-209) and no_ref_audio (cfm.py:146-147)
     "tiny_v1_duptest": dict(preset="tiny", wseed=1, nw=256 * 40, wavseed=7, batch=1, nt=24, tseed=8, duration=120, lens=None,
                             kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=9, duplicate_test=True, t_inter=0.25)),
@@ -81,6 +93,11 @@ CASES = {
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
 FULL_CASES = {
+    # the Small models at full width/depth on a shorter utterance (2.1 s prompt, 500 frames) to keep the fixtures small
+    "small_v1": dict(preset="F5TTS_v1_Small", wseed=0, nw=256 * 200, wavseed=0, batch=1, nt=80, tseed=0, duration=500, lens=None,
+                     kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    "small_e2": dict(preset="E2TTS_Small", wseed=0, nw=256 * 200, wavseed=0, batch=1, nt=80, tseed=0, duration=500, lens=None,
+                     kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[4] backbone at full size: E2-TTS Base (UNetT, depth 24, ff_mult 4), same prompt/duration as config 1
     "e2_base_cfg5": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
@@ -103,7 +120,7 @@ def case_inputs(c):
 
 def build_reference(cfg, sd, method="euler"):
     CFM, DiT, UNetT = ref_shims.reference_classes()
-    backbone = UNetT if cfg.backbone == "UNetT" else DiT
+    backbone = {"UNetT": UNetT, "MMDiT": ref_shims.reference_mmdit()}.get(cfg.backbone, DiT)
     model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method=method))
     model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
     return model.eval()

@@ -226,7 +226,7 @@ def install():
             pkg.__path__ = [path]
             sys.modules[name] = pkg
     for sub in ("f5_tts.model.utils", "f5_tts.model.modules", "f5_tts.model.backbones.dit",
-                "f5_tts.model.backbones.unett", "f5_tts.model.cfm"):
+                "f5_tts.model.backbones.unett", "f5_tts.model.backbones.mmdit", "f5_tts.model.cfm"):
         importlib.import_module(sub)
 
 
@@ -238,6 +238,14 @@ def reference_classes():
     from f5_tts.model.cfm import CFM
 
     return CFM, DiT, UNetT
+
+
+def reference_mmdit():
+    """The reference's own MMDiT class (src/f5_tts/model/backbones/mmdit.py)."""
+    install()
+    from f5_tts.model.backbones.mmdit import MMDiT
+
+    return MMDiT
 
 
 def reference_conv_stft():

@@ -328,6 +328,27 @@ def test_full_size_e2_unett_golden():
         eng.close()
 
 
+@pytest.mark.parametrize("name", ["small_v1", "small_e2"])
+def test_small_models_golden(name):
+    """The shipped Small configs (dim 768 = 12 heads, 48 channels per conv-position group; configs/F5TTS_v1_Small.yaml,
+    E2TTS_Small.yaml) at full width and depth against goldens minted from the reference's own DiT / UNetT."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES[name]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    g = gold(name)
+    try:
+        for prec, tol in (("fp32", TIGHT), ("fp16x3", X3TOL)):
+            out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
+            e = maxerr(out, g["out"])
+            print(f"{name} {prec}: max-abs {e:.2e}")
+            assert e < tol and maxerr(traj[1], g["traj_1"]) < tol
+    finally:
+        eng.close()
+
+
 def test_invalid_arguments_raise(engines):
     from f5_tts_amd.engine import F5HipCFM
 
