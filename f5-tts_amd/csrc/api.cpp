@@ -57,8 +57,69 @@ const float* W(const f5hip_ctx* ctx, const std::string& name) {
 
 // Blob order is chosen so that fused operands are contiguous: [to_q|to_k|to_v] per block, and the
 // AdaLN linears of ALL blocks back to back (one GEMM computes every block's modulation for every step).
+void add_vocos_slots(f5hip_ctx* ctx);
+
+// MMDiT (reference backbones/mmdit.py:112-134, modules.py:773-814).  Order matters in two places: to_q|to_k|to_v (and their biases) are
+// contiguous so one GEMM computes the fused projection, and the AdaLN linears of all blocks are contiguous per stream so one GEMM per
+// stream produces every block's modulation for a time step.
+void build_slots_mmdit(f5hip_ctx* ctx) {
+  const auto& c = ctx->cfg;
+  const int64_t D = c.dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
+  const std::string p = "transformer.";
+  add_slot(ctx, p + "time_embed.time_mlp.0.weight", D * 256);
+  add_slot(ctx, p + "time_embed.time_mlp.0.bias", D);
+  add_slot(ctx, p + "time_embed.time_mlp.2.weight", D * D);
+  add_slot(ctx, p + "time_embed.time_mlp.2.bias", D);
+  add_slot(ctx, p + "text_embed.text_embed.weight", (int64_t)(c.text_num_embeds + 1) * D);
+  add_slot(ctx, p + "audio_embed.linear.weight", D * 2 * mel);
+  add_slot(ctx, p + "audio_embed.linear.bias", D);
+  const int64_t cpg = D / c.conv_pos_groups;
+  for (int j = 0; j < 2; ++j) {
+    const std::string b = p + "audio_embed.conv_pos_embed.conv1d." + std::to_string(2 * j) + ".";
+    add_slot(ctx, b + "weight", D * cpg * c.conv_pos_kernel);
+    add_slot(ctx, b + "bias", D);
+  }
+  add_slot(ctx, p + "rotary_embed.inv_freq", c.dim_head / 2, /*optional=*/true);
+  auto blk = [&](int i) { return p + "transformer_blocks." + std::to_string(i) + "."; };
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, blk(i) + "attn_norm_x.linear.weight", 6 * D * D);
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, blk(i) + "attn_norm_x.linear.bias", 6 * D);
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, blk(i) + "attn_norm_c.linear.weight", (i == c.depth - 1 ? 2 : 6) * D * D);
+  for (int i = 0; i < c.depth; ++i) add_slot(ctx, blk(i) + "attn_norm_c.linear.bias", (i == c.depth - 1 ? 2 : 6) * D);
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = blk(i);
+    const bool last = i == c.depth - 1;
+    for (const char* sfx : {"", "_c"}) {
+      for (const char* w : {"to_q", "to_k", "to_v"}) add_slot(ctx, b + "attn." + w + sfx + ".weight", inner * D);
+      for (const char* w : {"to_q", "to_k", "to_v"}) add_slot(ctx, b + "attn." + w + sfx + ".bias", inner);
+    }
+    add_slot(ctx, b + "attn.to_out.0.weight", D * inner);
+    add_slot(ctx, b + "attn.to_out.0.bias", D);
+    if (!last) {
+      add_slot(ctx, b + "attn.to_out_c.weight", D * inner);
+      add_slot(ctx, b + "attn.to_out_c.bias", D);
+    }
+    if (c.qk_norm)
+      for (const char* w : {"q_norm", "k_norm", "c_q_norm", "c_k_norm"}) add_slot(ctx, b + "attn." + w + ".weight", c.dim_head);
+    for (const char* ff : {"ff_x", "ff_c"}) {
+      if (last && ff[3] == 'c') continue;
+      add_slot(ctx, b + ff + ".ff.0.0.weight", F * D);
+      add_slot(ctx, b + ff + ".ff.0.0.bias", F);
+      add_slot(ctx, b + ff + ".ff.2.weight", D * F);
+      add_slot(ctx, b + ff + ".ff.2.bias", D);
+    }
+  }
+  add_slot(ctx, p + "norm_out.linear.weight", 2 * D * D);
+  add_slot(ctx, p + "norm_out.linear.bias", 2 * D);
+  add_slot(ctx, p + "proj_out.weight", mel * D);
+  add_slot(ctx, p + "proj_out.bias", mel);
+  add_slot(ctx, p + "text_embed.freqs_cis", 1024 * D, /*optional=*/true);  // non-persistent buffer (mmdit.py:40)
+  ctx->dit_elems = ctx->blob_elems;
+  add_vocos_slots(ctx);
+}
+
 void build_slots(f5hip_ctx* ctx) {
   const auto& c = ctx->cfg;
+  if (c.backbone == 2) return build_slots_mmdit(ctx);
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
   const std::string p = "transformer.";
   add_slot(ctx, p + "time_embed.time_mlp.0.weight", D * 256);
@@ -146,6 +207,10 @@ void build_slots(f5hip_ctx* ctx) {
   }
   add_slot(ctx, p + "text_embed.freqs_cis", 8192 * T, /*optional=*/true);  // non-persistent buffer (dit.py:48)
   ctx->dit_elems = ctx->blob_elems;
+  add_vocos_slots(ctx);
+}
+
+void add_vocos_slots(f5hip_ctx* ctx) {
   if (ctx->has_vocos) {
     const auto& v = ctx->vcfg;
     const int64_t C = v.dim, I = v.intermediate_dim;
@@ -275,12 +340,14 @@ int finalize_impl(f5hip_ctx* ctx) {
   const bool unett = c.backbone == 1;
   const bool skip_concat = unett && c.skip_connect_type == 0;
   const int64_t skip_elems = skip_concat ? (int64_t)(c.depth / 2) * D * 2 * D : (!unett && c.long_skip_connection) ? D * 2 * D : 0;
-  HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
+  const bool mmdit = c.backbone == 2;
+  const int64_t cstream_elems = mmdit ? per_block * (c.depth - 1) + 3 * inner * D : 0;  // text stream; the last block only projects q/k/v
+  HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
   f16* hp = ctx->half_pool.as<f16>();
   ctx->blocks.assign(c.depth, BlockW{});
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = p + (unett ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
-    const std::string ba = b + (unett ? "2." : "attn."), bf = b + (unett ? "4." : "ff.");
+    const std::string ba = b + (unett ? "2." : "attn."), bf = b + (unett ? "4." : mmdit ? "ff_x." : "ff.");
     BlockW& bw = ctx->blocks[i];
     bw.wqkv = W(ctx, ba + "to_q.weight");
     bw.bqkv = W(ctx, ba + "to_q.bias");
@@ -311,6 +378,27 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk));
     HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk));
     if (bw.wskip) HIPCHK(carve(bw.wskip, D, 2 * D, bw.wskip_hi, bw.wskip_pk));
+    if (mmdit) {  // text stream of the block (modules.py:791-814)
+      const bool last = i == c.depth - 1;
+      bw.wqkv_c = W(ctx, ba + "to_q_c.weight");
+      bw.bqkv_c = W(ctx, ba + "to_q_c.bias");
+      HIPCHK(carve(bw.wqkv_c, 3 * inner, D, bw.wqkv_c_hi, bw.wqkv_c_pk));
+      if (!last) {
+        bw.wo_c = W(ctx, ba + "to_out_c.weight");
+        bw.bo_c = W(ctx, ba + "to_out_c.bias");
+        bw.w1_c = W(ctx, b + "ff_c.ff.0.0.weight");
+        bw.b1_c = W(ctx, b + "ff_c.ff.0.0.bias");
+        bw.w2_c = W(ctx, b + "ff_c.ff.2.weight");
+        bw.b2_c = W(ctx, b + "ff_c.ff.2.bias");
+        HIPCHK(carve(bw.wo_c, D, inner, bw.wo_c_hi, bw.wo_c_pk));
+        HIPCHK(carve(bw.w1_c, F, D, bw.w1_c_hi, bw.w1_c_pk));
+        HIPCHK(carve(bw.w2_c, D, F, bw.w2_c_hi, bw.w2_c_pk));
+      }
+      if (c.qk_norm) {
+        bw.qn_c = W(ctx, ba + "c_q_norm.weight");
+        bw.kn_c = W(ctx, ba + "c_k_norm.weight");
+      }
+    }
     if (!unett && c.long_skip_connection && i == c.depth - 1) {
       ctx->wlong = W(ctx, p + "long_skip_connection.weight");
       HIPCHK(carve(ctx->wlong, D, 2 * D, ctx->wlong_hi, ctx->wlong_pk));
@@ -318,6 +406,11 @@ int finalize_impl(f5hip_ctx* ctx) {
   }
   if (unett) {
     ctx->norm_out_g = W(ctx, p + "norm_out.g");
+  } else if (mmdit) {
+    ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm_x.linear.weight");
+    ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm_x.linear.bias");
+    ctx->adaln_c_w = W(ctx, p + "transformer_blocks.0.attn_norm_c.linear.weight");
+    ctx->adaln_c_b = W(ctx, p + "transformer_blocks.0.attn_norm_c.linear.bias");
   } else {
     ctx->adaln_w = W(ctx, p + "transformer_blocks.0.attn_norm.linear.weight");
     ctx->adaln_b = W(ctx, p + "transformer_blocks.0.attn_norm.linear.bias");
@@ -336,7 +429,7 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(ctx->conv_w32[j].ensure(n * sizeof(float)));
     HIPCHK(ctx->conv_whi[j].ensure(n * sizeof(f16)));
     HIPCHK(ctx->conv_wlo[j].ensure(n * sizeof(f16)));
-    HIPCHK(launch_convpos_pack(W(ctx, p + "input_embed.conv_pos_embed.conv1d." + std::to_string(2 * j) + ".weight"), (int)D, cpg,
+    HIPCHK(launch_convpos_pack(W(ctx, p + (mmdit ? "audio_embed" : "input_embed") + ".conv_pos_embed.conv1d." + std::to_string(2 * j) + ".weight"), (int)D, cpg,
                                c.conv_pos_kernel, ctx->conv_w32[j].as<float>(), ctx->conv_whi[j].as<f16>(), ctx->conv_wlo[j].as<f16>(), st));
   }
   // depthwise weights [C,1,7] -> [7,C]
@@ -355,7 +448,24 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(launch_dw_pack(W(ctx, b + "dwconv.weight"), (int)T, tb.dw7, st));
   }
   // absolute sinusoid position table of the text encoder (reference model/modules.py:207-218), fp32 op order as torch
-  if (c.conv_layers > 0) {
+  if (mmdit) {  // mmdit.py:39-40,57-60: 1024 positions of width dim; positions past the table reuse its last row (get_pos_embed_indices
+                // clips, modules.py:229) — materialised here as 8192 rows so the embedding kernel indexes it directly
+    const int64_t n = (int64_t)8192 * D;
+    HIPCHK(ctx->freqs_cis.ensure(n * sizeof(float)));
+    std::vector<float> tab(n);
+    const int half = (int)D / 2;
+    for (int k = 0; k < half; ++k) {
+      const float f = 1.0f / powf(10000.0f, (float)(2 * k) / (float)D);
+      for (int pos = 0; pos < 8192; ++pos) {
+        const float a = (float)std::min(pos, 1023) * f;
+        tab[(int64_t)pos * D + k] = cosf(a);
+        tab[(int64_t)pos * D + half + k] = sinf(a);
+      }
+    }
+    HIPCHK(hipMemcpy(ctx->freqs_cis.p, tab.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    if (slot_loaded(ctx, p + "text_embed.freqs_cis"))  // a checkpoint that does carry the buffer wins for the rows it has
+      HIPCHK(hipMemcpy(ctx->freqs_cis.p, W(ctx, p + "text_embed.freqs_cis"), (size_t)1024 * D * sizeof(float), hipMemcpyDeviceToDevice));
+  } else if (c.conv_layers > 0) {
     const int64_t n = (int64_t)8192 * T;
     HIPCHK(ctx->freqs_cis.ensure(n * sizeof(float)));
     if (slot_loaded(ctx, p + "text_embed.freqs_cis")) {
@@ -502,6 +612,7 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
   } else {
     HIPCHK(ctx->mods.ensure((size_t)steps * c.depth * 6 * D * sizeof(float), &moved));
     HIPCHK(ctx->fmods.ensure((size_t)steps * 2 * D * sizeof(float), &moved));
+    if (c.backbone == 2) HIPCHK(ctx->cmods.ensure((size_t)steps * ((c.depth - 1) * 6 + 2) * D * sizeof(float), &moved));
   }
   if (moved) ctx->ws_epoch++;
   ctx->t_host.assign(t, t + steps);
@@ -523,24 +634,36 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->mods.as<float>(), nm, ctx->adaln_b), 1, st));
     g = core(ctx->tsilu.p, D, W(ctx, p + "norm_out.linear.weight"), D, steps, 2 * (int)D, (int)D);
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->fmods.as<float>(), 2 * D, W(ctx, p + "norm_out.linear.bias")), 1, st));
+    if (c.backbone == 2) {  // text-stream AdaLN of every block: 6 chunks, the last block (AdaLayerNorm_Final) only (scale, shift)
+      const int nc = ((c.depth - 1) * 6 + 2) * (int)D;
+      g = core(ctx->tsilu.p, D, ctx->adaln_c_w, D, steps, nc, (int)D);
+      HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->cmods.as<float>(), nc, ctx->adaln_c_b), 1, st));
+    }
   }
   return F5HIP_OK;
 }
 
 // ---- workspace -----------------------------------------------------------------------------------
-int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
+int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_attn) {
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
-  const bool unett = c.backbone == 1;
-  const int ns = n + (unett ? 1 : 0);                 // tokens per sequence inside the backbone (UNetT prepends the time token)
+  const bool unett = c.backbone == 1, mmdit = c.backbone == 2;
+  // tokens per sequence inside the backbone: UNetT prepends the time token; MMDiT attends over audio frames + text tokens jointly
+  // (its row-wise buffers hold the audio rows of all sequences first, then the text rows)
+  const int ns = n + (unett ? 1 : mmdit ? nt : 0);
   const int64_t BN = (int64_t)B * n, M = 2 * (int64_t)B * ns;
   bool moved = false;
 #define ENS(buf, bytes) HIPCHK(ctx->buf.ensure((size_t)(bytes), &moved))
-  ENS(tok, BN * 4); ENS(valid, BN); ENS(textkeep, M); ENS(rowvalid, M); ENS(condmask, BN); ENS(kvlen, 2 * B * 4);
-  ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, 2 * B * 2 * T * 4);
+  ENS(tok, std::max<int64_t>(BN, (int64_t)B * nt) * 4); ENS(valid, std::max<int64_t>(BN, (int64_t)B * nt)); ENS(textkeep, M); ENS(rowvalid, M);
+  ENS(condmask, BN); ENS(kvlen, 2 * B * 4);
+  if (mmdit) {
+    ENS(ctext0, 2 * (int64_t)B * nt * D * 4); ENS(cmask, 2 * (int64_t)B * nt); ENS(kvlen2, 2 * B * 4);
+  } else {
+    ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, 2 * B * 2 * T * 4);
+  }
   ENS(step_cond, BN * mel * 4); ENS(cconst, M * D * 4); ENS(y, BN * mel * 4);
   ENS(h, M * D * 4); ENS(c1, M * D * 4); ENS(x, M * D * 4);
-  ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)ns * c.dim_head * 4);
+  ENS(vel, M * mel * 4); ENS(dbg_vel, BN * mel * 4); ENS(rope, (int64_t)ns * c.dim_head * 4);  // MMDiT: max(n, nt) positions fit
   if (unett && c.skip_connect_type != 2) ENS(skipcat, (int64_t)(c.depth / 2) * M * 2 * D * (op == OP_F16 ? 2 : 4));
   if (!unett && c.long_skip_connection) ENS(skipcat, M * 2 * D * (op == OP_F16 ? 2 : 4));
   if (c.text_average_upsampling) ENS(avgidx, BN * 4);
@@ -556,7 +679,7 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
     ENS(q32, M * inner * 4); ENS(k32, M * inner * 4);
     if ((size_t)(2 * B * c.heads * c.dim_head * np * 4) > ctx->vt32.cap) {
       HIPCHK(ctx->vt32.ensure((size_t)(2 * B * c.heads * c.dim_head * np * 4), &moved, /*zero=*/true));
-    } else if (ctx->ws_n != n) {
+    } else if (ctx->ws_n != n || ctx->ws_nt != nt) {
       HIPCHK(hipMemset(ctx->vt32.p, 0, ctx->vt32.cap));  // padding columns must be zero for the new row stride
     }
     ENS(scores, (int64_t)2 * B * c.heads * ns * np * 4);
@@ -574,6 +697,7 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int op, bool exact_attn) {
   if (moved) ctx->ws_epoch++;
   ctx->ws_B = B;
   ctx->ws_n = n;
+  ctx->ws_nt = nt;
   return F5HIP_OK;
 }
 
@@ -652,7 +776,7 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
 // ---- attention over [2B * H] (batch', head) slabs of ns tokens: q/k/v were written by the QKV epilogue -------------------------------
 // S sequences starting at sequence s0 of the packed [cond | uncond] batch (o32/o_hi/o_lo/kvlen are already offset by the caller)
 int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
-                  int64_t ldO, hipStream_t st) {
+                  int64_t ldO, hipStream_t st, const int32_t* kvlen2 = nullptr, int seg2_off = 0) {
   const auto& c = ctx->cfg;
   const int H = c.heads, dh = c.dim_head, inner = H * dh;
   const int64_t qoff = (int64_t)s0 * H * n * dh;                      // q/k slabs [seq*H, n, dh]
@@ -668,7 +792,7 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         EpiStore e = epi_store(sc, np, nullptr);
         e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
         HIPCHK(launch_gemm_store(OP_F32, g, e, S * H, st));
-        HIPCHK(launch_softmax_rows(sc, (int64_t)S * H * n, np, n, H, kvlen, n, st));
+        HIPCHK(launch_softmax_rows(sc, (int64_t)S * H * n, np, n, H, kvlen, n, st, kvlen2, seg2_off));
         g = core(sc, np, vt, np, n, dh, np);
         g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
         EpiStore e2 = epi_store(o32, inner, nullptr);
@@ -686,7 +810,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         const int64_t voff = (int64_t)s0 * inner * ldv;
         HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
                                  ctx->k16.as<f16>() + qoff, x3 ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
-                                 x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk));
+                                 x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
+                                 kvlen2, seg2_off));
       }
     }
   return F5HIP_OK;
@@ -998,17 +1123,207 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
   return F5HIP_OK;
 }
 
+// ---- MMDiT (reference backbones/mmdit.py, MMDiTBlock modules.py:763-845, JointAttnProcessor modules.py:563-705) -----------------------
+// Row layout of every row-wise buffer (x, a_*, f_*): the audio rows of all S sequences first ([S*n, .]), then the text rows
+// ([S*nt, .]).  Attention slabs are joint per (sequence, head): tokens [0, n) = audio frames, [n, n + nt) = text tokens.
+
+// text stream input, once per utterance (mmdit.py:43-66): embedding + absolute sinusoid positions, padding rows zeroed
+int run_text_embed_mmdit(f5hip_ctx* ctx, int B, int nt, const int64_t* text, hipStream_t st) {
+  const auto& c = ctx->cfg;
+  const int64_t BT = (int64_t)B * nt;
+  if (nt > 8192) FAIL(F5HIP_ERR_INVALID, "nt=%d exceeds the 8192-row text position table", nt);
+  std::vector<int32_t> tok(BT);
+  std::vector<uint8_t> valid(BT, 1), cm(2 * BT);
+  for (int64_t i = 0; i < BT; ++i) {
+    const int64_t id = text[i] + 1;  // 0 = filler / batch padding (mmdit.py:44)
+    if (id < 0 || id > c.text_num_embeds) FAIL(F5HIP_ERR_INVALID, "text id %lld out of range at %lld", (long long)(id - 1), (long long)i);
+    tok[i] = (int32_t)id;
+    cm[i] = cm[BT + i] = id != 0;  // c_mask (mmdit.py:232)
+  }
+  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok.data(), BT * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BT, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->cmask.p, cm.data(), 2 * BT, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  Prof pr(ctx, st, KC_TEXT, 0, 2.0 * BT * c.dim * 4.0 * 2);
+  HIPCHK(launch_text_embed(ctx->tok.as<int32_t>(), ctx->valid.as<uint8_t>(), W(ctx, "transformer.text_embed.text_embed.weight"),
+                           ctx->freqs_cis.as<float>(), B, nt, c.dim, c.text_mask_padding, 1, ctx->ctext0.as<float>(), st));
+  return F5HIP_OK;
+}
+
+int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op, bool exact_attn, int use_mask, hipStream_t st) {
+  const int step = sg.eidx, nb = ctx->nb;
+  const auto& c = ctx->cfg;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner, H = c.heads, dh = c.dim_head;
+  const int S = nb * B, ns = n + nt;
+  const int64_t BN = (int64_t)B * n;
+  const int Mx = S * n, Mc = S * nt;
+  const std::string p = "transformer.";
+  const uint8_t* rowvalid = use_mask ? ctx->rowvalid.as<uint8_t>() : nullptr;  // audio mask [S, n] (modules.py:699-700)
+  const uint8_t* cmask = ctx->cmask.as<uint8_t>();                              // text mask [S, nt], always applied (modules.py:701-702)
+  float* x = ctx->x.as<float>();                 // audio stream state [S*n, D]
+  float* cs = x + (int64_t)Mx * D;               // text stream state  [S*nt, D]
+  float* h = ctx->h.as<float>();
+  float* c1 = ctx->c1.as<float>();
+  const float* cconst = ctx->cconst.as<float>();
+  const int wbytes = op == OP_F32 ? 4 : 2;
+  const int pk = op == OP_F16X3 ? 1 : 0;
+  const int64_t pl = pk ? 2 : 1, ldA = D * pl, ldO = inner * pl, ldF = F * pl;
+  const int esz = op == OP_F32 ? 4 : 2;          // bytes per stored operand element
+  // operand buffers: audio rows then text rows
+  char* a_base = op == OP_F32 ? ctx->a32.as<char>() : ctx->a_hi.as<char>();
+  char* o_base = op == OP_F32 ? ctx->o32.as<char>() : ctx->o_hi.as<char>();
+  char* f_base = op == OP_F32 ? ctx->f32.as<char>() : ctx->f_hi.as<char>();
+  auto a_rows = [&](int64_t row) { return a_base + row * ldA * esz; };
+  auto f_rows = [&](int64_t row) { return f_base + row * ldF * esz; };
+  // LayerNorm (no affine, eps 1e-6) with AdaLN modulation into the operand buffer
+  auto ln_mod = [&](const float* src, int M, int64_t row0, const float* scale, const float* shift) -> hipError_t {
+    Prof pr(ctx, st, KC_LNMOD, 0, (double)M * D * (4 + wbytes * pl));
+    char* dst = a_rows(row0);
+    if (op == OP_F32) return launch_layernorm(src, D, M, D, 1e-6f, nullptr, nullptr, scale, shift, reinterpret_cast<float*>(dst), nullptr, nullptr, D, st);
+    f16* hi = reinterpret_cast<f16*>(dst);
+    return launch_layernorm(src, D, M, D, 1e-6f, nullptr, nullptr, scale, shift, nullptr, hi, pk ? hi + 32 : nullptr, D, st, pk, ldA);
+  };
+  // joint attention mask (modules.py:643-657) only when the config enables it and a mask exists
+  const bool amask = c.attn_mask_enabled && use_mask;
+  const int32_t* kvlen = amask ? ctx->kvlen.as<int32_t>() : nullptr;
+  const int32_t* kvlen2 = amask ? ctx->kvlen2.as<int32_t>() : nullptr;
+
+  {  // AudioEmbedding (mmdit.py:79-85): linear over cat(x, cond) — the cond part is step-invariant (cconst) — then conv_pos + residual, no mask
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
+    GemmCore g = core(sg.yin, mel, W(ctx, p + "audio_embed.linear.weight"), 2 * mel, (int)BN, D, mel);
+    EpiStore e = epi_store(h, D, nullptr);
+    e.res = cconst; e.ldres = D;
+    if (nb == 2) { e.out2 = h + BN * D; e.res2 = cconst + BN * D; }
+    HIPCHK(launch_gemm_store(OP_F32, g, e, 1, st));
+  }
+  {
+    const int cpg = D / c.conv_pos_groups;
+    Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops(Mx, D, (int64_t)cpg * c.conv_pos_kernel), 0);
+    HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
+                          W(ctx, p + "audio_embed.conv_pos_embed.conv1d.0.bias"), nullptr, nullptr, S, n, D, c.conv_pos_groups, c.conv_pos_kernel,
+                          c1, st));
+    HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
+                          W(ctx, p + "audio_embed.conv_pos_embed.conv1d.2.bias"), nullptr, h, S, n, D, c.conv_pos_groups, c.conv_pos_kernel, x, st));
+  }
+  {  // the text stream starts every evaluation from the cached embedding (mmdit.py:190-206)
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 2.0 * Mc * D * 4);
+    HIPCHK(hipMemcpyAsync(cs, ctx->ctext0.p, (size_t)Mc * D * 4, hipMemcpyDeviceToDevice, st));
+  }
+  const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
+  const float* cmods_step = ctx->cmods.as<float>() + (int64_t)step * ((c.depth - 1) * 6 + 2) * D;
+
+  // fused q|k|v projection of one stream into the joint slabs
+  auto qkv = [&](const BlockW& bw, bool text) -> int {
+    const int M = text ? Mc : Mx, nseq = text ? nt : n;
+    EpiQKV e{};
+    e.bias = text ? bw.bqkv_c : bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = nseq; e.heads = H; e.dh = dh;
+    e.pe_heads = -1; e.qscale = 1.0f / sqrtf((float)dh);  // rope on every head of both streams, each from position 0 (modules.py:626-636)
+    e.slab_n = ns; e.pos_off = text ? n : 0;
+    e.qk_raw = c.qk_norm ? 1 : 0;
+    if (exact_attn || c.qk_norm) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); }
+    if (exact_attn) {
+      e.ldvt = (ns + 3) & ~3;
+      e.vt32 = ctx->vt32.as<float>();
+    } else {
+      e.ldvt = (ns + 7) & ~7;
+      e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>();
+      if (op == OP_F16X3 && ctx->attn_impl != 3) {
+        e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
+        if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+      }
+    }
+    Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
+    GemmCore g = core(a_rows(text ? Mx : 0), ldA, text ? wsel(op, bw.wqkv_c, bw.wqkv_c_hi, bw.wqkv_c_pk) : wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk),
+                      ldA, M, 3 * inner, D);
+    HIPCHK(launch_gemm_qkv(op, g, e, st));
+    return F5HIP_OK;
+  };
+  // to_out / to_out_c over the stream's rows of the joint attention output, one GEMM batch per sequence:
+  //   state += gate * masked(o . W^T + b)
+  auto out_proj = [&](bool text, const void* Wsel, const float* bias, const float* gate, float* state) -> int {
+    const int M = text ? nt : n;
+    Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops((int64_t)S * M, D, inner), 0);
+    GemmCore g = core(o_base + (int64_t)(text ? n : 0) * ldO * esz, ldO, Wsel, ldO, M, D, inner);
+    g.strideA = (int64_t)ns * ldO;
+    EpiStore e = epi_store(state, D, bias);
+    e.colscale = gate; e.res = state; e.ldres = D;
+    e.rowmask = text ? cmask : rowvalid; e.mask_mode = 1; e.smask = M;
+    e.zdiv = 1; e.so1 = (int64_t)M * D; e.so2 = 0;
+    HIPCHK(launch_gemm_store(op, g, e, S, st));
+    return F5HIP_OK;
+  };
+  // FeedForward of one stream: state += gate * (gelu_tanh(a . W1^T + b1) . W2^T + b2)
+  auto feed_forward = [&](int M, int64_t row0, const void* W1, const float* b1, const void* W2, const float* b2, const float* gate, float* state) -> int {
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
+      GemmCore g = core(a_rows(row0), ldA, W1, ldA, M, F, D);
+      EpiStore e = epi_store(op == OP_F32 ? reinterpret_cast<float*>(f_rows(row0)) : nullptr, F, b1, ACT_GELU_TANH);
+      if (op != OP_F32) { f16* fh = reinterpret_cast<f16*>(f_rows(row0)); e.out16 = fh; e.out16_lo = pk ? fh + 32 : nullptr; e.pk16 = pk; e.ldo16 = ldF; }
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), 0);
+    GemmCore g = core(f_rows(row0), ldF, W2, ldF, M, D, F);
+    EpiStore e = epi_store(state, D, b2);
+    e.colscale = gate; e.res = state; e.ldres = D;
+    HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    return F5HIP_OK;
+  };
+
+  for (int i = 0; i < c.depth; ++i) {
+    const BlockW& bw = ctx->blocks[i];
+    const bool last = i == c.depth - 1;  // context_pre_only (mmdit.py:118)
+    const float* mx = mods_step + (int64_t)i * 6 * D;   // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:323)
+    const float* mc = cmods_step + (int64_t)i * 6 * D;  // same for the text stream; the last block holds (scale, shift) only (modules.py:344)
+    HIPCHK(ln_mod(x, Mx, 0, mx + D, mx));
+    HIPCHK(last ? ln_mod(cs, Mc, Mx, mc, mc + D) : ln_mod(cs, Mc, Mx, mc + D, mc));
+    CHK(qkv(bw, false));
+    CHK(qkv(bw, true));
+    if (c.qk_norm) {
+      Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
+      HIPCHK(launch_qk_norm_rope(ctx->q32.as<float>(), ctx->k32.as<float>(), bw.qn, bw.kn, ctx->rope.as<float>(), (int64_t)S * H * ns, ns, H, dh, -1,
+                                 1.0f / sqrtf((float)dh), 1e-6f, exact_attn ? nullptr : ctx->q16.as<f16>(),
+                                 (!exact_attn && op == OP_F16X3 && ctx->attn_impl != 3) ? ctx->q16_lo.as<f16>() : nullptr,
+                                 exact_attn ? nullptr : ctx->k16.as<f16>(),
+                                 (!exact_attn && op == OP_F16X3 && ctx->attn_impl != 3) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));
+    }
+    CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, op == OP_F32 ? reinterpret_cast<float*>(o_base) : nullptr,
+                      op != OP_F32 ? reinterpret_cast<f16*>(o_base) : nullptr, pk ? reinterpret_cast<f16*>(o_base) + 32 : nullptr, pk, ldO, st, kvlen2, n));
+    if (!last) {  // text stream (modules.py:829-837)
+      CHK(out_proj(true, wsel(op, bw.wo_c, bw.wo_c_hi, bw.wo_c_pk), bw.bo_c, mc + 2 * D, cs));
+      HIPCHK(ln_mod(cs, Mc, Mx, mc + 4 * D, mc + 3 * D));
+      CHK(feed_forward(Mc, Mx, wsel(op, bw.w1_c, bw.w1_c_hi, bw.w1_c_pk), bw.b1_c, wsel(op, bw.w2_c, bw.w2_c_hi, bw.w2_c_pk), bw.b2_c, mc + 5 * D, cs));
+    }
+    // audio stream (modules.py:839-843)
+    CHK(out_proj(false, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), bw.bo, mx + 2 * D, x));
+    HIPCHK(ln_mod(x, Mx, 0, mx + 4 * D, mx + 3 * D));
+    CHK(feed_forward(Mx, 0, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), bw.b1, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), bw.b2, mx + 5 * D, x));
+  }
+  {  // norm_out + proj_out (mmdit.py:259-260)
+    const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
+    HIPCHK(ln_mod(x, Mx, 0, fm, fm + D));
+    Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(Mx, mel, D), 0);
+    GemmCore g = core(a_rows(0), ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, Mx, mel, D);
+    HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias")), 1, st));
+  }
+  {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
+    HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            sg.traj, ctx->dbg_vel.as<float>(), st));
+  }
+  return F5HIP_OK;
+}
+
 // The whole solve on the given evaluation tables: euler = one evaluation per step; midpoint (torchdiffeq fixed-grid "midpoint":
 // y_mid = y + f(t, y) dt/2; y += dt f(t + dt/2, y_mid)) = two, through the scratch state ymid.
-int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int method, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
-  const bool unett = ctx->cfg.backbone == 1;
+int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, int op, bool exact_attn, int use_mask, float* traj, hipStream_t st) {
+  const bool unett = ctx->cfg.backbone == 1, mmdit = ctx->cfg.backbone == 2;
   const int64_t slab = (int64_t)B * n * ctx->cfg.mel_dim;
   float* y = ctx->y.as<float>();
   float* ymid = ctx->ymid.as<float>();
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
+  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1018,6 +1333,7 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int steps, int method, int op, b
     auto one = [&](hipStream_t s_, int br) {
       return unett ? run_step_unett(ctx, B, n, sg, op, exact_attn, use_mask, s_, br) : run_step(ctx, B, n, sg, op, exact_attn, use_mask, s_, br);
     };
+    if (mmdit) return run_step_mmdit(ctx, B, n, nt, sg, op, exact_attn, use_mask, st);
     if (!split) return one(st, -1);
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
@@ -1061,7 +1377,10 @@ int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int d
   if (cpg != 16 && cpg != 32 && cpg != 48 && cpg != 64) return bad("dim/conv_pos_groups must be 16, 32, 48 or 64");
   if (!(dc->conv_pos_kernel & 1)) return bad("conv_pos_kernel must be odd");
   if (dc->mel_dim > 256) return bad("mel_dim must be <= 256");
-  if (dc->backbone != 0 && dc->backbone != 1) return bad("backbone must be 0 (DiT) or 1 (UNetT)");
+  if (dc->backbone < 0 || dc->backbone > 2) return bad("backbone must be 0 (DiT), 1 (UNetT) or 2 (MMDiT)");
+  if (dc->backbone == 2 && (dc->text_dim != dc->dim || dc->conv_layers != 0 || dc->depth < 1 || dc->pe_attn_head >= 0 || dc->long_skip_connection ||
+                            dc->text_average_upsampling))
+    return bad("MMDiT: text_dim == dim, no text conv blocks, rope on all heads, no DiT-only switches (mmdit.py:94-134)");
   if (dc->backbone == 1 && (dc->conv_layers != 0 || (dc->depth & 1))) return bad("UNetT: conv_layers must be 0 and depth even (unett.py:130)");
   if (dc->qk_norm != 0 && dc->qk_norm != 1) return bad("Unimplemented qk_norm (modules.py:409): 0 = None, 1 = rms_norm");
   if (dc->qk_norm && (dc->dim_head % 4 || dc->dim_head > 256 || (dc->dim_head & (dc->dim_head - 1)))) return bad("qk_norm: dim_head must be a power of two <= 256");
@@ -1238,7 +1557,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   // cfg_strength < 1e-5: the reference evaluates only the conditional branch (cfm.py:166-177); otherwise cond + uncond rows are packed
   const int nb = cfg_strength < 1e-5f ? 1 : 2;
   if (ctx->nb != nb) { ctx->nb = nb; ctx->ws_epoch++; }
-  CHK(ensure_workspace(ctx, B, n, op, exact_attn));
+  CHK(ensure_workspace(ctx, B, n, nt, op, exact_attn));
   HIPCHK(ctx->ymid.ensure((size_t)BN * mel * sizeof(float)));
   {  // evaluation times and update coefficients of the chosen fixed-grid solver (torchdiffeq euler / midpoint on the supplied grid)
     const int E = ode_method == 0 ? steps : 2 * steps;
@@ -1264,6 +1583,19 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     }
     HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv.data(), 2 * BNs, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->kvlen.p, kv.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
+    std::vector<int32_t> kv2(2 * B, 0);
+    if (c.backbone == 2) {  // MMDiT joint key mask = cat(audio mask, c_mask) (modules.py:643-648): the valid text tokens as a second run
+      for (int b = 0; b < B; ++b) {
+        int len = 0;
+        while (len < nt && text[(int64_t)b * nt + len] != -1) ++len;
+        if (c.attn_mask_enabled && use_mask)
+          for (int j = len; j < nt; ++j)
+            if (text[(int64_t)b * nt + j] != -1)
+              FAIL(F5HIP_ERR_UNSUPPORTED, "MMDiT with attn_mask_enabled: padding (-1) inside the text of sample %d (only trailing padding is built)", b);
+        kv2[b] = kv2[B + b] = len;
+      }
+      HIPCHK(hipMemcpyAsync(ctx->kvlen2.p, kv2.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
+    }
     HIPCHK(hipMemcpyAsync(ctx->condmask.p, cond_mask, BN, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
   }
@@ -1272,8 +1604,24 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     HIPCHK(launch_mask_select(cond, ctx->condmask.as<uint8_t>(), BN, mel, ctx->step_cond.as<float>(), st));  // cfm.py:151-153
     HIPCHK(hipMemcpyAsync(ctx->y.p, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (trajectory) HIPCHK(hipMemcpyAsync(trajectory, y0, BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCHK(launch_rope_table(ctx->inv_freq.as<float>(), n + (c.backbone == 1 ? 1 : 0), c.dim_head / 2, ctx->rope.as<float>(), st));
+    HIPCHK(launch_rope_table(ctx->inv_freq.as<float>(), c.backbone == 2 ? std::max(n, nt) : n + (c.backbone == 1 ? 1 : 0), c.dim_head / 2,
+                             ctx->rope.as<float>(), st));
   }
+  if (c.backbone == 2) {
+    CHK(run_text_embed_mmdit(ctx, B, nt, text, st));
+    // step-invariant part of AudioEmbedding.linear (mmdit.py:79-83): W[:, mel:] . cond + b for the cond rows, b alone for the uncond rows
+    Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
+    const float* Wp = W(ctx, "transformer.audio_embed.linear.weight");
+    const float* bp = W(ctx, "transformer.audio_embed.linear.bias");
+    float* cc = ctx->cconst.as<float>();
+    GemmCore g = core(ctx->step_cond.p, mel, Wp + mel, 2 * mel, (int)BN, D, mel);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(cc, D, bp), 1, st));
+    if (nb == 2) {  // alpha = 0: the epilogue just broadcasts the bias
+      EpiStore e0 = epi_store(cc + BN * D, D, bp);
+      e0.alpha = 0.f;
+      HIPCHK(launch_gemm_store(OP_F32, g, e0, 1, st));
+    }
+  } else {
   CHK(run_text_embed(ctx, B, n, text, nt, duration, use_mask, st));
   {  // step-invariant part of InputEmbedding.proj: W_c.cond + W_t.text + b  (cond branch), W_t.text_uncond + b (uncond, cond=0)
     Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
@@ -1290,6 +1638,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     g = core(ctx->tx.as<float>() + BN * c.text_dim, c.text_dim, Wp + 2 * mel, ldw, (int)BN, D, c.text_dim);
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(cc + BN * D, D, bp), 1, st));
   }
+  }
 
   // ---- the NFE loop: eager, or one hipGraph replay ------------------------------------------------
   bool done = false;
@@ -1304,27 +1653,27 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
       if (moved) ctx->ws_epoch++;
       tbuf = ctx->traj_buf.as<float>();
     }
-    const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
+    const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.nt == (c.backbone == 2 ? nt : 0) && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
                      k.method == ode_method && k.traj == tbuf && k.ws_epoch == ctx->ws_epoch;
     if (!hit) {
       if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
       if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
-      int r = enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, tbuf, ctx->cap_stream);
+      int r = enqueue_steps(ctx, B, n, nt, steps, ode_method, op, exact_attn, use_mask, tbuf, ctx->cap_stream);
       hipError_t ce = hipStreamEndCapture(ctx->cap_stream, &graph);
       if (r != F5HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return r; }
       HIPCHK(ce);
       HIPCHK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
-      k.B = B; k.n = n; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = tbuf; k.ws_epoch = ctx->ws_epoch;
+      k.B = B; k.n = n; k.nt = c.backbone == 2 ? nt : 0; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = tbuf; k.ws_epoch = ctx->ws_epoch;
     }
     HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
     if (trajectory)  // states 1..steps (state 0 = y0 was copied above)
       HIPCHK(hipMemcpyAsync(trajectory + BN * mel, tbuf + BN * mel, (size_t)steps * BN * mel * sizeof(float), hipMemcpyDeviceToDevice, st));
     done = true;
   }
-  if (!done) CHK(enqueue_steps(ctx, B, n, steps, ode_method, op, exact_attn, use_mask, trajectory, st));
+  if (!done) CHK(enqueue_steps(ctx, B, n, nt, steps, ode_method, op, exact_attn, use_mask, trajectory, st));
 
   {  // out = where(cond_mask, cond, y_final) (cfm.py:221-223)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
@@ -1344,6 +1693,7 @@ int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, voi
   if (BN == 0) FAIL(F5HIP_ERR_STATE, "no sample call yet");
   const float* src = nullptr;
   int64_t want = 0;
+  if (c.backbone == 2 && which < 2) FAIL(F5HIP_ERR_UNSUPPORTED, "MMDiT keeps the text stream at its own length: no [batch, n, text_dim] text tap");
   switch (which) {
     case 0: src = ctx->tx.as<float>(); want = BN * c.text_dim; break;
     case 1: src = ctx->tx.as<float>() + BN * c.text_dim; want = BN * c.text_dim; break;

@@ -35,6 +35,8 @@ struct FlashArgs {
   const f16 *q, *q_lo, *k, *k_lo, *vt, *vt_lo;
   f16 *o, *o_lo;
   const int32_t* kvlen;  // per batch' or null
+  const int32_t* kvlen2; // MMDiT joint attention with a key mask (modules.py:643-657): a second run of valid keys [seg2_off, seg2_off +
+  int seg2_off;          // kvlen2[batch']) behind the first one [0, kvlen[batch']) — audio frames, then the text tokens; null = one run
   int n, ldv, heads, nqb, nwg, o_packed;
 };
 
@@ -62,7 +64,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
   const int bh = L / a.nqb, qb = L - bh * a.nqb;
   const int bp = bh / a.heads, hh = bh - bp * a.heads;
   const int n = a.n;
-  const int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n;
+  // valid keys: [0, hole_lo) and [hole_hi, kv_end); the hole is empty unless a second run is given
+  int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n, hole_lo = 0, hole_hi = 0;
+  if (a.kvlen && a.kvlen2) {
+    hole_lo = kv_end;
+    hole_hi = min(a.seg2_off, n);
+    kv_end = min(a.seg2_off + a.kvlen2[bp], n);
+    if (hole_lo >= hole_hi) hole_lo = hole_hi = 0;
+  }
   const int ntile = (kv_end + KT - 1) / KT;
 
   // K / V^T slabs of this (batch', head) through buffer descriptors: rows or keys past the end read as zeros (hardware
@@ -156,13 +165,14 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
       }
 
     // ---- online softmax (fp32), lane-local per query row ----------------------------------------------
-    if ((t + 1) * KT > kv_end) {  // tail tile: keys >= kv_end do not exist / are masked
+    if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {  // tail tile (keys >= kv_end do not exist / are
+                                                                                      // masked) or a tile touching the masked hole
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= kv_end) s[kb][r] = -INFINITY;
+          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) s[kb][r] = -INFINITY;
         }
     }
     float mx = s[0][0];
@@ -289,9 +299,11 @@ hipError_t init_attention_kernels() {
 }
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
-                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed) {
+                             int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed,
+                             const int32_t* kvlen2, int seg2_off) {
   FlashArgs a{};
   a.o_packed = o_packed;
+  a.kvlen2 = kvlen2; a.seg2_off = seg2_off;
   a.q = q; a.q_lo = q_lo; a.k = k; a.k_lo = k_lo; a.vt = vt; a.vt_lo = vt_lo;
   a.o = o16; a.o_lo = o16_lo; a.kvlen = kvlen;
   a.n = n; a.ldv = ldv; a.heads = heads;

@@ -315,19 +315,25 @@ __global__ void dw_pack_kernel(const float* w, int C, float* w7) {
 
 // exact attention: softmax over the first kv columns of each score row, zero the rest (incl. padding to ld)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, int64_t rows, int ld, int nseq, int heads,
-                                                            const int32_t* kvlen, int kv_default) {
+                                                            const int32_t* kvlen, int kv_default, const int32_t* kvlen2, int seg2_off) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int bp = (int)(row / ((int64_t)heads * nseq));
-  const int kv = kvlen ? kvlen[bp] : kv_default;
+  // valid columns: [0, hlo) and [hhi, kv) (the hole is empty unless a second key run is given: MMDiT audio + text mask)
+  int kv = kvlen ? kvlen[bp] : kv_default, hlo = 0, hhi = 0;
+  if (kvlen && kvlen2) {
+    hlo = kv; hhi = seg2_off; kv = seg2_off + kvlen2[bp];
+    if (hlo >= hhi) hlo = hhi = 0;
+  }
   float* p = S + row * ld;
   float mx = -INFINITY;
-  for (int c = lane; c < kv; c += 64) mx = fmaxf(mx, p[c]);
+  for (int c = lane; c < kv; c += 64)
+    if (c < hlo || c >= hhi) mx = fmaxf(mx, p[c]);
   mx = wave_max(mx);
   float sum = 0.f;
   for (int c = lane; c < kv; c += 64) {
-    const float e = expf(p[c] - mx);
+    const float e = (c < hlo || c >= hhi) ? expf(p[c] - mx) : 0.f;
     p[c] = e;
     sum += e;
   }
@@ -465,9 +471,9 @@ hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
-                               hipStream_t s) {
+                               hipStream_t s, const int32_t* kvlen2, int seg2_off) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, rows, ld, nseq, heads, kvlen_per_batch,
-                     kv_default);
+                     kv_default, kvlen2, seg2_off);
   return hipGetLastError();
 }
 hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s) {
@@ -482,7 +488,8 @@ namespace {
 // One thread owns 4 consecutive channels of one row; the dh/4 threads of a row sit in one wavefront and reduce with shuffles.
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(float* q32, float* k32, const float* __restrict__ wq, const float* __restrict__ wk,
                                                            const float* __restrict__ rope_cs, int64_t rows, int nseq, int heads, int dh,
-                                                           int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo) {
+                                                           int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo,
+                                                           int n1, const float* __restrict__ wq2, const float* __restrict__ wk2) {
   const int tpr = dh >> 2;                                     // threads per row (power of two, <= 64)
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t row = t / tpr;
@@ -495,10 +502,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(float* q32, float* k3
   for (int o = tpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   if (!live) return;
   const float r = rsqrtf(ss / (float)dh + eps);
-  const float4 g = *reinterpret_cast<const float4*>((which ? wk : wq) + d);
-  float x[4] = {v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w};
   const int64_t bh = row / nseq;
-  const int pos = (int)(row - bh * nseq), hh = (int)(bh % heads);
+  int pos = (int)(row - bh * nseq);
+  const int hh = (int)(bh % heads);
+  const bool second = n1 > 0 && pos >= n1;  // text-stream token of an MMDiT joint slab: own gains, positions restart at 0
+  if (second) pos -= n1;
+  const float4 g = *reinterpret_cast<const float4*>((second ? (which ? wk2 : wq2) : (which ? wk : wq)) + d);
+  float x[4] = {v.x * r * g.x, v.y * r * g.y, v.z * r * g.z, v.w * r * g.w};
   if (pe_heads < 0 || hh < pe_heads) {
     const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((int64_t)pos * (dh / 2) + d / 2) * 2);
     const float a0 = x[0] * cs.x - x[1] * cs.y, a1 = x[1] * cs.x + x[0] * cs.y;
@@ -545,12 +555,12 @@ __global__ void add_inplace_kernel(float* x, const float* __restrict__ y, int64_
 
 hipError_t launch_qk_norm_rope(float* q32, float* k32, const float* wq, const float* wk, const float* rope_cs, int64_t rows, int nseq,
                                int heads, int dh, int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo,
-                               hipStream_t s) {
+                               hipStream_t s, int n1, const float* wq2, const float* wk2) {
   const int tpr = dh / 4;
   if (dh % 4 || tpr < 1 || tpr > 64 || (tpr & (tpr - 1))) return hipErrorInvalidValue;
   const int64_t threads = rows * tpr;
   hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s, q32, k32, wq, wk, rope_cs, rows, nseq,
-                     heads, dh, pe_heads, qscale, eps, q16, q16_lo, k16, k16_lo);
+                     heads, dh, pe_heads, qscale, eps, q16, q16_lo, k16, k16_lo, n1, wq2, wk2);
   return hipGetLastError();
 }
 hipError_t launch_gather_seq_rows(const float* src, const int32_t* idx, int S, int B, int n, int C, float* out, hipStream_t s) {

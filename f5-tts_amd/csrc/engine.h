@@ -56,6 +56,11 @@ struct BlockW {  // per DiT block
   const float *g_attn = nullptr, *g_ff = nullptr, *wskip = nullptr;
   f16 *wskip_hi = nullptr, *wskip_pk = nullptr;
   const float *qn = nullptr, *kn = nullptr;  // qk_norm == rms_norm: RMSNorm gains over dim_head (modules.py:402-409)
+  // MMDiT only: the text ("context") stream of the block (modules.py:791-814); absent (null) in the last, context_pre_only block
+  const float *wqkv_c = nullptr, *bqkv_c = nullptr, *wo_c = nullptr, *bo_c = nullptr, *w1_c = nullptr, *b1_c = nullptr, *w2_c = nullptr,
+              *b2_c = nullptr, *qn_c = nullptr, *kn_c = nullptr;
+  f16 *wqkv_c_hi = nullptr, *wo_c_hi = nullptr, *w1_c_hi = nullptr, *w2_c_hi = nullptr;
+  f16 *wqkv_c_pk = nullptr, *wo_c_pk = nullptr, *w1_c_pk = nullptr, *w2_c_pk = nullptr;
 };
 struct TextBlockW {
   const float *dw_b, *ln_w, *ln_b, *pw1_w, *pw1_b, *gamma, *beta, *pw2_w, *pw2_b;
@@ -131,6 +136,10 @@ struct f5hip_ctx {
                                        // same slabs hold fp32 [rows, D] copies); DiT long_skip_connection: one such buffer
   const float* wlong = nullptr;        // DiT long_skip_connection.weight [D, 2D] (dit.py:228) and its fp16 operand copies
   f16 *wlong_hi = nullptr, *wlong_pk = nullptr;
+  // MMDiT: AdaLN tables of the text stream, its per-utterance embedding [2B*nt, D], its row mask [2B*nt] and valid-token counts [2B]
+  const float *adaln_c_w = nullptr, *adaln_c_b = nullptr;  // [(depth-1)*6D + 2D, D], [(depth-1)*6D + 2D]
+  DevBuf cmods, ctext0, cmask, kvlen2;
+  int ws_nt = 0;
   DevBuf avgidx;                       // text average upsampling: source token position per frame [B, n] int32, -1 = zero row
 
   // workspace (grow-only)
@@ -160,7 +169,7 @@ struct f5hip_ctx {
   // graph cache
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
-    int B = 0, n = 0, steps = 0, prec = -1, use_mask = 0, method = 0;
+    int B = 0, n = 0, nt = 0, steps = 0, prec = -1, use_mask = 0, method = 0;
     float* traj = nullptr;
     uint64_t ws_epoch = 0;
   } graph_key;

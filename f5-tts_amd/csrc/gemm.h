@@ -46,6 +46,7 @@ struct EpiStore {
   float* out2;
   const uint8_t* rowmask;
   int mask_mode;
+  int64_t smask;      // batch stride of rowmask: row m of batch z reads rowmask[(z / zdiv) * smask + m] (0 = shared by all batches)
   float* out32;
   f16* out16;
   f16* out16_lo;
@@ -73,7 +74,7 @@ struct EpiStore {
       const float4 c = *reinterpret_cast<const float4*>(colscale + n);
       x[0] *= c.x; x[1] *= c.y; x[2] *= c.z; x[3] *= c.w;
     }
-    const bool dead = rowmask && !rowmask[m];
+    const bool dead = rowmask && !rowmask[(zdiv ? (int64_t)(z / zdiv) * smask : 0) + m];
     if (dead && mask_mode == 1) { x[0] = x[1] = x[2] = x[3] = 0.f; }
     const int64_t zoff = zdiv ? (int64_t)(z / zdiv) * so1 + (int64_t)(z % zdiv) * so2 : 0;
     const int64_t o = zoff + (int64_t)m * ldo + n;
@@ -115,6 +116,8 @@ struct EpiQKV {
   f16 *q16_lo, *k16_lo, *vt16_lo;
   float *q32, *k32, *vt32;
   int64_t ldvt;
+  int slab_n, pos_off;  // MMDiT joint attention: the per-(batch', head) slabs hold slab_n tokens and this GEMM's sequences of nseq rows
+                        // land at token pos_off + pos (rope still uses pos); slab_n == 0 means slab_n = nseq, pos_off = 0
   int qk_raw;           // qk_norm variant: q and k leave as fp32 rows holding Wx + b only (q32/k32); qk_norm_rope_kernel finishes them
 
   __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
@@ -125,8 +128,9 @@ struct EpiQKV {
     const int bp = m / nseq, pos = m - bp * nseq;
     const float4 b = *reinterpret_cast<const float4*>(bias + n);
     float x[4] = {v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w};
+    const int sn = slab_n ? slab_n : nseq, tokp = pos_off + pos;  // slab length, token index inside the slab
     if (qk_raw && which < 2) {
-      float* dst = (which == 0 ? q32 : k32) + (((int64_t)bp * heads + hh) * nseq + pos) * dh + d;
+      float* dst = (which == 0 ? q32 : k32) + (((int64_t)bp * heads + hh) * sn + tokp) * dh + d;
       *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
       return;
     }
@@ -143,11 +147,11 @@ struct EpiQKV {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hv[e] = h; lv[e] = l; }
       if (which < 2) {
-        const int64_t off = (bh * nseq + pos) * dh + d;
+        const int64_t off = (bh * sn + tokp) * dh + d;
         *reinterpret_cast<f16x4*>((which == 0 ? q16 : k16) + off) = hv;
         if (q16_lo) *reinterpret_cast<f16x4*>((which == 0 ? q16_lo : k16_lo) + off) = lv;
       } else {
-        const int64_t off = (bh * dh + d) * ldvt + pos;
+        const int64_t off = (bh * dh + d) * ldvt + tokp;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           vt16[off + e * ldvt] = hv[e];
@@ -156,10 +160,10 @@ struct EpiQKV {
       }
     } else {
       if (which < 2) {
-        float* dst = (which == 0 ? q32 : k32) + (bh * nseq + pos) * dh + d;
+        float* dst = (which == 0 ? q32 : k32) + (bh * sn + tokp) * dh + d;
         *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
       } else {
-        float* dst = vt32 + (bh * dh + d) * ldvt + pos;
+        float* dst = vt32 + (bh * dh + d) * ldvt + tokp;
         dst[0] = x[0]; dst[ldvt] = x[1]; dst[2 * ldvt] = x[2]; dst[3 * ldvt] = x[3];
       }
     }

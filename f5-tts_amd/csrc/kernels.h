@@ -54,7 +54,8 @@ hipError_t launch_cfg_euler(const float* base, float* dst, const float* v, int64
 // (hi/lo) planes); gather of text rows per sequence (idx [B, n], -1 = zero row; cond and uncond halves share it); x += y
 hipError_t launch_qk_norm_rope(float* q32, float* k32, const float* wq, const float* wk, const float* rope_cs, int64_t rows, int nseq,
                                int heads, int dh, int pe_heads, float qscale, float eps, f16* q16, f16* q16_lo, f16* k16, f16* k16_lo,
-                               hipStream_t s);
+                               hipStream_t s, int n1 = 0, const float* wq2 = nullptr, const float* wk2 = nullptr);
+// n1 > 0 (MMDiT joint slabs): tokens >= n1 of every slab belong to the text stream — gains wq2 / wk2, rope position = token - n1
 hipError_t launch_gather_seq_rows(const float* src, const int32_t* idx, int S, int B, int n, int C, float* out, hipStream_t s);
 hipError_t launch_add_inplace(float* x, const float* y, int64_t n, hipStream_t s);
 // sinusoidal time embedding (reference model/modules.py:157-169): t [S] -> out [S, 256]
@@ -71,7 +72,7 @@ hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32
 hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s);
 // row softmax for the exact (materialised-score) attention: S [rows, ld], cols >= kvlen(row) get 0
 hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
-                               hipStream_t s);
+                               hipStream_t s, const int32_t* kvlen2 = nullptr, int seg2_off = 0);  // second key run: see launch_flash_attn
 // im2col for the Vocos embed conv (k=7, pad 3): mel [B, T, Cin] (frame-major) -> col [B*T, 7*Cin] with k index = ci*7 + tap
 hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s);
 
@@ -92,7 +93,8 @@ bool flash_attn_available();
 hipError_t init_attention_kernels();
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s,
-                             int o_packed = 0);
+                             int o_packed = 0, const int32_t* kvlen2 = nullptr, int seg2_off = 0);
+// kvlen2 / seg2_off: a second run of valid keys [seg2_off, seg2_off + kvlen2[b']) behind [0, kvlen[b']) (MMDiT joint attention mask)
 
 // ---- audio.hip --------------------------------------------------------------------------------
 struct AudioTables {

@@ -81,7 +81,7 @@ class F5HipEngine:
                        text_mask_padding=int(dit_cfg.text_mask_padding),
                        pe_attn_head=-1 if dit_cfg.pe_attn_head is None else int(dit_cfg.pe_attn_head),
                        attn_mask_enabled=int(dit_cfg.attn_mask_enabled), conv_pos_kernel=dit_cfg.conv_pos_kernel,
-                       conv_pos_groups=dit_cfg.conv_pos_groups, backbone=1 if dit_cfg.backbone == "UNetT" else 0,
+                       conv_pos_groups=dit_cfg.conv_pos_groups, backbone={"DiT": 0, "UNetT": 1, "MMDiT": 2}[dit_cfg.backbone],
                        qk_norm={None: 0, "rms_norm": 1}[dit_cfg.qk_norm],  # KeyError == the reference's ValueError (modules.py:409)
                        long_skip_connection=int(dit_cfg.long_skip_connection),
                        text_average_upsampling=int(dit_cfg.text_embedding_average_upsampling),

@@ -55,7 +55,10 @@ typedef struct f5hip_dit_config {
   int32_t attn_mask_enabled;   /* bool: key-padding mask inside attention */
   int32_t conv_pos_kernel, conv_pos_groups;
   int32_t backbone;            /* 0 = DiT (F5-TTS, dit.py), 1 = UNetT (E2-TTS, reference src/f5_tts/model/backbones/unett.py:108-307:
-                                  time embedding as a prepended token, x_transformers RMSNorm pre-norm, concat skip connections) */
+                                  time embedding as a prepended token, x_transformers RMSNorm pre-norm, concat skip connections),
+                                  2 = MMDiT (reference src/f5_tts/model/backbones/mmdit.py:91-262: the text is a second token stream of its
+                                  own length nt with its own weights; every block attends jointly over [n audio frames | nt text tokens];
+                                  requires text_dim == dim, conv_layers == 0, pe_attn_head == -1) */
   /* optional constructor switches no shipped yaml enables (dit.py:181-189, unett.py:120-127); all 0 for the released models.
    * qk_norm applies to both backbones (UNetT keys: layers.{i}.2.q_norm.weight). */
   int32_t qk_norm;               /* 0 = None, 1 = "rms_norm": RMSNorm(dim_head, eps 1e-6) on q and k before rope (modules.py:402-409,493-496);
