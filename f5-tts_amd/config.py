@@ -120,6 +120,7 @@ PRESETS = {
     "F5TTS_Small": F5TTS_SMALL,
     "E2TTS_Small": E2TTS_SMALL,
     "tiny48": replace(DIT_TINY, dim=768, heads=12),  # 48 channels per conv group (768 / 16), like the Small models, at depth 2
+    "tiny_inner512": replace(DIT_TINY, heads=8),  # attention width heads*dim_head = 512 != dim = 256 (modules.py:397-400)
     "tiny_flags": DIT_TINY_FLAGS,
     "tiny_qknorm": replace(DIT_TINY, qk_norm="rms_norm"),
     "tiny_longskip": replace(DIT_TINY, long_skip_connection=True),

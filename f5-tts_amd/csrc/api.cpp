@@ -1369,7 +1369,7 @@ const char* f5hip_last_error(const f5hip_ctx* ctx) { return ctx ? ctx->err.c_str
 int f5hip_create(const f5hip_dit_config* dc, const f5hip_vocos_config* vc, int device, f5hip_ctx** out) {
   if (!dc || !out) { g_create_err = "null argument"; return F5HIP_ERR_INVALID; }
   const auto bad = [&](const char* m) { g_create_err = m; return F5HIP_ERR_INVALID; };
-  if (dc->dim <= 0 || dc->depth <= 0 || dc->heads * dc->dim_head != dc->dim) return bad("dim must equal heads*dim_head and be > 0");
+  if (dc->dim <= 0 || dc->depth <= 0 || dc->heads <= 0) return bad("dim, depth and heads must be > 0");  // heads*dim_head may differ from dim (modules.py:397-400)
   if (dc->dim_head != 64) return bad("dim_head must be 64 (attention kernels are built for dh=64)");
   if (dc->dim % 4 || dc->text_dim % 4 || dc->mel_dim % 4 || dc->ff_inner % 8 || dc->dim % 8) return bad("dim/text_dim/mel_dim/ff_inner alignment");
   if (dc->conv_pos_groups <= 0 || dc->dim % dc->conv_pos_groups) return bad("conv_pos_groups must divide dim");
