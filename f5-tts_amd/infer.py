@@ -158,8 +158,8 @@ def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos"
     """reference utils_infer.py:238-276.  ``model_cfg``: a preset name ("F5TTS_v1_Base", "F5TTS_Base", "E2TTS_Base"), a ``DiTConfig``
     or the reference's ``model.arch`` dict.  The returned object quacks like the reference's ``CFM`` on the inference path; its
     engine also hosts the vocoder (``load_vocoder(engine=model.engine, ...)``)."""
-    if mel_spec_type != "vocos":
-        raise ValueError("only the vocos mel front-end / vocoder is built (BigVGAN's source is absent upstream of the reference tree)")
+    if mel_spec_type not in ("vocos", "bigvgan"):
+        raise ValueError("mel_spec_type must be vocos or bigvgan (modules.py:127)")
     vocab_char_map, vocab_size = (get_tokenizer(vocab_file, "custom") if vocab_file else (None, None))
     if isinstance(model_cfg, str):
         cfg = PRESETS[model_cfg]
@@ -179,7 +179,9 @@ def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos"
         load_checkpoint(engine, ckpt_path, use_ema=use_ema)
     if vocos_cfg is None:
         engine.finalize()
-    return F5HipCFM(engine, vocab_char_map=vocab_char_map, ode_method=ode_method, precision=precision)
+    # mel_spec_type="bigvgan": the BigVGAN-type mel front-end runs on the engine; the BigVGAN generator itself is not built (its source is
+    # an un-vendored submodule of the reference) — infer_batch_process then calls the caller's own ``vocoder(mel)`` (utils_infer.py:512-513)
+    return F5HipCFM(engine, vocab_char_map=vocab_char_map, ode_method=ode_method, precision=precision, mel_spec_type=mel_spec_type)
 
 
 def load_vocoder(vocoder_name: str = "vocos", is_local: bool = True, local_path: str = "", engine: Optional[F5HipEngine] = None,
@@ -290,9 +292,12 @@ def infer_batch_process(ref_audio, ref_text: str, gen_text_batches: Sequence[str
         generated, _ = model_obj.sample(cond=audio, text=final_text_list, duration=duration, steps=nfe_step, cfg_strength=cfg_strength,
                                         sway_sampling_coef=sway_sampling_coef, seed=seed)
         generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
-        if mel_spec_type != "vocos":
-            raise ValueError("only the vocos vocoder is built")
-        wave_out = vocoder.decode(generated)
+        if mel_spec_type == "vocos":
+            wave_out = vocoder.decode(generated)
+        elif mel_spec_type == "bigvgan":  # a caller-supplied generator module (utils_infer.py:512-513); none is built here
+            wave_out = vocoder(generated)
+        else:
+            raise ValueError("mel_spec_type must be vocos or bigvgan")
         if rms < target_rms:
             wave_out = wave_out * rms / target_rms
         return wave_out.squeeze().cpu().numpy(), generated

@@ -109,6 +109,34 @@ def test_bigvgan_mel_matches_reference_golden(engines):
         eng.mel(wav.cuda(), mel_spec_type="hifigan")  # modules.py:127
 
 
+def test_bigvgan_type_sampler_and_glue(engines):
+    """BASELINE configs[4] pairs E2-TTS with the BigVGAN-type mel: CFM.sample on a raw wave then uses get_bigvgan_mel_spectrogram
+    (cfm.py:106-109 -> modules.py:138-151).  The generator itself is the caller's module (utils_infer.py:512-513)."""
+    from f5_tts_amd import infer as I
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.UNETT_TINY
+    eng = engines("tiny_unett", 3)
+    sd = synth.synth_dit_state_dict(cfg, seed=3)
+    wav = synth.synth_wave(256 * 50, seed=6)
+    text = synth.synth_text_ids(1, 30, cfg.text_num_embeds, seed=4)
+    kw = dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)
+    model = F5HipCFM(eng, mel_spec_type="bigvgan")
+    out, _ = model.sample(wav.cuda(), text, 140, **kw)
+    ref, _ = O.cfm_sample(sd, cfg, wav, text, 140, mel_spec_type="bigvgan", **kw)
+    assert out.shape == ref.shape == (1, 140, 100) and maxerr(out, ref) < TIGHT
+    seen = {}
+
+    def generator(mel):  # stands in for the BigVGAN module: [b, 100, T] -> [b, 1, 256 T]
+        seen["shape"] = tuple(mel.shape)
+        return mel.mean(dim=1, keepdim=True).repeat_interleave(256, dim=-1)
+
+    model.vocab_char_map = {c: i for i, c in enumerate(VOCAB)}
+    wave, sr, spec = next(iter(I.infer_batch_process((wav, 24000), "some call me nature.", ["others call me mother nature."], model, generator,
+                                                     mel_spec_type="bigvgan", nfe_step=4, seed=1)))
+    assert sr == 24000 and seen["shape"][1] == 100 and wave.shape[0] == 256 * seen["shape"][2]
+
+
 @pytest.mark.parametrize("nw", [513, 1024, 256 * 20, 256 * 20 + 255, 24000 * 3 + 17])
 def test_mel_edge_lengths(engines, nw):
     eng = engines("tiny", 1)
