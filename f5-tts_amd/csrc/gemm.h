@@ -26,6 +26,10 @@ struct GemmCore {
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
   int w_rows;         // rows of W that exist (<= N)
   int group_m;        // tile rasterisation: row-tiles per group (0/1 = channel tiles fastest over the whole grid), see gemm_kernel
+  // stream-K schedule for small grids (gemm_sk.h): workspace of sk_grid x 128 KB partial-tile slots followed by sk_grid + 1 ints
+  // (flags, error word), owned by the caller and private to one stream; null = plain tiled launch only
+  void* sk_ws;
+  int sk_grid;        // resident workgroups to spread the work over (multiple of 8)
 };
 
 // Generic store epilogue:
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
     }
   };
   auto mma_step = [&](const Frag (&fa)[NPL][TM], const Frag (&fw)[NPL][TN]) {
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);  // favour the wave that is feeding the matrix pipe over its SIMD partner's loads
+    if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(1);  // favour the wave that is feeding the matrix pipe over its SIMD partner's loads
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -486,10 +490,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
         Mma32<T>::mma(acc[j][i], fw[0][i], fa[0][j]);
         if constexpr (NPL == 2) {
           Mma32<T>::mma(acc[j][i], fw[0][i], fa[1][j]);
-          Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);
+          if constexpr (!(PRIO & 2)) Mma32<T>::mma(acc[j][i], fw[1][i], fa[0][j]);  // PRIO bit 1 (microbenchmark only): 2 of the 3 products
         }
       }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    if constexpr (PRIO & 1) __builtin_amdgcn_s_setprio(0);
   };
   auto compute = [&](int stage) {
     const uint32_t sA = lds0 + stage * STAGE + (wm * 32 * TM) * GEMM_KTB;

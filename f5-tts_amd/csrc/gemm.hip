@@ -3,6 +3,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "gemm_sk.h"
 
 namespace {
 
@@ -92,7 +93,11 @@ int pick_variant(const GemmCore& g, int batch) {
   const int64_t big = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
   // many waves of tiles: the 256x256 / 8-wave LDS-DMA tile (128x64 per wave) stages and reads the fewest LDS bytes per MFMA —
   // the LDS pipe, not the matrix pipe, is what the 128x128 tile saturates first (+10-16 % at M >= 22k in both fp16 modes)
-  if (big >= 1024 && g.M >= 16384 && g.N >= 1024 && batch == 1 && g.K % 32 == 0) return 21;
+  if (big >= 1024 && g.M >= 65536 && g.N >= 1024 && batch == 1 && g.K % 32 == 0) return 21;
+  // a few thousand to a few ten thousand rows (B = 2..16): 128x256 with 8 waves of 64x64 and a 3-stage ring (one workgroup per CU, two
+  // waves per SIMD sharing one LDS tile: 0.9 KB of LDS traffic per MFMA against 1.5 KB for two independent 4-wave 128x64 tiles) —
+  // 10-17 % faster than both the 256x256 tile (too few tiles, one k-tile in flight) and the 128x128 / 128x64 tiles at M = 11k-22k
+  if (g.M >= 8192 && g.N >= 1024 && batch == 1 && g.K % 32 == 0) return 31;  // in situ: -6 % end to end at B = 4 and 8, nothing at B = 2
   if (big >= 1024) return 2;
   // small grids: the direct-to-LDS ring (variant 6) wins where the tile count is lowest (N <= 1024: out-projection, FF2: -10 %),
   // the register-staged kernel elsewhere (tools/kernel_bench.py, B=1)
@@ -115,6 +120,36 @@ hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, s, g, e);
+  return hipGetLastError();
+}
+
+// stream-K launch (gemm_sk.h): 8 waves of 64x64, 256x128 (ROWS256) or 128x256 tile, grid = g.sk_grid resident workgroups
+constexpr int64_t SK_SLOT_BYTES = 512 * 4 * 16 * 4;  // 8 waves x 64 lanes x (2x2 tiles x 16 regs) fp32
+template <typename T, int NSPLIT, typename Epi, bool ROWS256>
+hipError_t launch_sk(const GemmCore& g, const Epi& e, hipStream_t s) {
+  constexpr int WGM = ROWS256 ? 4 : 2, WGN = ROWS256 ? 2 : 4, BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, 2, 2, WGM, WGN, 3>();
+  auto kern = gemm_sk_kernel<T, NSPLIT, 2, 2, Epi, WGM, WGN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    attr_done = true;
+  }
+  if (!g.sk_ws || g.sk_grid < 8 || (g.sk_grid & 7)) return hipErrorInvalidValue;
+  if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
+    return hipErrorInvalidValue;
+  SkArgs sk{};
+  sk.ws = reinterpret_cast<float*>(g.sk_ws);
+  sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(g.sk_ws) + (int64_t)g.sk_grid * SK_SLOT_BYTES);
+  sk.err = sk.flags + g.sk_grid;
+  static const bool dbg_env = getenv("F5HIP_SK_DEBUG") != nullptr;  // microbenchmark only: the caller sized the workspace for the stamps
+  sk.dbg = dbg_env ? reinterpret_cast<long long*>(sk.err + 2) : nullptr;
+  sk.tiles_n = (g.N + BN - 1) / BN;
+  sk.tiles = ((g.M + BM - 1) / BM) * sk.tiles_n;
+  const int kbytes = g.K * (int)sizeof(T) * (NSPLIT == 3 ? 2 : 1);
+  sk.kt = (kbytes + GEMM_KTB - 1) / GEMM_KTB;
+  hipLaunchKernelGGL(kern, dim3(g.sk_grid), dim3(512), lds, s, g, e, sk);
   return hipGetLastError();
 }
 
@@ -147,6 +182,17 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 14: return launch_glds<T, NSPLIT, 2, 4, Epi>(g, e, batch, s);  // 128x256, 4 waves of 64x128
     case 21: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2>(g, e, batch, s);  // 256x256, 8 waves of 128x64, 2-stage ring
     case 22: return launch_glds<T, NSPLIT, 2, 4, Epi, 4, 2, 2>(g, e, batch, s);  // 256x256, 8 waves of 64x128, 2-stage ring
+    // wave tile 64x64 (2/3 of the LDS fragment bytes per MFMA of the 64x32 wave tile of variant 6) at unchanged workgroup tile counts
+    case 26: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 1, 3>(g, e, batch, s);  // 128x64, 2 waves of 64x64, 3-stage ring (72 KB: 2 WG/CU)
+    case 27: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 1, 2>(g, e, batch, s);  // 128x64, 2 waves of 64x64, 2-stage ring (48 KB: 3 WG/CU)
+    case 28: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 2, 2>(g, e, batch, s);  // 128x128, 4 waves of 64x64, 2-stage ring (64 KB: 2 WG/CU)
+    case 29: return launch_glds<T, NSPLIT, 2, 2, Epi, 1, 2, 3>(g, e, batch, s);  // 64x128, 2 waves of 64x64, 3-stage ring
+    case 30: return launch_glds<T, NSPLIT, 2, 2, Epi, 4, 2, 3>(g, e, batch, s);  // 256x128, 8 waves of 64x64, 3-stage ring (144 KB, 1 WG/CU)
+    case 31: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 4, 3>(g, e, batch, s);  // 128x256, 8 waves of 64x64, 3-stage ring
+    case 40: return launch_sk<T, NSPLIT, Epi, true>(g, e, s);   // stream-K, 256x128 tiles
+    case 41: return launch_sk<T, NSPLIT, Epi, false>(g, e, s);  // stream-K, 128x256 tiles
+    case 24: return launch_glds<T, NSPLIT, 2, 1, Epi, 2, 2, 3, 2>(g, e, batch, s);     // ablation: variant 6 with 2 of the 3 fp16x3 products
+    case 25: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 2>(g, e, batch, s);     // ablation: variant 21 with 2 of the 3 fp16x3 products
     case 23: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 1>(g, e, batch, s);  // variant 21 + s_setprio around the MFMA clusters
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);

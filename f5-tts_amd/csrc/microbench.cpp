@@ -87,6 +87,14 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   g.A = op == OP_F32 ? (const void*)a32 : (const void*)ah;
   g.W = op == OP_F32 ? (const void*)w32 : (const void*)wh;
   g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
+  if (variant == 40 || variant == 41) {  // stream-K: private workspace (grid x 128 KB slots + flags + error word), zeroed flags
+    const char* gv = getenv("KB_SKGRID");
+    g.sk_grid = gv ? atoi(gv) : 256;
+    const size_t slots = (size_t)g.sk_grid * 131072, total = slots + ((size_t)g.sk_grid + 2) * sizeof(int) + (size_t)g.sk_grid * 64;
+    char* ws = t.get<char>(total);
+    if (!ws || hipMemsetAsync(ws + slots, 0, total - slots, s) != hipSuccess) return F5HIP_ERR_HIP;
+    g.sk_ws = ws;
+  }
   EpiStore e{};
   e.alpha = 1.f; e.bias = bias; e.ldo = N; e.ldres = N;
   if (epilogue == 2) {  // out-proj / FF2: x += gate * (acc + bias), fp32 residual stream
@@ -97,7 +105,38 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
     if (op == OP_F32) e.out32 = o32;
     else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = 1; e.ldo16 = 2 * (int64_t)N; } }
   }
-  return time_it([&] { return launch_gemm_store_variant(op, g, e, 1, variant, s); }, iters, s, avg_ms);
+  if (getenv("KB_CHECK") && epilogue != 2) {  // compare this variant's output with the plain 128x64 tiling (variant 1), bit for bit
+    const size_t nb = op == OP_F32 ? (size_t)M * N * 4 : (size_t)M * N * pl * 2;
+    void* outp = op == OP_F32 ? (void*)o32 : (void*)oh;
+    std::vector<unsigned char> ref(nb), got(nb);
+    if (hipMemsetAsync(outp, 0, nb, s) != hipSuccess || launch_gemm_store_variant(op, g, e, 1, 1, s) != hipSuccess ||
+        hipMemcpyAsync(ref.data(), outp, nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return F5HIP_ERR_HIP;
+    for (int rep = 0; rep < 3; ++rep) {
+      if (hipMemsetAsync(outp, 0, nb, s) != hipSuccess || launch_gemm_store_variant(op, g, e, 1, variant, s) != hipSuccess ||
+          hipMemcpyAsync(got.data(), outp, nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return F5HIP_ERR_HIP;
+      size_t bad = 0, first = 0;
+      for (size_t i = 0; i < nb; ++i)
+        if (ref[i] != got[i]) { if (!bad) first = i; ++bad; }
+      int errw = 0;
+      if (g.sk_ws) (void)hipMemcpy(&errw, reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * 131072 + (size_t)g.sk_grid * sizeof(int), sizeof(int), hipMemcpyDeviceToHost);
+      fprintf(stderr, "KB_CHECK variant %d rep %d: %zu of %zu bytes differ from variant 1 (first at %zu), sk err word %d\n", variant, rep, bad, nb, first, errw);
+    }
+  }
+  const int rc = time_it([&] { return launch_gemm_store_variant(op, g, e, 1, variant, s); }, iters, s, avg_ms);
+  if (g.sk_ws && getenv("F5HIP_SK_DEBUG")) {  // phase stamps of the last launch (10 ns ticks relative to the earliest start)
+    std::vector<long long> st((size_t)g.sk_grid * 8);
+    (void)hipMemcpy(st.data(), reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * 131072 + ((size_t)g.sk_grid + 2) * sizeof(int), st.size() * 8, hipMemcpyDeviceToHost);
+    long long t0 = st[0];
+    for (int b = 0; b < g.sk_grid; ++b) if (st[(size_t)b * 8] && st[(size_t)b * 8] < t0) t0 = st[(size_t)b * 8];
+    for (int b = 0; b < g.sk_grid && b < 48; b += (b < 8 ? 8 : 8)) {
+      fprintf(stderr, "sk wg %3d:", b);
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " %7.2f", st[(size_t)b * 8 + k] ? (st[(size_t)b * 8 + k] - t0) * 0.01 : -1.0);
+      fprintf(stderr, " us\n");
+    }
+  }
+  return rc;
 }
 
 // flash attention over [batch2 * heads, n, 64]; precision FP16 -> plain fp16 operands, FP16X3 -> hi/lo split

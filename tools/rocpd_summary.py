@@ -60,6 +60,44 @@ def main(path):
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"| `{k}` | {a[0]} | {a[1] / 1e6:.3f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / tot:.2f} |")
     print(f"\ntotal kernel time {tot / 1e6:.3f} ms over {len(rows)} dispatches")
+    timeline(rows)
+
+
+def timeline(rows):
+    """GPU occupancy over the densest part of the trace (the NFE loops): time with 0 / 1 / >= 2 kernels resident, the gap between
+    consecutive kernels, and the share of wall time that is not covered by any kernel (launch latency, drain, cache write-back)."""
+    ev = sorted((s, e) for _, s, e in rows)
+    if len(ev) < 100:
+        return
+    # the trace has long idle stretches (python, weight upload): keep the dispatches whose predecessor ended < 200 us earlier
+    segs, cur = [], [ev[0]]
+    last_end = ev[0][1]
+    for s, e in ev[1:]:
+        if s - last_end > 200_000:
+            segs.append(cur)
+            cur = []
+        cur.append((s, e))
+        last_end = max(last_end, e)
+    segs.append(cur)
+    segs = [g for g in segs if len(g) >= 500]
+    if not segs:
+        return
+    print("\n### timeline (bursts of >= 500 dispatches with no idle stretch > 200 us)\n")
+    print("| burst | dispatches | wall ms | no kernel | 1 kernel | >= 2 kernels | median gap us (serial part) |")
+    print("|---:|---:|---:|---:|---:|---:|---:|")
+    for bi, g in enumerate(segs):
+        pts = []
+        for s, e in g:
+            pts.append((s, 1)); pts.append((e, -1))
+        pts.sort()
+        depth, t_prev, occ = 0, pts[0][0], [0, 0, 0]
+        for t, d in pts:
+            occ[min(depth, 2)] += t - t_prev
+            depth += d
+            t_prev = t
+        wall = pts[-1][0] - pts[0][0]
+        gaps = sorted(max(0, g[i + 1][0] - g[i][1]) for i in range(len(g) - 1))
+        print(f"| {bi} | {len(g)} | {wall / 1e6:.2f} | {100 * occ[0] / wall:.1f} % | {100 * occ[1] / wall:.1f} % | {100 * occ[2] / wall:.1f} % | {gaps[len(gaps) // 2] / 1e3:.2f} |")
 
 
 if __name__ == "__main__":
