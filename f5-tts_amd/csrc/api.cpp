@@ -811,7 +811,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
                                  ctx->k16.as<f16>() + qoff, x3 ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
                                  x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
-                                 kvlen2, seg2_off));
+                                 kvlen2, seg2_off));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
+                                                      // (the two chains are rarely in attention at the same time)
       }
     }
   return F5HIP_OK;

@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int QB = 128;              // query rows per workgroup
+constexpr int QB = 128;              // query rows per workgroup (4 waves); the 6-wave variant takes 192
 constexpr int KT = 64;               // keys per tile
 constexpr int K_ROWB = 144;          // K tile LDS row: 64 halves + 16 B pad (conflict-free 32-row ds_read_b128)
 constexpr int V_ROWB = 136;          // V^T tile LDS row: 64 halves + 8 B pad (conflict-free 32-row ds_read_b64)
@@ -48,8 +48,11 @@ constexpr int flash_lds_bytes() {
   return 2 * ((NSPLIT == 3 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
 }
 
-template <int NSPLIT, int PVSPLIT>
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
+// NW: waves per workgroup = 32-row query groups per block.  4 (128 query rows, two workgroups per CU) everywhere except where 6
+// (192 rows, one workgroup per CU) makes the grid fit the chip in ONE round: B = 1, N = 1406 gives 11 x 32 = 352 blocks of 128 rows
+// (CUs with 2 and CUs with 1 workgroup: 69 % balance) but 8 x 32 = 256 blocks of 192 rows.  Only the first 4 waves stage K / V tiles.
+template <int NSPLIT, int PVSPLIT, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(FlashArgs a) {
   constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
   if constexpr (NPV == 2) Vr[1] = make_rsrc(a.vt_lo + (int64_t)bh * 64 * a.ldv, v_bytes);
 
   // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]
-  const int qrow = qb * QB + wave * 32 + ql;
+  const int qrow = qb * (32 * NW) + wave * 32 + ql;
   Frag fq[NPL][4];
 #pragma unroll
   for (int p = 0; p < NPL; ++p)
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
   }
   uint4 rk0[NPL][2], rv0[NPV][2], rk1[NPL][2], rv1[NPV][2];
   auto load_global = [&](int t, uint4 (&rk)[NPL][2], uint4 (&rv)[NPV][2]) {
+    if (NW > 4 && wave >= 4) return;  // waves 4.. only compute
     const uint32_t key0 = (uint32_t)t * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
     }
   };
   auto store_lds = [&](int stage, const uint4 (&rk)[NPL][2], const uint4 (&rv)[NPV][2]) {
+    if (NW > 4 && wave >= 4) return;
     char* base = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -275,15 +280,29 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FlashArgs a) {
 }
 
 template <int NSPLIT, int PVSPLIT>
-hipError_t launch(const FlashArgs& a, hipStream_t s) {
+hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   constexpr int lds = flash_lds_bytes<NSPLIT, PVSPLIT>();
-  auto kern = flash_attn_kernel<NSPLIT, PVSPLIT>;
-  hipLaunchKernelGGL(kern, dim3(a.nwg), dim3(256), lds, s, a);
+  static const int nw_env = [] { const char* v = getenv("F5HIP_ATTN_WAVES"); return v ? atoi(v) : 0; }();  // tuning knob: 4 or 6
+  const int nqb6 = (a.n + 191) / 192, nqb4 = (a.n + QB - 1) / QB;
+  // 192-row blocks when they (times the `co` identical launches that run concurrently: the cond / uncond chains) fit the chip in one
+  // round of one workgroup per CU and the 128-row blocks neither fit one round nor fill two per CU
+  const int e4 = bh * co * nqb4, e6 = bh * co * nqb6;
+  const bool six = nw_env ? nw_env == 6 : (e6 <= 256 && e4 > 256 && e4 < 512);
+  if (six) {
+    a.nqb = nqb6; a.nwg = bh * nqb6;
+    hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6>), dim3(a.nwg), dim3(384), lds, s, a);
+  } else {
+    a.nqb = nqb4; a.nwg = bh * nqb4;
+    hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4>), dim3(a.nwg), dim3(256), lds, s, a);
+  }
   return hipGetLastError();
 }
 template <int NSPLIT, int PVSPLIT>
 hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     flash_lds_bytes<NSPLIT, PVSPLIT>());
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              flash_lds_bytes<NSPLIT, PVSPLIT>());
 }
 
@@ -300,22 +319,21 @@ hipError_t init_attention_kernels() {
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed,
-                             const int32_t* kvlen2, int seg2_off) {
+                             const int32_t* kvlen2, int seg2_off, int co_launches) {
   FlashArgs a{};
   a.o_packed = o_packed;
   a.kvlen2 = kvlen2; a.seg2_off = seg2_off;
   a.q = q; a.q_lo = q_lo; a.k = k; a.k_lo = k_lo; a.vt = vt; a.vt_lo = vt_lo;
   a.o = o16; a.o_lo = o16_lo; a.kvlen = kvlen;
   a.n = n; a.ldv = ldv; a.heads = heads;
-  a.nqb = (n + QB - 1) / QB;
-  a.nwg = Bp * heads * a.nqb;
+  const int bh = Bp * heads;
   if (nsplit == 3) {  // hi/lo q, k, v, P
     if (!q_lo || !k_lo || !vt_lo) return hipErrorInvalidValue;
-    return launch<3, 3>(a, s);
+    return launch<3, 3>(a, bh, co_launches < 1 ? 1 : co_launches, s);
   }
   if (nsplit == 2) {  // hi/lo q and k (scores), plain fp16 P and V
     if (!q_lo || !k_lo) return hipErrorInvalidValue;
-    return launch<3, 1>(a, s);
+    return launch<3, 1>(a, bh, co_launches < 1 ? 1 : co_launches, s);
   }
-  return launch<1, 1>(a, s);
+  return launch<1, 1>(a, bh, co_launches < 1 ? 1 : co_launches, s);
 }
