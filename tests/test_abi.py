@@ -73,3 +73,31 @@ def test_create_rejects_bad_config():
                            conv_layers=2, text_mask_padding=1, pe_attn_head=-1, attn_mask_enabled=0, conv_pos_kernel=31, conv_pos_groups=16)
     ctx = C.c_void_p()
     assert lib.f5hip_create(C.byref(c), None, 0, C.byref(ctx)) == 1  # F5HIP_ERR_INVALID before touching any device
+
+
+def test_config_structs_match_the_header():
+    """Field order of the ctypes structs == field order of the C structs in include/f5hip.h (all int32)."""
+    src = open(HEADER).read()
+    for cname, pyc in (("f5hip_dit_config", binding.DitConfigC), ("f5hip_vocos_config", binding.VocosConfigC)):
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", src, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in re.findall(r"int32_t\s+([^;]+);", body):
+            fields += [f.strip() for f in decl.split(",")]
+        assert fields == [n for n, _ in pyc._fields_], cname
+
+
+@pytest.mark.parametrize("bad", [dict(qk_norm=2), dict(text_average_upsampling=1, text_mask_padding=0), dict(skip_connect_type=1),
+                                 dict(backbone=1, long_skip_connection=1, conv_layers=0), dict(backbone=2, conv_layers=0, text_dim=128),
+                                 dict(backbone=2, conv_layers=0, text_dim=256, pe_attn_head=1), dict(backbone=3), dict(skip_connect_type=3, backbone=1, conv_layers=0)])
+def test_create_rejects_bad_switches(bad):
+    """The constructor-switch combinations the reference itself refuses (dit.py:43, modules.py:409) or that do not exist."""
+    lib = binding.load_library()
+    import ctypes as C
+
+    kw = dict(dim=256, depth=2, heads=4, dim_head=64, ff_inner=512, mel_dim=100, text_num_embeds=255, text_dim=128, conv_layers=2,
+              text_mask_padding=1, pe_attn_head=-1, attn_mask_enabled=0, conv_pos_kernel=31, conv_pos_groups=16)
+    kw.update(bad)
+    ctx = C.c_void_p()
+    assert lib.f5hip_create(C.byref(binding.DitConfigC(**kw)), None, 0, C.byref(ctx)) == 1
+    assert lib.f5hip_last_error(None)
