@@ -101,3 +101,11 @@ def test_create_rejects_bad_switches(bad):
     ctx = C.c_void_p()
     assert lib.f5hip_create(C.byref(binding.DitConfigC(**kw)), None, 0, C.byref(ctx)) == 1
     assert lib.f5hip_last_error(None)
+
+
+def test_graft_entry_build_check_runs():
+    """__graft_entry__.build() is what the driver runs on the CPU box every round: it must pass against the in-tree library."""
+    import importlib
+
+    g = importlib.import_module("__graft_entry__")
+    g.build()
