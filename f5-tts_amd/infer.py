@@ -11,7 +11,8 @@ working when ``load_model`` / ``load_vocoder`` hand back the HIP adapters (INTEG
   cross-fade, streaming generator.
 
 No numerics of the hot path live here: every ``sample`` / ``decode`` call goes to ``libf5hip.so`` through ``engine.py``.
-Not built (host-only, needs packages that are absent offline): ``preprocess_ref_audio_text`` (pydub silence trimming, whisper ASR).
+``preprocess_ref_audio_text`` / ``remove_silence_edges`` (``utils_infer.py:279-378``) live in ``refaudio.py`` (pydub's silence logic
+restated on PCM .wav files; the Whisper ASR fallback is a caller-supplied callable) and are re-exported here.
 """
 from __future__ import annotations
 
@@ -27,6 +28,7 @@ import torch
 
 from .config import HOP_LENGTH, PRESETS, TARGET_SAMPLE_RATE, VOCOS_MEL_24K, DiTConfig, VocosConfig
 from .engine import F5HipCFM, F5HipEngine, F5HipVocos, filter_vocos_keys, map_checkpoint_keys
+from .refaudio import preprocess_ref_audio_text, remove_silence_edges  # noqa: F401  (same import surface as utils_infer.py)
 
 # defaults of the reference module (utils_infer.py:52-65)
 target_sample_rate = TARGET_SAMPLE_RATE
