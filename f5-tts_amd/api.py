@@ -1,0 +1,125 @@
+"""``F5TTS`` — the reference's one-class Python API (reference ``src/f5_tts/api.py:23-149``) on top of the HIP engine.
+
+Same constructor / ``infer`` / ``export_wav`` / ``export_spectrogram`` surface.  Differences, all forced by the offline box and stated
+where they bite: the architecture comes from ``config.PRESETS`` (the reference reads the same numbers from its Hydra yaml,
+``api.py:35-40``); checkpoints are never downloaded (``api.py:77-80``): pass ``ckpt_file`` / ``vocoder_local_path`` (or in-memory state
+dicts); ``transcribe`` needs a caller-supplied ASR callable; ``.wav`` files are written with the standard library as 16-bit PCM
+(the reference uses ``soundfile``); the spectrogram picture needs matplotlib, otherwise the array is saved as ``.npy``.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import wave
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import infer as I
+from .config import PRESETS, VOCOS_MEL_24K, VocosConfig
+from .refaudio import PcmSegment, preprocess_ref_audio_text, split_on_silence
+
+
+def seed_everything(seed: int = 0) -> None:
+    """reference src/f5_tts/model/utils.py:19-26 (the cudnn switches have no counterpart here)."""
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def remove_silence_for_generated_wav(filename: str) -> None:
+    """reference utils_infer.py:599-608: drop every pause longer than 1 s (keeping 0.5 s on each side), in place."""
+    aseg = PcmSegment.from_file(filename)
+    out = PcmSegment.silent(duration=0)
+    for seg in split_on_silence(aseg, min_silence_len=1000, silence_thresh=-50, keep_silence=500, seek_step=10):
+        out = out + seg
+    out.export(filename, format="wav")
+
+
+def save_spectrogram(spectrogram, path: str) -> str:
+    """reference utils_infer.py:614-619; without matplotlib the mel is saved next to the requested path as .npy."""
+    try:
+        import matplotlib
+
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except Exception:
+        out = os.path.splitext(path)[0] + ".npy"
+        np.save(out, np.asarray(spectrogram))
+        return out
+    plt.figure(figsize=(12, 4))
+    plt.imshow(spectrogram, origin="lower", aspect="auto")
+    plt.colorbar()
+    plt.savefig(path)
+    plt.close()
+    return path
+
+
+class F5TTS:
+    def __init__(self, model: str = "F5TTS_v1_Base", ckpt_file: str = "", vocab_file: str = "", ode_method: str = "euler", use_ema: bool = True,
+                 vocoder_local_path: Optional[str] = None, device=None, hf_cache_dir=None, *, precision: str = "fp16x3",
+                 mel_spec_type: str = "vocos", vocos_cfg: VocosConfig = VOCOS_MEL_24K,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, vocoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 transcribe: Optional[Callable[[str], str]] = None):
+        if model not in PRESETS:
+            raise ValueError(f"unknown model {model!r}; known: {sorted(PRESETS)}")
+        self.mel_spec_type = mel_spec_type
+        self.target_sample_rate = I.target_sample_rate
+        self.ode_method, self.use_ema = ode_method, use_ema
+        self.device = 0 if device is None else device  # the engine only runs on a HIP device (reference api.py:45-58 falls back to cpu)
+        self._transcribe = transcribe
+        if not ckpt_file and state_dict is None:
+            raise ValueError("no network here: pass ckpt_file (the reference would download hf://SWivid/..., api.py:77-80)")
+        if mel_spec_type == "vocos" and vocoder_local_path is None and vocoder_state_dict is None:
+            raise ValueError("no network here: pass vocoder_local_path (a directory with pytorch_model.bin, utils_infer.py:110-118)")
+        self.ema_model = I.load_model(model, ckpt_file or None, mel_spec_type, vocab_file, ode_method, use_ema, self.device, precision=precision,
+                                      vocos_cfg=vocos_cfg if mel_spec_type == "vocos" else None, state_dict=state_dict)
+        if mel_spec_type == "vocos":
+            self.vocoder = I.load_vocoder("vocos", vocoder_local_path is not None, vocoder_local_path or "", engine=self.ema_model.engine,
+                                          state_dict=vocoder_state_dict)
+        else:  # bigvgan-type mel: the generator is the caller's module (its source is not part of the reference tree)
+            self.vocoder = None
+        self.seed = None
+
+    def transcribe(self, ref_audio, language=None):
+        if self._transcribe is None:
+            raise ValueError("the Whisper ASR pipeline of the reference (utils_infer.py:150-186) is not available offline: pass transcribe=")
+        return self._transcribe(ref_audio)
+
+    def export_wav(self, wav, file_wave: str, remove_silence: bool = False) -> None:
+        pcm = (np.clip(np.asarray(wav, dtype=np.float32), -1.0, 1.0) * 32767.0).astype("<i2")
+        with wave.open(file_wave, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(self.target_sample_rate)
+            w.writeframes(pcm.tobytes())
+        if remove_silence:
+            remove_silence_for_generated_wav(file_wave)
+
+    def export_spectrogram(self, spec, file_spec: str) -> str:
+        return save_spectrogram(spec, file_spec)
+
+    def infer(self, ref_file, ref_text, gen_text, show_info=print, progress=None, target_rms=0.1, cross_fade_duration=0.15,
+              sway_sampling_coef=-1, cfg_strength=2, nfe_step=32, speed=1.0, fix_duration=None, remove_silence=False, file_wave=None,
+              file_spec=None, seed=None, vocoder=None):
+        """reference api.py:98-149.  ``seed`` also reaches every chunk's ``sample`` call, which makes multi-chunk requests reproducible
+        under the thread pool (the reference only seeds the global generator)."""
+        if seed is None:
+            seed = random.randint(0, sys.maxsize)
+        seed_everything(seed)
+        self.seed = seed
+        ref_file, ref_text = preprocess_ref_audio_text(ref_file, ref_text, show_info=show_info, transcribe=self._transcribe)
+        wav, sr, spec = I.infer_process(ref_file, ref_text, gen_text, self.ema_model, vocoder if vocoder is not None else self.vocoder,
+                                        self.mel_spec_type, show_info=show_info, progress=progress, target_rms=target_rms,
+                                        cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
+                                        sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=self.device,
+                                        seed=seed % (2**63))
+        if file_wave is not None:
+            self.export_wav(wav, file_wave, remove_silence)
+        if file_spec is not None:
+            self.export_spectrogram(spec, file_spec)
+        return wav, sr, spec

@@ -484,6 +484,41 @@ def test_infer_process_matches_oracle_glue(tmp_path):
 
 
 # ---- size-independent properties at BASELINE.json's full sizes, long sequences, degenerate text --------------------------------
+def test_f5tts_api_class(tmp_path):
+    """The reference's one-class API (api.py:23-149) over the engine: preprocess the prompt file, chunk, sample, vocode, cross-fade,
+    export; the same seed gives the same wave."""
+    import wave as wavemod
+
+    from f5_tts_amd import api as A
+
+    cfg = config.DIT_TINY
+    vocab = _write_vocab(tmp_path)
+    from dataclasses import replace
+
+    cfg = replace(cfg, text_num_embeds=len(VOCAB))
+    sd = synth.synth_dit_state_dict(cfg, seed=5)
+    vsd = synth.synth_vocos_state_dict(config.VOCOS_TINY, seed=1)
+    A.PRESETS["tiny_vocab"] = cfg
+    try:
+        tts = A.F5TTS(model="tiny_vocab", vocab_file=vocab, device=0, precision="fp32", vocos_cfg=config.VOCOS_TINY, state_dict=sd,
+                      vocoder_state_dict=vsd)
+    finally:
+        A.PRESETS.pop("tiny_vocab", None)
+    ref = tmp_path / "ref.wav"
+    pcm = (synth.synth_wave(24000 * 2, seed=4)[0].numpy() * 32767).astype("<i2")
+    with wavemod.open(str(ref), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes(pcm.tobytes())
+    kw = dict(ref_file=str(ref), ref_text="some call me nature", gen_text="others call me mother nature.", nfe_step=4, show_info=lambda m: None)
+    out_file = tmp_path / "gen.wav"
+    w1, sr, spec = tts.infer(seed=11, file_wave=str(out_file), **kw)
+    w2, _, _ = tts.infer(seed=11, **kw)
+    assert sr == 24000 and w1.ndim == 1 and np.isfinite(w1).all() and spec.shape[0] == 100
+    assert np.array_equal(w1, w2) and tts.seed == 11
+    with wavemod.open(str(out_file), "rb") as w:
+        assert w.getframerate() == 24000 and w.getnframes() == w1.shape[0]
+    tts.ema_model.engine.close()
+
+
 def test_full_size_batch_rows_equal_single_utterance():
     """F5-TTS Base at full size: a fixed-length batch of identical utterances (packed cond+uncond launches, M = 2*B*N rows) must give
     every row the result of the B=1 call (cond / uncond branches on two streams, M = N rows per launch) — same arithmetic, different

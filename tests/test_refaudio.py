@@ -94,3 +94,23 @@ def test_missing_transcript_needs_a_transcriber(tmp_path):
     with pytest.raises(ValueError):
         R.preprocess_ref_audio_text(p, "  ", show_info=lambda m: None)
     assert R.preprocess_ref_audio_text(p, "", show_info=lambda m: None, transcribe=lambda path: "hello world")[1] == "hello world. "
+
+
+def test_api_helpers_cpu(tmp_path):
+    """The CPU-side pieces of the F5TTS API class (reference api.py): constructor argument errors, wav export, silence removal."""
+    from f5_tts_amd import api as A
+
+    with pytest.raises(ValueError):
+        A.F5TTS(model="nope", ckpt_file="x")
+    with pytest.raises(ValueError):
+        A.F5TTS(model="tiny")  # no checkpoint and no network
+    tts = object.__new__(A.F5TTS)
+    tts.target_sample_rate = SR
+    wav = np.concatenate([tone(1.0), silence(2.5), tone(1.0)]).astype(np.float32) / 32768.0
+    out = str(tmp_path / "o.wav")
+    tts.export_wav(wav, out)
+    assert abs(read_len_ms(out) - 4500) < 1
+    tts.export_wav(wav, out, remove_silence=True)  # the 2.5 s pause shrinks to 0.5 s + 0.5 s of kept silence
+    assert abs(read_len_ms(out) - 3000) <= 20
+    saved = tts.export_spectrogram(np.zeros((100, 7), np.float32), str(tmp_path / "s.png"))
+    assert os.path.isfile(saved)
