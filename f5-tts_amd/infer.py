@@ -344,3 +344,54 @@ def infer_process(ref_audio, ref_text: str, gen_text: str, model_obj, vocoder, m
                                     target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
                                     cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, speed=speed,
                                     fix_duration=fix_duration, device=device, seed=seed))
+
+
+# ---- speech editing (reference src/f5_tts/infer/speech_edit.py:139-235) --------------------------------------------------------------
+def build_edit_condition(original_mel: torch.Tensor, parts_to_edit: Sequence[Sequence[float]], fix_duration: Optional[Sequence[float]] = None,
+                         sample_rate: int = target_sample_rate, hop: int = hop_length) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Frame-level conditioning of an edit: the original mel with every [start, end] span (seconds) replaced by zero frames of the wanted
+    length (``fix_duration`` per span, else the span's own length), and the mask of frames to KEEP (speech_edit.py:154-200).
+    original_mel [1, frames, mel] -> (mel_cond [1, frames', mel], edit_mask bool [1, frames'])."""
+    dev, mel = original_mel.device, original_mel.shape[-1]
+    mel_cond = torch.zeros(1, 0, mel, device=dev)
+    edit_mask = torch.zeros(1, 0, dtype=torch.bool, device=dev)
+    fix = list(fix_duration) if fix_duration is not None else None
+    offset = 0
+    for start, end in parts_to_edit:
+        dur = end - start if fix is None else fix.pop(0)
+        start_f, end_f, dur_f = round(start * sample_rate / hop), round(end * sample_rate / hop), round(dur * sample_rate / hop)
+        mel_cond = torch.cat((mel_cond, original_mel[:, offset:start_f, :], torch.zeros(1, dur_f, mel, device=dev)), dim=1)
+        edit_mask = torch.cat((edit_mask, torch.ones(1, start_f - offset, dtype=torch.bool, device=dev),
+                               torch.zeros(1, dur_f, dtype=torch.bool, device=dev)), dim=-1)
+        offset = end_f
+    mel_cond = torch.cat((mel_cond, original_mel[:, offset:, :]), dim=1)
+    edit_mask = torch.nn.functional.pad(edit_mask, (0, mel_cond.shape[1] - edit_mask.shape[-1]), value=True)
+    return mel_cond, edit_mask
+
+
+def speech_edit(model_obj, vocoder, audio, sr: int, target_text: str, parts_to_edit: Sequence[Sequence[float]],
+                fix_duration: Optional[Sequence[float]] = None, mel_spec_type: str = "vocos", nfe_step: int = 32, cfg_strength: float = 2.0,
+                sway_sampling_coef: Optional[float] = -1.0, seed: Optional[int] = None, target_rms: float = target_rms,
+                tokenizer: str = "pinyin"):
+    """The body of the reference's speech_edit.py script as a function: regenerate the given time spans of ``audio`` so that the whole
+    utterance reads ``target_text``; everything outside the spans is kept (``edit_mask``).  Returns (wave [1, n], mel [1, mel, frames])."""
+    audio = torch.as_tensor(audio, dtype=torch.float32)
+    if audio.ndim == 1:
+        audio = audio[None]
+    if audio.shape[0] > 1:
+        audio = audio.mean(dim=0, keepdim=True)
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < target_rms:
+        audio = audio * target_rms / rms
+    if sr != target_sample_rate:
+        audio = resample(audio, sr, target_sample_rate)
+    original_mel = model_obj.mel_spec(audio.to(model_obj.device)).permute(0, 2, 1)  # mel of the clean original first (speech_edit.py:148-152)
+    mel_cond, edit_mask = build_edit_condition(original_mel, parts_to_edit, fix_duration)
+    text_list = convert_char_to_pinyin([target_text]) if tokenizer == "pinyin" else [[target_text]]
+    generated, _ = model_obj.sample(cond=mel_cond, text=text_list, duration=mel_cond.shape[1], steps=nfe_step, cfg_strength=cfg_strength,
+                                    sway_sampling_coef=sway_sampling_coef, seed=seed, edit_mask=edit_mask)
+    gen_mel = generated.to(torch.float32).permute(0, 2, 1)
+    wave_out = vocoder.decode(gen_mel) if mel_spec_type == "vocos" else vocoder(gen_mel).squeeze(0)
+    if rms < target_rms:
+        wave_out = wave_out * rms / target_rms
+    return wave_out.cpu(), gen_mel.cpu()

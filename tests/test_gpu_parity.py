@@ -484,6 +484,34 @@ def test_infer_process_matches_oracle_glue(tmp_path):
 
 
 # ---- size-independent properties at BASELINE.json's full sizes, long sequences, degenerate text --------------------------------
+def test_speech_edit_matches_oracle(engines):
+    """speech_edit.py as a function: mel of the original, zero frames + edit_mask for the edited spans, sample, vocode — against the
+    oracle run on the same condition."""
+    from f5_tts_amd import infer as I
+    from f5_tts_amd.engine import F5HipCFM, F5HipVocos
+
+    cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
+    eng = engines("tiny", 1, vocos=True)
+    sd, vsd = synth.synth_dit_state_dict(cfg, seed=1), synth.synth_vocos_state_dict(vcfg, seed=1)
+    model = F5HipCFM(eng, vocab_char_map={c: i for i, c in enumerate(VOCAB)})
+    wav = synth.synth_wave(24000 * 2, seed=9)
+    parts, fix = [[0.4, 0.8], [1.2, 1.5]], [0.5, 0.2]
+    text = "some call me nature, others do not."
+    wave_out, mel_out = I.speech_edit(model, F5HipVocos(eng), wav, 24000, text, parts, fix, nfe_step=6, seed=3)
+    rms = torch.sqrt(torch.mean(torch.square(wav)))
+    wav_n = wav * 0.1 / rms if rms < 0.1 else wav  # the script's RMS normalisation (speech_edit.py:141-143)
+    cond, mask = I.build_edit_condition(O.vocos_mel(wav_n).permute(0, 2, 1), parts, fix)
+    ids = torch.tensor([[model.vocab_char_map.get(c, 0) for c in I.convert_char_to_pinyin([text])[0]]])
+    ref, _ = O.cfm_sample(sd, cfg, cond, ids, cond.shape[1], steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3, edit_mask=mask)
+    n = cond.shape[1]  # CFM.sample raises the duration to lens + 1 (cfm.py:135-137), exactly as it does for the reference script
+    assert ref.shape == (1, n + 1, 100) and mel_out.shape == (1, 100, n + 1) and maxerr(mel_out.permute(0, 2, 1), ref) < TIGHT
+    assert maxerr(mel_out.permute(0, 2, 1)[:, :n][mask], cond[mask]) < 1e-4  # kept frames are the original mel
+    wref = O.vocos_decode(vsd, ref.permute(0, 2, 1), vcfg.num_layers)
+    if rms < 0.1:
+        wref = wref * rms / 0.1
+    assert wave_out.shape == wref.shape and maxerr(wave_out, wref) < 1e-3 * max(1.0, float(wref.abs().max()))
+
+
 def test_f5tts_api_class(tmp_path):
     """The reference's one-class API (api.py:23-149) over the engine: preprocess the prompt file, chunk, sample, vocode, cross-fade,
     export; the same seed gives the same wave."""

@@ -98,3 +98,29 @@ def test_get_tokenizer(tmp_path):
     vocab, n = I.get_tokenizer(str(p))
     assert n == 4 and vocab[" "] == 0 and vocab["zh1"] == 3
     assert I.get_tokenizer("", "byte") == (None, 256)
+
+
+def test_build_edit_condition_matches_the_reference_script():
+    """Frame bookkeeping of speech_edit.py:154-200 (kept frames, zero frames of the wanted length, mask), against a literal re-run of
+    the script's loop."""
+    import torch
+
+    from f5_tts_amd import infer as I
+
+    mel = torch.arange(1 * 300 * 4, dtype=torch.float32).reshape(1, 300, 4)
+    parts, fix = [[0.5, 1.0], [2.0, 2.6]], [0.3, 0.9]
+    cond, mask = I.build_edit_condition(mel, parts, fix)
+    # literal restatement
+    off, ref_c, ref_m = 0, [], []
+    for (s0, e0), d in zip(parts, fix):
+        sf, ef, df = round(s0 * 24000 / 256), round(e0 * 24000 / 256), round(d * 24000 / 256)
+        ref_c += [mel[:, off:sf], torch.zeros(1, df, 4)]
+        ref_m += [torch.ones(1, sf - off, dtype=torch.bool), torch.zeros(1, df, dtype=torch.bool)]
+        off = ef
+    ref_c.append(mel[:, off:])
+    ref_c = torch.cat(ref_c, 1)
+    ref_m = torch.cat(ref_m + [torch.ones(1, ref_c.shape[1] - sum(x.shape[1] for x in ref_m), dtype=torch.bool)], 1)
+    assert torch.equal(cond, ref_c) and torch.equal(mask, ref_m)
+    assert cond.shape[1] == 300 - (round(1.0 * 93.75) - round(0.5 * 93.75)) - (round(2.6 * 93.75) - round(2.0 * 93.75)) + round(0.3 * 93.75) + round(0.9 * 93.75)
+    cond2, mask2 = I.build_edit_condition(mel, parts)  # spans keep their own length
+    assert cond2.shape[1] == 300 and int((~mask2).sum()) == (round(1.0 * 93.75) - round(0.5 * 93.75)) + (round(2.6 * 93.75) - round(2.0 * 93.75))
