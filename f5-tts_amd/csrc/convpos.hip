@@ -16,7 +16,12 @@ struct ConvCfg {
   static constexpr int ROWB = CPG * (int)sizeof(T) + 16;         // LDS row bytes (padded)
   static constexpr int KSTEPS = CPG * (int)sizeof(T) / 32;       // 32-byte k-steps per tap
   static constexpr int WROWS = COT * 32;
-  static constexpr int WPLANE = WROWS * ROWB;
+  // weight tile rows: when a row is exactly one 128-byte line (fp16, 64 channels per group: the Base models) they are stored UNPADDED
+  // with the 16-byte chunk index XOR-swizzled by (row & 7) — conflict-free fragment reads like the padded layout, and 4 KB less LDS
+  // per workgroup, which is what lets TWO workgroups share a CU (80.4 KB -> 76.4 KB; 160 KB per CU)
+  static constexpr bool WSWZ = CPG * (int)sizeof(T) == 128;
+  static constexpr int WROWB = WSWZ ? 128 : ROWB;
+  static constexpr int WPLANE = WROWS * WROWB;
   static constexpr int WSTAGE = NPL * WPLANE;
 };
 
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         const int r = c / CPR, cc = c - r * CPR;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-          *reinterpret_cast<uint4*>(sW + stage * C::WSTAGE + p * C::WPLANE + r * C::ROWB + cc * 16) = rw[p][i];
+          *reinterpret_cast<uint4*>(sW + stage * C::WSTAGE + p * C::WPLANE + r * C::WROWB + ((C::WSWZ ? (cc ^ (r & 7)) : cc) << 4)) = rw[p][i];
       }
     }
   };
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
   const int koff = (lane >> 5) * 16;
   for (int tap = 0; tap < K; ++tap) {
     if (tap + 1 < K) load_w(tap + 1);
-    const char* wbase = sW + (tap & 1) * C::WSTAGE + (lane & 31) * C::ROWB + koff;
+    const char* wbase = sW + (tap & 1) * C::WSTAGE + (lane & 31) * C::WROWB;  // + chunk offset (swizzled per row) below
+    const int wrow7 = lane & 7;                                               // (row & 7) of rows lane&31 + 32 i
     const char* xbase = sX + (wave * 32 + (lane & 31) + tap) * C::ROWB + koff;
 #pragma unroll
     for (int ks = 0; ks < C::KSTEPS; ++ks) {
@@ -115,7 +121,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         fx[p].u = *reinterpret_cast<const uint4*>(xbase + p * xplane + ks * 32);
 #pragma unroll
         for (int i = 0; i < C::COT; ++i)
-          fw[p][i].u = *reinterpret_cast<const uint4*>(wbase + p * C::WPLANE + i * 32 * C::ROWB + ks * 32);
+          fw[p][i].u = *reinterpret_cast<const uint4*>(wbase + p * C::WPLANE + i * 32 * C::WROWB +
+                                                       (C::WSWZ ? (((2 * ks + (lane >> 5)) ^ wrow7) << 4) : koff + ks * 32));
       }
 #pragma unroll
       for (int i = 0; i < C::COT; ++i) {
