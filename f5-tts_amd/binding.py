@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
 
-ABI_VERSION = 3  # F5HIP_ABI_VERSION in include/f5hip.h
+ABI_VERSION = 4  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 
@@ -27,6 +27,14 @@ class DitConfigC(C.Structure):
 
 class VocosConfigC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("input_channels", "dim", "intermediate_dim", "num_layers", "n_fft", "hop_length")]
+
+
+class BigVGANConfigC(C.Structure):
+    _fields_ = [("num_mels", C.c_int32), ("num_upsamples", C.c_int32), ("upsample_initial_channel", C.c_int32),
+                ("upsample_rates", C.c_int32 * 8), ("upsample_kernel_sizes", C.c_int32 * 8), ("resblock", C.c_int32),
+                ("num_kernels", C.c_int32), ("resblock_kernel_sizes", C.c_int32 * 4), ("resblock_num_dilations", C.c_int32 * 4),
+                ("resblock_dilation_sizes", (C.c_int32 * 4) * 4), ("activation", C.c_int32), ("snake_logscale", C.c_int32),
+                ("use_tanh_at_final", C.c_int32), ("use_bias_at_final", C.c_int32)]
 
 
 # every symbol include/f5hip.h declares: name -> (restype, argtypes)
@@ -53,6 +61,15 @@ SYMBOLS = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "f5hip_reset_kernel_stats": (C.c_int, [_P]),
     "f5hip_bench_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "f5hip_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfigC), C.c_int, C.POINTER(_P)]),
+    "f5hip_bigvgan_destroy": (C.c_int, [_P]),
+    "f5hip_bigvgan_last_error": (C.c_char_p, [_P]),
+    "f5hip_bigvgan_num_tensors": (C.c_int, [_P]),
+    "f5hip_bigvgan_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "f5hip_bigvgan_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "f5hip_bigvgan_finalize": (C.c_int, [_P]),
+    "f5hip_bigvgan_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "f5hip_bigvgan_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "f5hip_bench_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 
@@ -83,10 +100,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     return lib
 
 
-def check(lib: C.CDLL, ctx, status: int) -> None:
+def check(lib: C.CDLL, ctx, status: int, last_error=None) -> None:
     if status == 0:
         return
-    msg = lib.f5hip_last_error(ctx)
+    msg = (last_error or lib.f5hip_last_error)(ctx)
     text = msg.decode("utf-8", "replace") if msg else "unknown error"
     # mirror the reference's error behaviour: bad shapes/arguments are ValueError (asserts in cfm.py:109,124),
     # everything else RuntimeError

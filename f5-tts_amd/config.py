@@ -7,8 +7,9 @@ Mirrors the ``model.arch`` / ``model.mel_spec`` blocks of the reference's Hydra 
 """
 from __future__ import annotations
 
+import math
 from dataclasses import asdict, dataclass, replace
-from typing import Optional
+from typing import Optional, Tuple
 
 # mel front-end constants: reference src/f5_tts/infer/utils_infer.py:52-58
 TARGET_SAMPLE_RATE = 24000
@@ -79,6 +80,32 @@ class VocosConfig:
     hop_length: int = HOP_LENGTH
 
 
+@dataclass(frozen=True)
+class BigVGANConfig:
+    """``config.json`` of nvidia/bigvgan_v2_24khz_100band_256x, the generator the reference pairs with ``mel_spec_type="bigvgan"``
+    (reference src/f5_tts/infer/utils_infer.py:130-144).  The generator source is an un-vendored submodule of the reference
+    (``.gitmodules:1-3``); field names are upstream's (NVIDIA/BigVGAN ``bigvgan.py`` / ``config.json``)."""
+    num_mels: int = N_MEL_CHANNELS
+    upsample_rates: Tuple[int, ...] = (4, 4, 2, 2, 2, 2)
+    upsample_kernel_sizes: Tuple[int, ...] = (8, 8, 4, 4, 4, 4)
+    upsample_initial_channel: int = 1536
+    resblock: str = "1"                                  # "1": AMPBlock1 (convs1 + convs2), "2": AMPBlock2
+    resblock_kernel_sizes: Tuple[int, ...] = (3, 7, 11)
+    resblock_dilation_sizes: Tuple[Tuple[int, ...], ...] = ((1, 3, 5), (1, 3, 5), (1, 3, 5))
+    activation: str = "snakebeta"                        # "snake" | "snakebeta"
+    snake_logscale: bool = True
+    use_tanh_at_final: bool = False
+    use_bias_at_final: bool = False
+
+    @property
+    def hop(self) -> int:
+        return math.prod(self.upsample_rates)
+
+    def channels(self, stage: int) -> int:
+        """channels after upsampling stage `stage` (0-based)"""
+        return self.upsample_initial_channel // (2 ** (stage + 1))
+
+
 F5TTS_V1_BASE = DiTConfig()  # api/cli default (reference src/f5_tts/api.py:26)
 # E2-TTS: flat U-Net transformer (reference src/f5_tts/model/backbones/unett.py:108-186, configs/E2TTS_Base.yaml:25-31):
 # text_dim defaults to mel_dim, no ConvNeXt text blocks, ff_mult 4, rope on head 0 only, concat skip connections
@@ -108,6 +135,14 @@ MMDIT_SMALL = DiTConfig(dim=512, depth=16, heads=16, dim_head=32, ff_mult=2, tex
                         backbone="MMDiT")
 VOCOS_MEL_24K = VocosConfig()
 VOCOS_TINY = VocosConfig(dim=128, intermediate_dim=384, num_layers=2)
+BIGVGAN_V2_24K_100B_256X = BigVGANConfig()
+# reduced sizes for the parity tests: two stages (x4, x2), 64 -> 32 -> 16 channels, and a three-stage one that ends in 24 / 12
+# channels (rows that are not a multiple of the 32-element operand block) with AMPBlock2 / plain snake / tanh / final bias
+BIGVGAN_TINY = BigVGANConfig(num_mels=20, upsample_rates=(4, 2), upsample_kernel_sizes=(8, 4), upsample_initial_channel=64,
+                             resblock_kernel_sizes=(3, 7), resblock_dilation_sizes=((1, 3), (1, 3)))
+BIGVGAN_TINY2 = BigVGANConfig(num_mels=20, upsample_rates=(2, 2, 2), upsample_kernel_sizes=(4, 4, 4), upsample_initial_channel=96,
+                              resblock="2", resblock_kernel_sizes=(3, 11), resblock_dilation_sizes=((1, 5), (1, 3, 5)),
+                              activation="snake", snake_logscale=False, use_tanh_at_final=True, use_bias_at_final=True)
 
 PRESETS = {
     "F5TTS_v1_Base": F5TTS_V1_BASE,

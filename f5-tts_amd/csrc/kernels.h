@@ -111,3 +111,17 @@ hipError_t launch_istft_frames(const float* logits, int64_t ld, int B, int T, co
                                float* frames, hipStream_t s);
 // overlap-add + envelope normalisation + centre trim: frames [B, T, 1024] -> wav [B, 256*(T-1)]
 hipError_t launch_istft_ola(const float* frames, const float* window, int B, int T, float* wav, hipStream_t s);
+
+// ---- bigvgan.hip ------------------------------------------------------------------------------
+// BigVGAN generator path, channels-last fp32 activations [B, L, C] (see bigvgan.hip for the formulas each kernel evaluates).
+// Activation1d (x2 upsample -> Snake/SnakeBeta -> x2 downsample) with the host-computed 12-tap kaiser-sinc filter `filt12` (HOST pointer)
+hipError_t launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* filt12, int B, int L, int C,
+                           int logscale, hipStream_t s);
+// tap-gathered GEMM operand: out[(b, l), j * cpad + c] = src[b, l + shift0 + j * dstep, c] or 0, in operand layout `op` (OP_*);
+// sb / sl / sc = element strides of src (batch, time step, channel); ldo / ob = row / batch stride of out in elements of its type
+hipError_t launch_im2col_taps(const float* src, int64_t sb, int64_t sl, int64_t sc, int B, int L, int C, int ntaps, int shift0, int dstep,
+                              int cpad, int op, void* out, int64_t ldo, int64_t ob, hipStream_t s);
+// out = (r[0] + ... + r[nk-1]) / nk over n floats (n % 4 == 0, nk <= 4)
+hipError_t launch_mean_streams(const float* const* r, int nk, int64_t n, float* out, hipStream_t s);
+// Conv1d(C -> 1, k 7, pad 3) + tanh or clamp(-1, 1): y [B, L, C], w7 [7, C] tap-major, bias [1] or null -> out [B, L]
+hipError_t launch_conv_post(const float* y, const float* w7, const float* bias, int B, int L, int C, int use_tanh, float* out, hipStream_t s);

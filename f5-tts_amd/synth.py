@@ -17,7 +17,7 @@ from typing import Dict
 
 import torch
 
-from .config import DiTConfig, VocosConfig
+from .config import BigVGANConfig, DiTConfig, VocosConfig
 
 
 def _normal(g: torch.Generator, shape, std: float) -> torch.Tensor:
@@ -165,6 +165,55 @@ def synth_vocos_state_dict(cfg: VocosConfig, seed: int = 0) -> Dict[str, torch.T
     sd["head.out.weight"] = _normal(g, (cfg.n_fft + 2, C), 0.5 / math.sqrt(C))
     sd["head.out.bias"] = _normal(g, (cfg.n_fft + 2,), 0.1)
     sd["head.istft.window"] = torch.hann_window(cfg.n_fft)
+    return sd
+
+
+def synth_bigvgan_state_dict(cfg: BigVGANConfig, seed: int = 0, raw_weight_norm: bool = False) -> Dict[str, torch.Tensor]:
+    """Random-init BigVGAN generator weights with upstream's key names (NVIDIA/BigVGAN ``bigvgan.py``), activations of O(1) through
+    all stages.  ``raw_weight_norm``: the checkpoint spelling BEFORE ``remove_weight_norm()`` (``weight_g`` / ``weight_v``)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(9000011 * seed + 31)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, k, bias=True, transpose=False, gain=1.0):
+        fan = cin * k if not transpose else cin * k / max(1, cfg.upsample_rates[int(name.split(".")[1])])
+        w = torch.randn((cin, cout, k) if transpose else (cout, cin, k), generator=g) * (gain / math.sqrt(fan))
+        if raw_weight_norm:
+            norm = w.reshape(w.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+            sd[name + ".weight_g"] = norm * (1.0 + 0.1 * torch.randn(norm.shape, generator=g))
+            sd[name + ".weight_v"] = w * (0.5 + torch.rand(norm.shape, generator=g))
+        else:
+            sd[name + ".weight"] = w
+        if bias:
+            sd[name + ".bias"] = 0.1 * torch.randn(cout, generator=g)
+
+    def act(name, ch):
+        sd[name + ".act.alpha"] = 0.3 * torch.randn(ch, generator=g) if cfg.snake_logscale else 1.0 + 0.2 * torch.randn(ch, generator=g).abs()
+        if cfg.activation == "snakebeta":
+            sd[name + ".act.beta"] = 0.3 * torch.randn(ch, generator=g) if cfg.snake_logscale else 1.0 + 0.2 * torch.randn(ch, generator=g).abs()
+
+    c0 = cfg.upsample_initial_channel
+    conv("conv_pre", c0, cfg.num_mels, 7)
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        cin, ch = c0 // (2 ** i), c0 // (2 ** (i + 1))
+        conv(f"ups.{i}.0", ch, cin, k, transpose=True)
+        for j in range(nk):
+            pfx = f"resblocks.{i * nk + j}"
+            nd = len(cfg.resblock_dilation_sizes[j])
+            if cfg.resblock == "1":
+                for m in range(nd):
+                    conv(f"{pfx}.convs1.{m}", ch, ch, cfg.resblock_kernel_sizes[j], gain=0.7)
+                    conv(f"{pfx}.convs2.{m}", ch, ch, cfg.resblock_kernel_sizes[j], gain=0.5)
+                for q in range(2 * nd):
+                    act(f"{pfx}.activations.{q}", ch)
+            else:
+                for m in range(nd):
+                    conv(f"{pfx}.convs.{m}", ch, ch, cfg.resblock_kernel_sizes[j], gain=0.5)
+                    act(f"{pfx}.activations.{m}", ch)
+    chl = c0 // (2 ** len(cfg.upsample_rates))
+    act("activation_post", chl)
+    conv("conv_post", 1, chl, 7, bias=cfg.use_bias_at_final, gain=0.5)
     return sd
 
 

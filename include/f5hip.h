@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 3
+#define F5HIP_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -157,6 +157,51 @@ int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, voi
  * mel: device fp32; channel_major != 0 -> [batch, 100, frames] (the reference's call layout), else [batch, frames, 100].
  * out: device fp32 [batch, 256 * (frames - 1)] (torch.istft(center=True) length). */
 int f5hip_vocos_decode(f5hip_ctx* ctx, const float* mel, int batch, int frames, int channel_major, float* out, void* stream);
+
+/* ---- BigVGAN generator (mel_spec_type "bigvgan") -------------------------------------------------- */
+/* replaces: the object load_vocoder(vocoder_name="bigvgan") returns — bigvgan.BigVGAN.from_pretrained(...), .remove_weight_norm(),
+ * .eval() (reference utils_infer.py:130-144) — and its call `vocoder(mel)` (utils_infer.py:512-513).  The generator's source is an
+ * un-vendored submodule of the reference (.gitmodules:1-3, NVIDIA/BigVGAN, src/third_party/BigVGAN is empty): field and tensor
+ * names below are upstream's (bigvgan.py, config.json of nvidia/bigvgan_v2_24khz_100band_256x); parity is pinned only against
+ * this repo's CPU restatement of the published algorithm (oracle/bigvgan_oracle.py), see DESIGN.md.
+ * A separate context type: the reference's vocoder is a separate object too. */
+typedef struct f5hip_bigvgan_config {
+  int32_t num_mels, num_upsamples, upsample_initial_channel;
+  int32_t upsample_rates[8], upsample_kernel_sizes[8];
+  int32_t resblock;                 /* 1 = AMPBlock1 (convs1 + convs2), 2 = AMPBlock2 (convs) */
+  int32_t num_kernels;              /* parallel resblocks per stage (<= 4) */
+  int32_t resblock_kernel_sizes[4];
+  int32_t resblock_num_dilations[4];
+  int32_t resblock_dilation_sizes[4][4];
+  int32_t activation;               /* 0 = "snake", 1 = "snakebeta" */
+  int32_t snake_logscale, use_tanh_at_final, use_bias_at_final;   /* bools */
+} f5hip_bigvgan_config;
+
+typedef struct f5hip_bigvgan f5hip_bigvgan;
+
+int f5hip_bigvgan_create(const f5hip_bigvgan_config* cfg, int device, f5hip_bigvgan** out);
+int f5hip_bigvgan_destroy(f5hip_bigvgan* v);
+/* last error text of this context (or of the failed f5hip_bigvgan_create when v == NULL); never NULL */
+const char* f5hip_bigvgan_last_error(const f5hip_bigvgan* v);
+/* replaces: generator.load_state_dict(...) inside from_pretrained + remove_weight_norm().  `name` is the generator state-dict key
+ * AFTER weight-norm removal ("conv_pre.weight", "ups.0.0.weight", "resblocks.0.convs1.0.bias", "resblocks.0.activations.0.act.alpha",
+ * "activation_post.act.beta", "conv_post.weight", ...); the host binding folds weight_g / weight_v.  `data`: fp32 HOST memory. */
+int f5hip_bigvgan_num_tensors(const f5hip_bigvgan* v);
+int f5hip_bigvgan_tensor_info(const f5hip_bigvgan* v, int index, const char** name, int64_t* numel);
+int f5hip_bigvgan_load_tensor(f5hip_bigvgan* v, const char* name, const float* data, int64_t numel);
+/* after every tensor is loaded: builds the GEMM weight matrices (a Conv1d / ConvTranspose1d is one GEMM over a tap-gathered operand)
+ * in all three operand layouts and uploads them.  Synchronous. */
+int f5hip_bigvgan_finalize(f5hip_bigvgan* v);
+/* replaces: vocoder(mel) (utils_infer.py:512-513, BigVGAN.forward).
+ * mel: device fp32; channel_major != 0 -> [batch, num_mels, frames] (the reference's call layout), else [batch, frames, num_mels].
+ * precision: F5HIP_PREC_* operand mode of the conv GEMMs (activations, resampling filters and conv_post are always fp32).
+ * out: device fp32 [batch, frames * prod(upsample_rates)] (the reference's [batch, 1, T*hop] without the singleton axis). */
+int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int frames, int channel_major, int precision, float* out,
+                          void* stream);
+/* key/value options: "stop_after_stage" (parity tap for the tests; -1 = off): k >= 0 makes f5hip_bigvgan_forward write the
+ * channels-last fp32 tensor [batch, L_k, C_k] after conv_pre (k = 0) / after upsampling stage k (k >= 1: L_k = frames * prod(rates[:k]),
+ * C_k = upsample_initial_channel >> k) into `out` instead of the waveform. */
+int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value);
 
 /* ---- engine options / measurement ---------------------------------------------------------------- */
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = binding.load_library()
     for name in header_symbols():
         assert hasattr(lib, name)
-    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 3
+    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 4
     out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (f5hip_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported
@@ -136,3 +136,32 @@ def test_c_program_runs_the_path_through_the_c_abi():
     """mel -> sample (fp32 / fp16x3 / fp16) -> vocos_decode from plain C: finite, deterministic, prompt restored bit for bit."""
     r = subprocess.run([build_c_smoke()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "c_abi smoke ok" in r.stdout, r.stderr
+
+
+def test_bigvgan_config_struct_layout_matches_the_header():
+    """f5hip_bigvgan_config holds arrays: compare every field's offset / size as gcc lays the C struct out with the ctypes mirror."""
+    fields = [n for n, _ in binding.BigVGANConfigC._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "f5hip.h"\nint main(void) {\n'
+    for f in fields:
+        src += f'  printf("{f} %zu %zu\\n", offsetof(f5hip_bigvgan_config, {f}), sizeof(((f5hip_bigvgan_config*)0)->{f}));\n'
+    src += '  printf("total %zu 0\\n", sizeof(f5hip_bigvgan_config));\n  return 0;\n}\n'
+    out_dir = os.path.join(ROOT, "tests", "c_abi", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    cfile, exe = os.path.join(out_dir, "bv_layout.c"), os.path.join(out_dir, "bv_layout")
+    open(cfile, "w").write(src)
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {ln.split()[0]: (int(ln.split()[1]), int(ln.split()[2])) for ln in subprocess.run([exe], capture_output=True, text=True).stdout.splitlines()}
+    import ctypes as C
+
+    for f in fields:
+        d = getattr(binding.BigVGANConfigC, f)
+        assert got[f] == (d.offset, d.size), f
+    assert got["total"][0] == C.sizeof(binding.BigVGANConfigC)
+    # every C field is mirrored (the header's declaration order)
+    body = re.search(r"typedef struct f5hip_bigvgan_config \{(.*?)\} f5hip_bigvgan_config;", open(HEADER).read(), re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"int32_t\s+([^;]+);", body):
+        names += [re.sub(r"\[.*", "", f.strip()) for f in decl.split(",")]
+    assert names == fields
