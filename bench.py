@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="F5TTS_v1_Base")
     ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
+    ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
+                    help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
     return ap.parse_args()
 
 
@@ -62,7 +64,7 @@ def host_cores():
     return n
 
 
-def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen):
+def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen, bigvgan=None):
     """Oracle (port of the reference CPU path) on the host cores, bounded sample (~10-30 s of CPU work): mel + text-embed +
     1 ODE step, then 1 + `probe` steps, + the vocoder, all at full size; per-step time extrapolated to `nfe` steps (every
     step does identical work)."""
@@ -78,11 +80,18 @@ def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen):
     out, _ = O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1 + probe, **kw)
     t2 = time.perf_counter()
     gen = out[:, wav.shape[-1] // HOP:, :].permute(0, 2, 1)
-    O.vocos_decode(vsd, gen, vcfg.num_layers)
+    voc_scale = 1.0
+    if bigvgan is not None:  # the generator is linear in the frame count: time 64 frames of it and scale
+        from oracle import bigvgan_oracle as BO
+
+        BO.bigvgan_forward(bigvgan[1], bigvgan[0], gen[:, :, :64])
+        voc_scale = gen.shape[-1] / 64.0
+    else:
+        O.vocos_decode(vsd, gen, vcfg.num_layers)
     t3 = time.perf_counter()
     per_step = ((t2 - t1) - (t1 - t0)) / probe
     setup = max((t1 - t0) - per_step, 0.0)
-    total = setup + nfe * per_step + (t3 - t2)
+    total = setup + nfe * per_step + (t3 - t2) * voc_scale
     cpu_name = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -119,18 +128,28 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    cfg, vcfg = config.PRESETS[a.model], config.VOCOS_MEL_24K
+    big = a.vocoder == "bigvgan"
+    cfg, vcfg = config.PRESETS[a.model], (None if big else config.VOCOS_MEL_24K)
     eng = F5HipEngine(cfg, vcfg, device=dev)
     sd = vsd = None
     if rank == 0:  # rank 0 "reads the checkpoint"; the packed blob travels over RCCL/xGMI
-        sd, vsd = synth.synth_dit_state_dict(cfg, seed=0), synth.synth_vocos_state_dict(vcfg, seed=0)
+        sd = synth.synth_dit_state_dict(cfg, seed=0)
+        vsd = {} if big else synth.synth_vocos_state_dict(vcfg, seed=0)
         eng.load_state_dict({**sd, **vsd}, finalize=False)
     weights_via = "rccl broadcast of the packed blob from rank 0" if world > 1 else "local (single rank)"
     fdist.broadcast_engine_weights(eng, src=0)
     if not a.no_graph:
         eng.set_option("use_graph", 1)
     eng.set_option("branch_streams", a.branch_streams)
-    model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
+    if big:  # the generator is a context of its own (as in the reference); every rank builds the same seeded weights
+        from f5_tts_amd.bigvgan import F5HipBigVGAN
+
+        bcfg = config.BIGVGAN_V2_24K_100B_256X
+        model = F5HipCFM(eng, precision=a.precision, mel_spec_type="bigvgan")
+        bsd = synth.synth_bigvgan_state_dict(bcfg, seed=0)
+        voc = F5HipBigVGAN(bcfg, device=dev, precision=a.precision).load_state_dict(bsd)
+    else:
+        model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
 
     B, nw, nt, duration = a.batch, 120000, 220, 1406
     wav = synth.synth_wave(nw, seed=1000 * rank, batch=B).to(dev)  # resident in HBM before the timed region
@@ -142,6 +161,8 @@ def main():
     def one_pass():
         out, _ = model.sample(wav, text, duration, **kw)
         gen = out[:, ref_len:, :]  # [B, 938, 100] view; the engine takes frame-major directly
+        if big:  # vocoder(mel[b, 100, T]) as at reference utils_infer.py:509-513
+            return voc(gen.permute(0, 2, 1))[:, 0]
         return eng.vocos_decode(gen.contiguous(), channel_major=False)
 
     for _ in range(a.warmup):
@@ -156,7 +177,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = fdist.barrier_max_seconds(time.perf_counter() - t0, dev)
-    assert wave.shape == (B, HOP * (t_gen - 1)) and bool(torch.isfinite(wave).all())
+    assert wave.shape == (B, HOP * (t_gen if big else t_gen - 1)) and bool(torch.isfinite(wave).all())
 
     if rank != 0:
         if world > 1:
@@ -172,7 +193,7 @@ def main():
         "dtype": {"fp16x3": "fp16x3 (fp16 hi/lo split MFMA operands, fp32 accumulate/state)", "fp16": "fp16 (fp32 accumulate/state)",
                   "fp32": "fp32"}[a.precision],
         "data": "synthetic (seeded 0.1*N(0,1) prompts, uniform token ids, random-init weights of the named architecture)",
-        "config": {"workload": f"{a.model} + Vocos, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
+        "config": {"workload": f"{a.model} + {'BigVGAN-v2 (24 kHz, 100 band, 256x)' if big else 'Vocos'}, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
                                f"sway -1, CFG 2.0, euler (BASELINE.json configs[{1 if B == 1 else 2}])",
                    "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
                    "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via},
@@ -206,7 +227,7 @@ def main():
         for k, v in stats.items() if v["calls"] and v["ms"] > 0}
     if not a.no_cpu_baseline and world == 1:
         try:
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen)
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen, (bcfg, bsd) if big else None)
         except Exception as e:  # pragma: no cover
             res["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(res), flush=True)

@@ -64,7 +64,7 @@ class F5TTS:
                  vocoder_local_path: Optional[str] = None, device=None, hf_cache_dir=None, *, precision: str = "fp16x3",
                  mel_spec_type: str = "vocos", vocos_cfg: VocosConfig = VOCOS_MEL_24K,
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, vocoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
-                 transcribe: Optional[Callable[[str], str]] = None):
+                 transcribe: Optional[Callable[[str], str]] = None, bigvgan_cfg=None):
         if model not in PRESETS:
             raise ValueError(f"unknown model {model!r}; known: {sorted(PRESETS)}")
         self.mel_spec_type = mel_spec_type
@@ -81,7 +81,10 @@ class F5TTS:
         if mel_spec_type == "vocos":
             self.vocoder = I.load_vocoder("vocos", vocoder_local_path is not None, vocoder_local_path or "", engine=self.ema_model.engine,
                                           state_dict=vocoder_state_dict)
-        else:  # bigvgan-type mel: the generator is the caller's module (its source is not part of the reference tree)
+        elif vocoder_local_path is not None or vocoder_state_dict is not None:  # reference api.py:60-62 -> load_vocoder("bigvgan", ...)
+            self.vocoder = I.load_vocoder("bigvgan", vocoder_local_path is not None, vocoder_local_path or "", state_dict=vocoder_state_dict,
+                                          device=self.device, precision=precision, bigvgan_cfg=bigvgan_cfg)
+        else:  # no generator weights given: the caller assigns .vocoder (any module with the reference's `vocoder(mel)` call)
             self.vocoder = None
         self.seed = None
 

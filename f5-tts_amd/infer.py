@@ -181,18 +181,32 @@ def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos"
         load_checkpoint(engine, ckpt_path, use_ema=use_ema)
     if vocos_cfg is None:
         engine.finalize()
-    # mel_spec_type="bigvgan": the BigVGAN-type mel front-end runs on the engine; the BigVGAN generator itself is not built (its source is
-    # an un-vendored submodule of the reference) — infer_batch_process then calls the caller's own ``vocoder(mel)`` (utils_infer.py:512-513)
+    # mel_spec_type="bigvgan": the BigVGAN-type mel front-end runs on this engine; the generator is its own context
+    # (load_vocoder("bigvgan") -> F5HipBigVGAN) and infer_batch_process calls it as ``vocoder(mel)`` (utils_infer.py:512-513)
     return F5HipCFM(engine, vocab_char_map=vocab_char_map, ode_method=ode_method, precision=precision, mel_spec_type=mel_spec_type)
 
 
 def load_vocoder(vocoder_name: str = "vocos", is_local: bool = True, local_path: str = "", engine: Optional[F5HipEngine] = None,
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, **_ignored) -> F5HipVocos:
-    """reference utils_infer.py:106-129 (vocos branch): ``<local_path>/pytorch_model.bin`` (config.yaml is the fixed
-    charactr/vocos-mel-24khz architecture = ``VOCOS_MEL_24K``).  The vocoder lives in the same context as the backbone: pass
-    ``engine=model.engine``; loading its tensors finalises the context."""
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, device=0, precision: str = "fp16x3", bigvgan_cfg=None, **_ignored):
+    """reference utils_infer.py:106-145.
+
+    ``"vocos"`` (:107-129): ``<local_path>/pytorch_model.bin`` (config.yaml is the fixed charactr/vocos-mel-24khz architecture =
+    ``VOCOS_MEL_24K``).  The Vocos vocoder lives in the same context as the backbone: pass ``engine=model.engine``; loading its tensors
+    finalises the context.
+    ``"bigvgan"`` (:130-144): ``<local_path>/config.json`` + ``bigvgan_generator.pt`` (the files of nvidia/bigvgan_v2_24khz_100band_256x
+    that the reference downloads), weight norm folded at load (the reference's ``remove_weight_norm()``), its own HIP context
+    (``F5HipBigVGAN``); ``state_dict`` + ``bigvgan_cfg`` instead of files for synthetic weights."""
+    if vocoder_name == "bigvgan":
+        from .bigvgan import F5HipBigVGAN
+        from .config import BIGVGAN_V2_24K_100B_256X
+
+        if state_dict is not None:
+            return F5HipBigVGAN(bigvgan_cfg or BIGVGAN_V2_24K_100B_256X, device=device, precision=precision).load_state_dict(state_dict)
+        if not is_local:
+            raise ValueError("no network here: pass is_local=True and local_path")
+        return F5HipBigVGAN.from_pretrained(local_path, use_cuda_kernel=False, device=device, precision=precision)
     if vocoder_name != "vocos":
-        raise ValueError("only vocos is built")
+        raise ValueError("vocoder_name must be vocos or bigvgan (utils_infer.py:107,130)")
     if engine is None:
         raise ValueError("pass engine=model.engine (one HIP context hosts backbone + vocoder)")
     if state_dict is None:
@@ -296,7 +310,7 @@ def infer_batch_process(ref_audio, ref_text: str, gen_text_batches: Sequence[str
         generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
         if mel_spec_type == "vocos":
             wave_out = vocoder.decode(generated)
-        elif mel_spec_type == "bigvgan":  # a caller-supplied generator module (utils_infer.py:512-513); none is built here
+        elif mel_spec_type == "bigvgan":  # F5HipBigVGAN (load_vocoder("bigvgan")) or any caller-supplied generator (utils_infer.py:512-513)
             wave_out = vocoder(generated)
         else:
             raise ValueError("mel_spec_type must be vocos or bigvgan")
