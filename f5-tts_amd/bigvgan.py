@@ -171,6 +171,9 @@ class F5HipBigVGAN:
 
     __call__ = forward
 
+    def set_option(self, key: str, value: int):
+        self._chk(self.lib.f5hip_bigvgan_set_option(self._ctx, key.encode(), int(value)))
+
     def stage_tensor(self, x: torch.Tensor, stage: int) -> torch.Tensor:
         """Parity tap (tests): the channels-last tensor [b, L_k, C_k] after conv_pre (stage 0) / after upsampling stage k."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()

@@ -10,6 +10,7 @@
 // index arithmetic of every kernel here with torch gathers; tests/test_bigvgan_oracle.py checks that against the oracle.
 #include <math.h>
 
+#include "conv_gemm.h"
 #include "kernels.h"
 
 namespace {
@@ -31,6 +32,10 @@ struct AaArgs {
   const float* beta;
   int L, C, logscale;
   float f[12];
+  // optional fused operand emission (conv_impl 2): instead of y, write the GEMM operand copy [L, cpad] in layout `op` (channels
+  // [C, cpad) zero) — the conv that follows reads it directly (conv_gemm.h), no fp32 round trip, no separate launch_im2col_taps
+  void* oper;
+  int op, cpad;
 };
 
 __device__ __forceinline__ float aa_v(const float* __restrict__ xc, int ldx, int L, int m, const float (&f)[12], float a, float invb) {
@@ -50,7 +55,27 @@ template <int TL>
 __global__ __launch_bounds__(256) void aa_snake_kernel(AaArgs a) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   const int l0 = (blockIdx.y * 4 + threadIdx.y) * TL;
-  if (c >= a.C || l0 >= a.L) return;
+  if (l0 >= a.L) return;
+  // operand addressing of channel c (fused emission): element offset inside a row, row stride, elements are floats or halves
+  const int mul = a.op == OP_F16X3 ? 2 : 1;
+  const int64_t ldo = (int64_t)a.cpad * mul;
+  const int64_t ooff = (int64_t)blockIdx.z * a.L * ldo + pk_off(c, a.op == OP_F16X3);
+  auto emit = [&](int l, float z) {
+    if (a.op == OP_F32) {
+      reinterpret_cast<float*>(a.oper)[ooff + (int64_t)l * ldo] = z;
+    } else {
+      f16 h, w;
+      split_f16(z, h, w);
+      f16* o = reinterpret_cast<f16*>(a.oper) + ooff + (int64_t)l * ldo;
+      o[0] = h;
+      if (a.op == OP_F16X3) o[32] = w;
+    }
+  };
+  if (c >= a.C) {
+    if (a.oper && c < a.cpad)
+      for (int l = l0; l < min(l0 + TL, a.L); ++l) emit(l, 0.f);
+    return;
+  }
   const int64_t boff = (int64_t)blockIdx.z * a.L * a.C + c;
   const float* xc = a.x + boff;
   float* yc = a.y + boff;
@@ -67,7 +92,8 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(AaArgs a) {
     float z = 0.f;
 #pragma unroll
     for (int j = 0; j < 12; ++j) z = fmaf(a.f[j], vw[j], z);
-    yc[(int64_t)l * a.C] = z;
+    if (a.oper) emit(l, z);
+    else yc[(int64_t)l * a.C] = z;
 #pragma unroll
     for (int j = 0; j < 10; ++j) vw[j] = vw[j + 2];
     vw[10] = aa_v(xc, a.C, a.L, min(2 * l + 7, mmax), a.f, al, invb);  // window of step l+1: v[2(l+1) + j - 5]
@@ -162,13 +188,15 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* y, const fl
 }  // namespace
 
 hipError_t launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* filt12, int B, int L, int C,
-                           int logscale, hipStream_t s) {
+                           int logscale, hipStream_t s, void* oper, int op, int cpad) {
   constexpr int TL = 32;
+  if (oper && (cpad % 32 || cpad < C || (op != OP_F32 && op != OP_F16 && op != OP_F16X3))) return hipErrorInvalidValue;
   AaArgs a{};
   a.x = x; a.y = y; a.alpha = alpha; a.beta = beta; a.L = L; a.C = C; a.logscale = logscale;
+  a.oper = oper; a.op = oper ? op : OP_F32; a.cpad = oper ? cpad : C;
   for (int j = 0; j < 12; ++j) a.f[j] = filt12[j];
   const int chunks = (L + TL - 1) / TL;
-  dim3 grid((C + 63) / 64, (chunks + 3) / 4, B);
+  dim3 grid(((oper ? cpad : C) + 63) / 64, (chunks + 3) / 4, B);
   hipLaunchKernelGGL(aa_snake_kernel<TL>, grid, dim3(64, 4), 0, s, a);
   return hipGetLastError();
 }
@@ -197,4 +225,41 @@ hipError_t launch_conv_post(const float* y, const float* w7, const float* bias, 
   if (C % 4 || 7 * C * 4 > 48 * 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(conv_post_kernel, dim3((L + 255) / 256, B), dim3(256), 7 * C * sizeof(float), s, y, w7, bias, L, C, use_tanh, out);
   return hipGetLastError();
+}
+
+// ---- implicit-GEMM conv (conv_gemm.h) ------------------------------------------------------------------------------------------------
+namespace {
+template <typename T, int NSPLIT, int TM, int TN>
+hipError_t launch_conv_one(const GemmCore& g, const ConvTaps& tp, const EpiStore& e, int batch, hipStream_t s) {
+  constexpr int lds = gemm_lds_bytes<T, NSPLIT, TM, TN, 2, 2>();
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  auto kern = conv_gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    attr_done = true;
+  }
+  if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
+    return hipErrorInvalidValue;
+  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tp, e);
+  return hipGetLastError();
+}
+template <typename T, int NSPLIT>
+hipError_t launch_conv_op(const GemmCore& g, const ConvTaps& tp, const EpiStore& e, int batch, hipStream_t s) {
+  return g.N <= 64 ? launch_conv_one<T, NSPLIT, 2, 1>(g, tp, e, batch, s) : launch_conv_one<T, NSPLIT, 2, 2>(g, tp, e, batch, s);
+}
+}  // namespace
+
+hipError_t launch_conv_gemm(int op, const GemmCore& g, int ntaps, int shift0, int dstep, int cpad, const EpiStore& e, int batch, hipStream_t s) {
+  const int seg = cpad * (op == OP_F16 ? 2 : 4);  // bytes of one tap segment of an operand row (packed fp16x3: 2 planes x 2 bytes)
+  if (seg % GEMM_KTB || g.K != ntaps * cpad) return hipErrorInvalidValue;
+  ConvTaps tp{ntaps, shift0, dstep, seg / GEMM_KTB};
+  switch (op) {
+    case OP_F32: return launch_conv_op<float, 1>(g, tp, e, batch, s);
+    case OP_F16: return launch_conv_op<f16, 1>(g, tp, e, batch, s);
+    case OP_F16X3: return launch_conv_op<f16, 3>(g, tp, e, batch, s);
+    default: return hipErrorInvalidValue;
+  }
 }

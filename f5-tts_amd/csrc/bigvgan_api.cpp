@@ -70,6 +70,8 @@ struct f5hip_bigvgan {
   float filt[12];
   // workspace (grow-only)
   DevBuf xa, xb, tt, yy, col, rr[4];
+  int conv_impl = 0;          // 0 = tap-gathered operand + plain GEMM, 1 = implicit GEMM with tap-shifted rows (conv_gemm.h),
+                              // 2 = 1 + Activation1d writes the conv's operand copy itself
   int stop_after_stage = -1;  // parity tap (tests): >= 0 makes forward() return the channels-last stage tensor instead of the waveform
 };
 
@@ -256,22 +258,46 @@ int finalize_impl(f5hip_bigvgan* v) {
 
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
 
-// one conv as operand emission + GEMM: src [B, L, cin] (strides given) -> dst [B, L, N] (+ res)
+// one conv: src [B, L, cin] (strides given) -> dst [B, L, N] (+ res)
+//   conv_impl 0: tap-gathered operand [L, ntaps * cpad] (launch_im2col_taps) + the plain GEMM — k-fold write amplification, but built
+//                from the kernels the DiT path has exercised; the cross-check of
+//   conv_impl 1: ONE operand copy [L, cpad] + the implicit-GEMM kernel with tap-shifted rows (conv_gemm.h)
+//   conv_impl 2: as 1, and the Activation1d in front of a resblock conv writes that operand copy itself (src == nullptr here)
+bool can_implicit(const f5hip_bigvgan* v, const ConvW& cw, int op) { return v->conv_impl >= 1 && (op != OP_F16 || cw.cpad % 64 == 0); }
+
 int run_conv(f5hip_bigvgan* v, const ConvW& cw, int op, const float* src, int64_t sb, int64_t sl, int64_t sc, int B, int L, float* dst,
              const float* res, hipStream_t st) {
-  const int64_t ld = (int64_t)cw.K * (op == OP_F16X3 ? 2 : 1);
-  HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
+  const int mul = op == OP_F16X3 ? 2 : 1;
+  const bool implicit = can_implicit(v, cw, op);
+  const int64_t ld = (int64_t)(implicit ? cw.cpad : cw.K) * mul;
+  if (!src) {  // the operand copy is already in v->col (fused emission)
+    if (!implicit) FAIL(F5HIP_ERR_STATE, "internal: fused operand without the implicit-GEMM path");
+  } else if (implicit) HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, 1, 0, 1, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
+  else HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
   GemmCore g{};
   g.A = v->col.p;
   g.W = op == OP_F32 ? (const void*)cw.w32.p : op == OP_F16 ? (const void*)cw.w16.p : (const void*)cw.wpk.p;
-  g.lda = ld; g.ldw = ld; g.strideA = (int64_t)L * ld; g.strideW = 0;
+  g.lda = ld; g.ldw = (int64_t)cw.K * mul; g.strideA = (int64_t)L * ld; g.strideW = 0;
   g.M = L; g.N = cw.N; g.K = cw.K; g.a_rows = L; g.w_rows = cw.N;
   EpiStore e{};
   e.alpha = 1.f; e.act = ACT_NONE; e.bias = cw.bias.as<float>(); e.out32 = dst; e.ldo = cw.N; e.ldres = cw.N; e.res = res;
   e.zdiv = 1; e.so1 = (int64_t)L * cw.N; e.so2 = 0;
-  // narrow outputs (the last stages: 48 / 24 channels): the 128x64 tile instead of the heuristic's 128x128
-  HIPCHK(launch_gemm_store_variant(op, g, e, B, cw.N <= 64 ? 1 : -1, st));
+  if (implicit) HIPCHK(launch_conv_gemm(op, g, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, e, B, st));
+  else HIPCHK(launch_gemm_store_variant(op, g, e, B, cw.N <= 64 ? 1 : -1, st));  // narrow outputs (48 / 24 channels): the 128x64 tile
   return F5HIP_OK;
+}
+
+// Activation1d followed by a conv of the same resblock: y = act(x); dst = conv(y) (+ res)
+int run_act_conv(f5hip_bigvgan* v, const ActW& a, const ConvW& cw, int op, const float* x, int B, int L, int C, float* dst, const float* res,
+                 hipStream_t st) {
+  const int ls = v->cfg.snake_logscale;
+  if (v->conv_impl == 2 && can_implicit(v, cw, op)) {
+    HIPCHK(launch_aa_snake(x, nullptr, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st, v->col.p, op, cw.cpad));
+    return run_conv(v, cw, op, nullptr, 0, 0, 0, B, L, dst, res, st);
+  }
+  float* y = v->yy.as<float>();
+  HIPCHK(launch_aa_snake(x, y, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st));
+  return run_conv(v, cw, op, y, (int64_t)L * C, C, 1, B, L, dst, res, st);
 }
 
 int forward_impl(f5hip_bigvgan* v, const float* mel, int B, int T, int channel_major, int precision, float* out, hipStream_t st) {
@@ -322,13 +348,10 @@ int forward_impl(f5hip_bigvgan* v, const float* mel, int B, int T, int channel_m
       const float* rin = xn;  // the block's running stream: the stage input first, its own buffer afterwards
       for (size_t m = 0; m < r.c1.size(); ++m) {
         if (c.resblock == 1) {
-          HIPCHK(launch_aa_snake(rin, y, r.act[2 * m].alpha.as<float>(), r.act[2 * m].beta.as<float>(), v->filt, B, L, C, c.snake_logscale, st));
-          CHK(run_conv(v, r.c1[m], op, y, sb, C, 1, B, L, tt, nullptr, st));
-          HIPCHK(launch_aa_snake(tt, y, r.act[2 * m + 1].alpha.as<float>(), r.act[2 * m + 1].beta.as<float>(), v->filt, B, L, C, c.snake_logscale, st));
-          CHK(run_conv(v, r.c2[m], op, y, sb, C, 1, B, L, rj, rin, st));  // x = xt + x
+          CHK(run_act_conv(v, r.act[2 * m], r.c1[m], op, rin, B, L, C, tt, nullptr, st));
+          CHK(run_act_conv(v, r.act[2 * m + 1], r.c2[m], op, tt, B, L, C, rj, rin, st));  // x = xt + x
         } else {
-          HIPCHK(launch_aa_snake(rin, y, r.act[m].alpha.as<float>(), r.act[m].beta.as<float>(), v->filt, B, L, C, c.snake_logscale, st));
-          CHK(run_conv(v, r.c1[m], op, y, sb, C, 1, B, L, rj, rin, st));
+          CHK(run_act_conv(v, r.act[m], r.c1[m], op, rin, B, L, C, rj, rin, st));
         }
         rin = rj;
       }
@@ -445,6 +468,11 @@ int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value) {
   if (!strcmp(key, "stop_after_stage")) {
     if (value < -1 || value > v->cfg.num_upsamples) FAIL(F5HIP_ERR_INVALID, "stop_after_stage must be in [-1, num_upsamples]");
     v->stop_after_stage = (int)value;
+    return F5HIP_OK;
+  }
+  if (!strcmp(key, "conv_impl")) {
+    if (value < 0 || value > 2) FAIL(F5HIP_ERR_INVALID, "conv_impl must be 0, 1 or 2");
+    v->conv_impl = (int)value;
     return F5HIP_OK;
   }
   FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);

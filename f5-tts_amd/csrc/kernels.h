@@ -115,8 +115,9 @@ hipError_t launch_istft_ola(const float* frames, const float* window, int B, int
 // ---- bigvgan.hip ------------------------------------------------------------------------------
 // BigVGAN generator path, channels-last fp32 activations [B, L, C] (see bigvgan.hip for the formulas each kernel evaluates).
 // Activation1d (x2 upsample -> Snake/SnakeBeta -> x2 downsample) with the host-computed 12-tap kaiser-sinc filter `filt12` (HOST pointer)
+// oper != null: instead of y, write the GEMM operand copy [B, L, cpad] in layout `op` (channels [C, cpad) zero) for launch_conv_gemm
 hipError_t launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* filt12, int B, int L, int C,
-                           int logscale, hipStream_t s);
+                           int logscale, hipStream_t s, void* oper = nullptr, int op = 0, int cpad = 0);
 // tap-gathered GEMM operand: out[(b, l), j * cpad + c] = src[b, l + shift0 + j * dstep, c] or 0, in operand layout `op` (OP_*);
 // sb / sl / sc = element strides of src (batch, time step, channel); ldo / ob = row / batch stride of out in elements of its type
 hipError_t launch_im2col_taps(const float* src, int64_t sb, int64_t sl, int64_t sc, int B, int L, int C, int ntaps, int shift0, int dstep,
@@ -125,3 +126,7 @@ hipError_t launch_im2col_taps(const float* src, int64_t sb, int64_t sl, int64_t 
 hipError_t launch_mean_streams(const float* const* r, int nk, int64_t n, float* out, hipStream_t s);
 // Conv1d(C -> 1, k 7, pad 3) + tanh or clamp(-1, 1): y [B, L, C], w7 [7, C] tap-major, bias [1] or null -> out [B, L]
 hipError_t launch_conv_post(const float* y, const float* w7, const float* bias, int B, int L, int C, int use_tanh, float* out, hipStream_t s);
+// Conv1d / ConvTranspose1d as an implicit GEMM over ONE operand copy Y [batch, L, cpad] (conv_gemm.h): g.A = Y (row stride g.lda,
+// batch stride g.strideA), g.W = [N, ntaps * cpad] as for launch_im2col_taps + launch_gemm_store, g.K = ntaps * cpad, g.M = g.a_rows = L.
+// Needs cpad % 32 == 0 (fp32 / fp16x3) or cpad % 64 == 0 (fp16): a tap segment is a whole number of 128-byte k-tiles.
+hipError_t launch_conv_gemm(int op, const GemmCore& g, int ntaps, int shift0, int dstep, int cpad, const EpiStore& e, int batch, hipStream_t s);

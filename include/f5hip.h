@@ -198,7 +198,8 @@ int f5hip_bigvgan_finalize(f5hip_bigvgan* v);
  * out: device fp32 [batch, frames * prod(upsample_rates)] (the reference's [batch, 1, T*hop] without the singleton axis). */
 int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int frames, int channel_major, int precision, float* out,
                           void* stream);
-/* key/value options: "stop_after_stage" (parity tap for the tests; -1 = off): k >= 0 makes f5hip_bigvgan_forward write the
+/* key/value options: "conv_impl" (0 = every conv as a tap-gathered operand + the plain MFMA GEMM; 1 = one operand copy + the
+ * implicit-GEMM kernel with tap-shifted rows, csrc/conv_gemm.h; 2 = 1 with the operand copy written by the Activation1d kernel itself); "stop_after_stage" (parity tap for the tests; -1 = off): k >= 0 makes f5hip_bigvgan_forward write the
  * channels-last fp32 tensor [batch, L_k, C_k] after conv_pre (k = 0) / after upsampling stage k (k >= 1: L_k = frames * prod(rates[:k]),
  * C_k = upsample_initial_channel >> k) into `out` instead of the waveform. */
 int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value);

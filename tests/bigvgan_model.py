@@ -93,6 +93,23 @@ def conv_cl(y, w, bias, dilation, cpad=None):
     return out + bias if bias is not None else out
 
 
+def conv_implicit_cl(y, wmat, ntaps, shift0, dstep, cpad):
+    """The implicit-GEMM form (csrc/conv_gemm.h): ONE padded operand copy [b, L, cpad]; for tap j the activation rows are read shifted
+    by shift0 + j * dstep (zero outside [0, L)) against columns [j * cpad, (j + 1) * cpad) of the same weight matrix."""
+    b, L, C = y.shape
+    yp = torch.zeros(b, L, cpad)
+    yp[:, :, :C] = y
+    out = torch.zeros(b, L, wmat.shape[0])
+    l = torch.arange(L)
+    for j in range(ntaps):
+        src = l + shift0 + j * dstep
+        ok = (src >= 0) & (src < L)
+        rows = torch.zeros(b, L, cpad)
+        rows[:, ok] = yp[:, src[ok]]
+        out = out + rows @ wmat[:, j * cpad:(j + 1) * cpad].t()
+    return out
+
+
 def convt_cl(y, w, bias, u):
     cin, cout, k = w.shape
     cpad = rup(cin, 32)

@@ -150,6 +150,19 @@ def test_phase_stacked_gemm_equals_conv_transpose1d(cin, cout, k, u, L):
     assert torch.allclose(got, want, atol=1e-4)
 
 
+def test_implicit_gemm_form_equals_the_tap_gathered_form():
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(2, 19, 24, generator=g)
+    w = torch.randn(40, 24, 11, generator=g)
+    wm = M.conv_weight_matrix(w, 32)
+    a = M.im2col(y, 11, -5 * 3, 3, 32) @ wm.t()
+    assert torch.allclose(M.conv_implicit_cl(y, wm, 11, -15, 3, 32), a, atol=1e-5)
+    wt = torch.randn(24, 12, 8, generator=g)
+    s0, nt = M.convt_taps(8, 4)
+    wmt = M.convt_weight_matrix(wt, 4, 32)
+    assert torch.allclose(M.conv_implicit_cl(y, wmt, nt, s0, 1, 32), M.im2col(y, nt, s0, 1, 32) @ wmt.t(), atol=1e-5)
+
+
 @pytest.mark.parametrize("name", list(CFGS))
 @pytest.mark.parametrize("T", [1, 13])
 def test_whole_generator_in_the_kernels_formulation(name, T):

@@ -52,6 +52,25 @@ def test_stage_tensors_and_waveform(name, precision):
     assert (wav.cpu() - want).abs().max().item() < TOL[precision]
 
 
+@pytest.mark.parametrize("name", ["BIGVGAN_TINY", "BIGVGAN_TINY2"])
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3", "fp16"])
+def test_implicit_gemm_convs_equal_the_tap_gathered_path(name, precision):
+    """conv_impl 1 (tap-shifted rows inside the GEMM's k-loop) against conv_impl 0 (materialised operand + plain GEMM): the same
+    products in the same k order per tile, so the two agree to fp32 summation noise — and both against the oracle."""
+    from oracle import bigvgan_oracle as BO
+
+    cfg = getattr(config, name)
+    voc, sd = make(cfg, precision)
+    mel = torch.randn(2, cfg.num_mels, 53, generator=torch.Generator().manual_seed(5))
+    a = voc(mel.cuda()).cpu()
+    want = BO.bigvgan_forward(sd, cfg, mel)
+    for impl in (1, 2):  # 2: the activation kernel writes the operand copy itself
+        voc.set_option("conv_impl", impl)
+        b = voc(mel.cuda()).cpu()
+        assert (a - b).abs().max().item() < 1e-5, impl
+        assert (b - want).abs().max().item() < TOL[precision], impl
+
+
 @pytest.mark.parametrize("T", [1, 2, 5, 64, 129])
 def test_lengths_and_batch_rows_are_independent(T):
     from oracle import bigvgan_oracle as BO
