@@ -1,7 +1,18 @@
 // common.h — shared device helpers for libf5hip (gfx950 / CDNA4 only; wave = 64).
 #pragma once
+#ifdef F5_HIPEMU  // tests/hipemu: the same kernel source compiled for the host (one std::thread per HIP thread)
+#include "hipemu.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
+
+// the workgroup's dynamic LDS allocation as an array of `type`
+#ifdef F5_HIPEMU
+#define F5_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(hipemu::dyn_lds())
+#else
+#define F5_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
 
 typedef _Float16 f16;
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_gemm_kernel(GemmCore g, C
   constexpr int TILE_A = BM * GEMM_KTB, TILE_W = BN * GEMM_KTB;
   constexpr int STAGE = TILE_A + TILE_W;
   static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  F5_DYN_LDS(char, smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WGM, wn = wave / WGM;

@@ -1,6 +1,8 @@
 // engine.h — host-side state of libf5hip: context, packed weight blob, derived layouts, workspace.
 #pragma once
+#ifndef F5_HIPEMU  // under the host shim (tests/hipemu) common.h brings the runtime stand-ins
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cstdint>
 #include <mutex>

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
   constexpr int TILE_A = BM * GEMM_KTB, TILE_W = BN * GEMM_KTB;
   constexpr int STAGE = TILE_A + TILE_W;
   static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  F5_DYN_LDS(char, smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WGM, wn = wave / WGM;
@@ -358,6 +358,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
   }
 }
 
+#ifndef F5_HIPEMU  // inline asm: not part of the host-shim build
 // ---------------------------------------------------------------------------------------------------------------------
 // Direct-to-LDS variant: the k-tiles are fetched by LDS-DMA (buffer_load_dwordx4 ... lds: the wave writes 64 x 16 B to a
 // lane-linear 1 KiB LDS run, no VGPR round trip, no ds_write) into a ring of NS stages.  The swizzle lives on the per-lane
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
   constexpr int STAGE = TILE_A + TILE_W;
   static_assert(CA >= 1 && CW >= 1 && CA * NT == BM * CPR && CW * NT == BN * CPR, "tile does not split evenly over the threads");
   static_assert(NS == 3 || NS == 2, "ring depth 3 (two tiles in flight) or 2 (one tile in flight, for tiles whose stage is 64 KB)");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  F5_DYN_LDS(char, smem);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -555,3 +556,4 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
     }
   }
 }
+#endif  // F5_HIPEMU

@@ -1,9 +1,8 @@
 // kernels.h — host-callable launchers of every HIP kernel in libf5hip (internal; the public ABI is include/f5hip.h)
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "gemm.h"
+#include "gemm.h"  // common.h pulls in the HIP runtime (or the host shim under F5_HIPEMU)
 
 enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2 };  // GEMM operand kind
 

@@ -1,0 +1,315 @@
+// hipemu.h — a minimal HIP-on-CPU shim for THIS repo's kernels (TEST INFRASTRUCTURE; host clang++, -DF5_HIPEMU).
+//
+// Purpose: run the very kernel source that hipcc compiles for gfx950 (csrc/*.h kernels) on the CPU, thread for thread, so index
+// arithmetic, LDS images, MFMA fragment layouts and epilogues can be checked without a GPU.  One fiber per HIP thread, switched at
+// barriers only; __syncthreads() is a block barrier; the few amdgcn builtins the kernels use are emulated with their DOCUMENTED semantics:
+//   * v_mfma_f32_32x32x16_f16 / v_mfma_f32_32x32x2_f32: A[i][k] from lane i + 32 (k / kpl), B[k][j] from lane j + 32 (k / kpl)
+//     (kpl = k elements per lane: 8 / 1), D[i][j] in lane j + 32 ((i / 4) % 2), register (i % 4) + 4 (i / 8)   (common.h; proven on
+//     the GPU by the DiT parity suite — tests/test_hipemu.py first runs the GPU-proven gemm_kernel through this shim);
+//   * raw buffer loads: dwords at byte offsets >= num_records read as zero;
+//   * LDS: plain per-block memory; exp2 / rcp: libm.
+// Not emulated: inline asm (LDS-DMA ring / stream-K kernels are compiled out under F5_HIPEMU), timing, caches, memory ordering.
+#pragma once
+#define F5_HIPEMU 1
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef void* hipGraphExec_t;
+// the slice of the HIP runtime API the host side of the BigVGAN path calls (bigvgan_api.cpp, DevBuf): "device" memory is host memory
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+// every allocation sits between two 4 KiB guard zones of a known pattern, checked when it is freed: a kernel that WRITES outside its
+// buffers aborts the test instead of silently corrupting a neighbour (reads outside surface as wrong results)
+namespace hipemu {
+constexpr size_t kGuard = 4096;
+struct AllocHdr { size_t n; };
+inline void check_guards(void* p) {
+  char* base = static_cast<char*>(p) - kGuard;
+  const size_t n = reinterpret_cast<AllocHdr*>(base)->n;
+  for (size_t i = sizeof(AllocHdr); i < kGuard; ++i)
+    if (base[i] != (char)0xA5) { fprintf(stderr, "hipemu: write BEFORE a device buffer (offset -%zu)\n", kGuard - i); abort(); }
+  for (size_t i = 0; i < kGuard; ++i)
+    if (base[kGuard + n + i] != (char)0xA5) { fprintf(stderr, "hipemu: write PAST a device buffer of %zu bytes (+%zu)\n", n, i); abort(); }
+}
+}  // namespace hipemu
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  char* base = static_cast<char*>(aligned_alloc(4096, ((n + 4095) & ~size_t(4095)) + 2 * hipemu::kGuard));
+  if (!base) return hipErrorOutOfMemory;
+  memset(base, 0xA5, hipemu::kGuard);
+  memset(base + hipemu::kGuard + n, 0xA5, hipemu::kGuard);
+  reinterpret_cast<hipemu::AllocHdr*>(base)->n = n;
+  *p = base + hipemu::kGuard;
+  return hipSuccess;
+}
+static inline hipError_t hipFree(void* p) {
+  if (!p) return hipSuccess;
+  hipemu::check_guards(p);
+  free(static_cast<char*>(p) - hipemu::kGuard);
+  return hipSuccess;
+}
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+using std::max;
+using std::min;
+
+namespace hipemu {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+struct Rsrc {
+  const char* base;
+  uint32_t num_records;
+};
+struct Idx { unsigned x, y, z; };
+
+// Execution model: the HIP threads of one block are FIBERS of one OS thread (hand-rolled x86-64 context switch, ~10 ns), switched
+// only at barriers: __syncthreads() and the wave-wide rendezvous inside the emulated MFMA / shuffle.  Blocks are independent (the
+// kernels run here never communicate across blocks) and are dealt to a few OS threads.
+struct Barrier {
+  int expected = 0, arrived = 0;
+  unsigned gen = 0;
+};
+struct Fiber {
+  void* sp = nullptr;
+  Idx tidx{};
+  int lane = 0, wave = 0;
+  bool done = false;
+  Barrier* wait_bar = nullptr;
+  unsigned wait_gen = 0;
+};
+struct WaveCtx {
+  Barrier bar;
+  float a[64][8], b[64][8], sh[64];
+};
+struct BlockCtx {
+  Barrier bar;
+  std::vector<WaveCtx> waves;
+  std::vector<char> lds;
+  std::vector<Fiber> fibers;
+  Fiber* cur = nullptr;
+  void* sched_sp = nullptr;
+  Idx bidx{};
+  const std::function<void()>* fn = nullptr;
+};
+inline thread_local BlockCtx* blk = nullptr;
+inline thread_local Idx b_dim, g_dim;
+
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+inline void yield_to_scheduler() { hipemu_switch(&blk->cur->sp, blk->sched_sp); }
+inline void barrier_wait(Barrier& b) {
+  const unsigned g = b.gen;
+  if (++b.arrived == b.expected) { b.arrived = 0; ++b.gen; return; }
+  blk->cur->wait_bar = &b;
+  blk->cur->wait_gen = g;
+  yield_to_scheduler();
+}
+inline void barrier_drop(Barrier& b) {  // a thread that has returned no longer takes part in barriers (as on the GPU)
+  if (--b.expected > 0 && b.arrived == b.expected) { b.arrived = 0; ++b.gen; }
+}
+inline void fiber_entry() {
+  BlockCtx* c = blk;
+  Fiber* f = c->cur;
+  (*c->fn)();
+  f->done = true;
+  barrier_drop(c->waves[f->wave].bar);
+  barrier_drop(c->bar);
+  yield_to_scheduler();
+  abort();  // a finished fiber is never resumed
+}
+
+inline char* dyn_lds() { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(blk->lds.data()) + 63) & ~uintptr_t(63)); }
+inline WaveCtx& wv() { return blk->waves[blk->cur->wave]; }
+
+inline Rsrc make_rsrc(void* p, short, int num, int) { return {reinterpret_cast<const char*>(p), (uint32_t)num}; }
+inline u4 raw_buffer_load_b128(Rsrc r, int off, int soff, int) {
+  u4 v = {0, 0, 0, 0};
+  const uint32_t o = (uint32_t)off + (uint32_t)soff;
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t b = (uint64_t)o + 4u * i;
+    if (b + 4 <= r.num_records) { unsigned t; memcpy(&t, r.base + b, 4); v[i] = t; }
+  }
+  return v;
+}
+inline f16v mfma_32x32x16_f16(h8 a, h8 b, f16v c, int, int, int) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  for (int e = 0; e < 8; ++e) { w.a[lane][e] = (float)a[e]; w.b[lane][e] = (float)b[e]; }
+  barrier_wait(w.bar);
+  const int j = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float s = 0.f;
+    for (int k = 0; k < 16; ++k) s += w.a[i + 32 * (k >> 3)][k & 7] * w.b[j + 32 * (k >> 3)][k & 7];
+    c[r] += s;
+  }
+  barrier_wait(w.bar);
+  return c;
+}
+inline f16v mfma_32x32x2_f32(float a, float b, f16v c, int, int, int) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  w.a[lane][0] = a; w.b[lane][0] = b;
+  barrier_wait(w.bar);
+  const int j = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    c[r] += w.a[i][0] * w.b[j][0] + w.a[i + 32][0] * w.b[j + 32][0];
+  }
+  barrier_wait(w.bar);
+  return c;
+}
+inline float shfl_xor(float v, int mask, int) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  w.sh[lane] = v;
+  barrier_wait(w.bar);
+  const float r = w.sh[lane ^ mask];
+  barrier_wait(w.bar);
+  return r;
+}
+
+constexpr size_t kFiberStack = 128 * 1024;
+
+// one block, all its threads as fibers of the calling OS thread; `stacks` = nt * kFiberStack bytes
+inline void run_block(dim3 block, Idx bidx, size_t lds_bytes, const std::function<void()>& fn, char* stacks) {
+  const int nt = (int)(block.x * block.y * block.z), nw = (nt + 63) / 64;
+  BlockCtx ctx;
+  ctx.bar.expected = nt;
+  ctx.waves.resize(nw);
+  for (int w = 0; w < nw; ++w) ctx.waves[w].bar.expected = std::min(64, nt - 64 * w);
+  ctx.lds.resize(lds_bytes + 64);
+  ctx.fibers.resize(nt);
+  ctx.bidx = bidx;
+  ctx.fn = &fn;
+  for (int t = 0; t < nt; ++t) {
+    Fiber& f = ctx.fibers[t];
+    f.tidx = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+    f.lane = t & 63;
+    f.wave = t >> 6;
+    // initial frame for hipemu_switch: six callee-saved registers, then the entry point as the return address (stack 16-aligned + 8
+    // at the entry, as after a call)
+    uintptr_t top = (reinterpret_cast<uintptr_t>(stacks) + (size_t)(t + 1) * kFiberStack) & ~uintptr_t(15);
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;
+    *--sp = reinterpret_cast<void*>(&fiber_entry);
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    f.sp = sp;
+  }
+  BlockCtx* prev = blk;
+  blk = &ctx;
+  int remaining = nt, idle = 0;
+  for (int i = 0; remaining; i = (i + 1 == nt ? 0 : i + 1)) {
+    Fiber& f = ctx.fibers[i];
+    if (f.done || (f.wait_bar && f.wait_bar->gen == f.wait_gen)) {
+      if (++idle > 2 * nt) { fprintf(stderr, "hipemu: deadlock (a barrier some threads never reach)\n"); abort(); }
+      continue;
+    }
+    idle = 0;
+    f.wait_bar = nullptr;
+    ctx.cur = &f;
+    hipemu_switch(&ctx.sched_sp, f.sp);
+    if (f.done) --remaining;
+  }
+  blk = prev;
+}
+
+// run fn() once per HIP thread of a grid x block launch; every block has completed when this returns
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn) {
+  const int nt = (int)(block.x * block.y * block.z);
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  const int nworkers = (int)std::max(1L, std::min<long>(nblocks, std::min(8u, std::max(1u, std::thread::hardware_concurrency()))));
+  std::atomic<long> next{0};
+  auto worker = [&] {
+    std::unique_ptr<char[]> stacks(new char[(size_t)nt * kFiberStack + 64]);  // uninitialised: only the pages the fibers touch are faulted in
+    b_dim = {block.x, block.y, block.z};
+    g_dim = {grid.x, grid.y, grid.z};
+    for (long b = next++; b < nblocks; b = next++) {
+      const Idx bidx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y))};
+      run_block(block, bidx, lds_bytes, fn, stacks.get());
+    }
+  };
+  if (nworkers == 1) { worker(); return; }
+  std::vector<std::thread> th;
+  for (int w = 0; w < nworkers; ++w) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+}
+}  // namespace hipemu
+
+// kernel<<<grid, block, lds, stream>>>(args...): every block runs to completion before the call returns
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) hipemu::launch((grid), (block), (lds), [=] { kern(__VA_ARGS__); })
+
+#define threadIdx hipemu::blk->cur->tidx
+#define blockIdx hipemu::blk->bidx
+#define blockDim hipemu::b_dim
+#define gridDim hipemu::g_dim
+#define __syncthreads() hipemu::barrier_wait(hipemu::blk->bar)
+#define __shfl_xor(v, m, w) hipemu::shfl_xor((v), (m), (w))
+#define __amdgpu_buffer_rsrc_t hipemu::Rsrc
+#define __builtin_amdgcn_make_buffer_rsrc hipemu::make_rsrc
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu::raw_buffer_load_b128
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu::mfma_32x32x16_f16
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2_f32
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)

@@ -1,0 +1,127 @@
+// run_kernels.cpp — runs kernels of f5-tts_amd/csrc on the CPU through hipemu.h (TEST INFRASTRUCTURE, driven by tests/test_hipemu.py).
+// Tensors travel as raw little-endian files in the directory given as argv[1]; argv[2] is the mode, the rest its integer arguments.
+#include "hipemu.h"
+// kernel sources, exactly as hipcc sees them
+#include "bigvgan_kernels.h"
+#include "conv_gemm.h"
+
+#include <string>
+
+static std::string g_dir;
+template <typename T>
+static std::vector<T> rd(const char* name, bool optional = false) {
+  std::vector<T> v;
+  FILE* f = fopen((g_dir + "/" + name).c_str(), "rb");
+  if (!f) {
+    if (optional) return v;
+    fprintf(stderr, "missing %s\n", name);
+    exit(2);
+  }
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  v.resize(n / sizeof(T));
+  if (fread(v.data(), 1, n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return v;
+}
+template <typename T>
+static void wr(const char* name, const std::vector<T>& v) {
+  FILE* f = fopen((g_dir + "/" + name).c_str(), "wb");
+  fwrite(v.data(), sizeof(T), v.size(), f);
+  fclose(f);
+}
+
+template <typename T, int NSPLIT, int TM, int TN>
+static void run_gemm(bool conv, GemmCore g, ConvTaps tp, EpiStore e, int batch) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  const int lds = gemm_lds_bytes<T, NSPLIT, TM, TN, 2, 2>();
+  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
+  if (conv) hipemu::launch(grid, dim3(256), lds, [&] { conv_gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>(g, tp, e); });
+  else hipemu::launch(grid, dim3(256), lds, [&] { gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>(g, e); });
+}
+template <typename T, int NSPLIT>
+static void run_gemm_tile(bool conv, int tile, GemmCore g, ConvTaps tp, EpiStore e, int batch) {
+  if (tile == 1) run_gemm<T, NSPLIT, 2, 1>(conv, g, tp, e, batch);
+  else run_gemm<T, NSPLIT, 2, 2>(conv, g, tp, e, batch);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  g_dir = argv[1];
+  const std::string mode = argv[2];
+  auto A = [&](int i) { return atoi(argv[3 + i]); };
+  if (mode == "aa") {  // B L C logscale op(-1 = fp32 [B,L,C] out) cpad
+    const int B = A(0), L = A(1), C = A(2), ls = A(3), op = A(4), cpad = A(5);
+    auto x = rd<float>("x.bin"), al = rd<float>("alpha.bin"), be = rd<float>("beta.bin"), f = rd<float>("f.bin");
+    std::vector<float> y((size_t)B * L * C, -777.f);
+    std::vector<char> oper(op >= 0 ? (size_t)B * L * cpad * (op == OP_F16 ? 2 : 4) : 0, (char)0x5a);
+    AaArgs a{};
+    a.x = x.data(); a.y = y.data(); a.alpha = al.data(); a.beta = be.data(); a.L = L; a.C = C; a.logscale = ls;
+    a.oper = op >= 0 ? oper.data() : nullptr; a.op = op >= 0 ? op : OP_F32; a.cpad = op >= 0 ? cpad : C;
+    for (int j = 0; j < 12; ++j) a.f[j] = f[j];
+    constexpr int TL = 32;
+    const int chunks = (L + TL - 1) / TL;
+    dim3 grid(((op >= 0 ? cpad : C) + 63) / 64, (chunks + 3) / 4, B);
+    hipemu::launch(grid, dim3(64, 4), 0, [&] { aa_snake_kernel<TL>(a); });
+    if (op >= 0) wr("out.bin", oper); else wr("out.bin", y);
+  } else if (mode == "im2col") {  // B L C ntaps shift0 dstep cpad op sb sl sc
+    const int B = A(0), L = A(1), C = A(2), nt = A(3), s0 = A(4), ds = A(5), cpad = A(6), op = A(7);
+    auto src = rd<float>("src.bin");
+    const int64_t K = (int64_t)nt * cpad, ld = K * (op == OP_F16X3 ? 2 : 1);
+    std::vector<char> out((size_t)B * L * ld * (op == OP_F32 ? 4 : 2), (char)0x5a);
+    ColArgs a{};
+    a.src = src.data(); a.sb = A(8); a.sl = A(9); a.sc = A(10); a.L = L; a.C = C; a.ntaps = nt; a.shift0 = s0; a.dstep = ds; a.cpad = cpad;
+    a.op = op; a.out = out.data(); a.ldo = ld; a.ob = (int64_t)L * ld;
+    const int64_t n = (int64_t)L * (nt * cpad / 4);
+    hipemu::launch(dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, [&] { im2col_kernel(a); });
+    wr("out.bin", out);
+  } else if (mode == "mean") {  // nk n
+    const int nk = A(0);
+    const int64_t n = A(1);
+    std::vector<float> r[4], out(n);
+    for (int j = 0; j < nk; ++j) r[j] = rd<float>(("r" + std::to_string(j) + ".bin").c_str());
+    hipemu::launch(dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, [&] {
+      mean_kernel(r[0].data(), nk > 1 ? r[1].data() : nullptr, nk > 2 ? r[2].data() : nullptr, nk > 3 ? r[3].data() : nullptr, nk, (float)nk, n / 4, out.data());
+    });
+    wr("out.bin", out);
+  } else if (mode == "post") {  // B L C use_tanh has_bias
+    const int B = A(0), L = A(1), C = A(2), ut = A(3), hb = A(4);
+    auto y = rd<float>("y.bin"), w7 = rd<float>("w7.bin"), bias = rd<float>("bias.bin", true);
+    std::vector<float> out((size_t)B * L);
+    hipemu::launch(dim3((L + 255) / 256, B), dim3(256), 7 * C * sizeof(float),
+                   [&] { conv_post_kernel(y.data(), w7.data(), hb ? bias.data() : nullptr, L, C, ut, out.data()); });
+    wr("out.bin", out);
+  } else if (mode == "gemm" || mode == "conv") {  // op M N K batch tile has_res [ntaps shift0 dstep cpad]
+    const bool conv = mode == "conv";
+    const int op = A(0), M = A(1), N = A(2), K = A(3), batch = A(4), tile = A(5), has_res = A(6);
+    auto Ab = rd<char>("A.bin"), Wb = rd<char>("W.bin");
+    auto bias = rd<float>("bias.bin"), res = rd<float>("res.bin", true);
+    std::vector<float> out((size_t)batch * M * N, -777.f);
+    const int mul = op == OP_F16X3 ? 2 : 1;
+    GemmCore g{};
+    ConvTaps tp{};
+    g.A = Ab.data(); g.W = Wb.data();
+    g.ldw = (int64_t)K * mul; g.strideW = 0; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N; g.group_m = 1;
+    if (conv) {
+      const int cpad = A(10);
+      tp = ConvTaps{A(7), A(8), A(9), cpad * (op == OP_F16 ? 2 : 4) / GEMM_KTB};
+      g.lda = (int64_t)cpad * mul;
+    } else {
+      g.lda = (int64_t)K * mul;
+    }
+    g.strideA = (int64_t)M * g.lda;
+    EpiStore e{};
+    e.alpha = 1.f; e.act = ACT_NONE; e.bias = bias.data(); e.out32 = out.data(); e.ldo = N; e.ldres = N; e.res = has_res ? res.data() : nullptr;
+    e.zdiv = 1; e.so1 = (int64_t)M * N; e.so2 = 0;
+    switch (op) {
+      case OP_F32: run_gemm_tile<float, 1>(conv, tile, g, tp, e, batch); break;
+      case OP_F16: run_gemm_tile<f16, 1>(conv, tile, g, tp, e, batch); break;
+      default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
+    }
+    wr("out.bin", out);
+  } else {
+    return 1;
+  }
+  return 0;
+}
