@@ -301,6 +301,13 @@ GemmCore core(const void* A, int64_t lda, const void* Wt, int64_t ldw, int M, in
   g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
   return g;
 }
+// stream-K (option "gemm_streamk"): hand the launch heuristic the context's workspace; it falls back to the plain tiling when the shape
+// does not suit the schedule.  Only for launches that have the GPU to themselves (the packed schedule on one stream).
+constexpr int SK_GRID = 256;
+GemmCore sk_attach(f5hip_ctx* ctx, GemmCore g) {
+  if (ctx->sk_now) { g.sk_ws = ctx->sk_ws.p; g.sk_grid = SK_GRID; g.sk_variant = ctx->gemm_sk; }
+  return g;
+}
 EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_NONE) {
   EpiStore e{};
   e.alpha = 1.f; e.act = act; e.bias = bias; e.out32 = out32; e.ldo = ldo; e.ldres = ldo;
@@ -645,6 +652,11 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
 
 // ---- workspace -----------------------------------------------------------------------------------
 int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_attn) {
+  if (ctx->gemm_sk && !ctx->sk_ws.p) {  // stream-K workspace: [grid][2] slots of 128 KB + [grid][2] flags + error word, zeroed once (the
+                                        // flags clean themselves: gemm_skrs.h)
+    const size_t bytes = (size_t)SK_GRID * 2 * 131072 + ((size_t)SK_GRID * 2 + 4) * sizeof(int);
+    HIPCHK(ctx->sk_ws.ensure(bytes, nullptr, true));
+  }
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
   const bool unett = c.backbone == 1, mmdit = c.backbone == 2;
@@ -845,7 +857,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D);
+    GemmCore g = sk_attach(ctx, core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -876,6 +888,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   const float* cconst = ctx->cconst.as<float>() + r0 * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int npl = op == OP_F16X3 ? 3 : 1;
+  ctx->sk_now = ctx->gemm_sk != 0 && br < 0 && op != OP_F32 && ctx->sk_ws.p;  // workspace: ensure_workspace (never inside a capture)
 
   {  // InputEmbedding.proj: only the x columns are per-step (dit.py:162); cond/text part is in cconst
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
@@ -935,7 +948,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
+      GemmCore g = sk_attach(ctx, core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -946,14 +959,14 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
+      GemmCore g = sk_attach(ctx, core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
+      GemmCore g = sk_attach(ctx, core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -978,6 +991,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     GemmCore g = core(A, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
     HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>() + r0 * mel, mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
+  ctx->sk_now = false;
   if (br < 0) {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
     HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
@@ -1324,7 +1338,7 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
+  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && !ctx->gemm_sk && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1424,7 +1438,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
-                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes};
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->sk_ws};
   for (DevBuf* b : bufs) b->release();
   if (ctx->blob) (void)hipFree(ctx->blob);
   delete ctx;
@@ -1486,6 +1500,11 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "profile") ctx->profile = value != 0;
   else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
   else if (k == "branch_streams") { ctx->branch_streams = (int)value; ctx->ws_epoch++; }
+  else if (k == "gemm_streamk") {  // 0 = off; 42 / 43 = the DiT block GEMMs of the PACKED schedule through gemm_skrs.h (256x128 / 128x256 tiles)
+    if (value != 0 && value != 42 && value != 43) FAIL(F5HIP_ERR_INVALID, "gemm_streamk must be 0, 42 or 43");
+    ctx->gemm_sk = (int)value;
+    ctx->ws_epoch++;
+  }
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
   return F5HIP_OK;
 }

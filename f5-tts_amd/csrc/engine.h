@@ -177,6 +177,11 @@ struct f5hip_ctx {
   } graph_key;
   uint64_t ws_epoch = 0;
   hipStream_t cap_stream = nullptr;
+  // option "gemm_streamk": 0 off, 42 / 43 = DiT block GEMMs of the packed schedule through gemm_skrs.h; sk_now = set while run_step
+  // enqueues launches that have the GPU to themselves; sk_ws = its workspace (slots + self-cleaning flags)
+  int gemm_sk = 0;
+  bool sk_now = false;
+  DevBuf sk_ws;
   // cond / uncond branches on two streams (small batches): -1 auto, 0 off, 1 on
   int branch_streams = -1;
   hipStream_t side_stream = nullptr;

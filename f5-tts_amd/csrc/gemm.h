@@ -30,6 +30,7 @@ struct GemmCore {
   // (flags, error word), owned by the caller and private to one stream; null = plain tiled launch only
   void* sk_ws;
   int sk_grid;        // resident workgroups to spread the work over (multiple of 8)
+  int sk_variant;     // which stream-K kernel the launch heuristic should try when sk_ws is set (0 = none; 42 / 43 = gemm_skrs.h)
 };
 
 // Generic store epilogue:

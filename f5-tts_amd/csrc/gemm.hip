@@ -4,6 +4,7 @@
 
 #include "kernels.h"
 #include "gemm_sk.h"
+#include "gemm_skrs.h"
 
 namespace {
 
@@ -153,6 +154,37 @@ hipError_t launch_sk(const GemmCore& g, const Epi& e, hipStream_t s) {
   return hipGetLastError();
 }
 
+// stream-K with the reduce-scattered epilogue (gemm_skrs.h).  Workspace (caller-owned, private to one stream, flags zeroed once):
+// [grid][2] slots of 128 KB, then [grid][2] int flags, then the error word.
+template <typename T, int NSPLIT, typename Epi, bool ROWS256>
+hipError_t launch_skrs(const GemmCore& g, const Epi& e, hipStream_t s) {
+  constexpr int WGM = ROWS256 ? 4 : 2, WGN = ROWS256 ? 2 : 4, BM = 64 * WGM, BN = 64 * WGN;
+  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, 2, 2, WGM, WGN, 3>();
+  auto kern = gemm_skrs_kernel<T, NSPLIT, Epi, WGM, WGN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    attr_done = true;
+  }
+  if (!g.sk_ws || g.sk_grid < 8 || (g.sk_grid & 7)) return hipErrorInvalidValue;
+  if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
+    return hipErrorInvalidValue;
+  SkrsArgs sk{};
+  sk.ws = reinterpret_cast<float*>(g.sk_ws);
+  sk.flags = reinterpret_cast<int*>(reinterpret_cast<char*>(g.sk_ws) + (int64_t)g.sk_grid * 2 * SK_SLOT_BYTES);
+  sk.err = sk.flags + 2 * g.sk_grid;
+  sk.tiles_n = (g.N + BN - 1) / BN;
+  sk.tiles = ((g.M + BM - 1) / BM) * sk.tiles_n;
+  const int kbytes = g.K * (int)sizeof(T) * (NSPLIT == 3 ? 2 : 1);
+  sk.kt = (kbytes + GEMM_KTB - 1) / GEMM_KTB;
+  // every share must be non-empty and at least an eighth of a tile long: a tile then has at most 9 contributors (16 units to deal out)
+  const int64_t min_class_iters = (int64_t)(sk.tiles / 8) * sk.kt, gx = g.sk_grid >> 3;
+  if (min_class_iters < gx || min_class_iters / gx < (sk.kt + 7) / 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(g.sk_grid), dim3(512), lds, s, g, e, sk);
+  return hipGetLastError();
+}
+
 // microbenchmark ablations of the 128x128 variant (variant id 8 + ABL); EpiStore only
 template <typename T, int NSPLIT, int ABL, typename Epi, int VID = 2>
 hipError_t launch_abl(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
@@ -191,6 +223,8 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 31: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 4, 3>(g, e, batch, s);  // 128x256, 8 waves of 64x64, 3-stage ring
     case 40: return launch_sk<T, NSPLIT, Epi, true>(g, e, s);   // stream-K, 256x128 tiles
     case 41: return launch_sk<T, NSPLIT, Epi, false>(g, e, s);  // stream-K, 128x256 tiles
+    case 42: return launch_skrs<T, NSPLIT, Epi, true>(g, e, s);   // stream-K, reduce-scattered epilogue, 256x128 tiles
+    case 43: return launch_skrs<T, NSPLIT, Epi, false>(g, e, s);  // stream-K, reduce-scattered epilogue, 128x256 tiles
     case 24: return launch_glds<T, NSPLIT, 2, 1, Epi, 2, 2, 3, 2>(g, e, batch, s);     // ablation: variant 6 with 2 of the 3 fp16x3 products
     case 25: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 2>(g, e, batch, s);     // ablation: variant 21 with 2 of the 3 fp16x3 products
     case 23: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 1>(g, e, batch, s);  // variant 21 + s_setprio around the MFMA clusters
@@ -224,6 +258,12 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   static const int gm_env = [] { const char* v = getenv("F5HIP_GEMM_GROUPM"); return v ? atoi(v) : -1; }();  // tuning knob
   // default: groups of 4 row-tiles once the grid is many waves deep (+2-5 % at M >= 22k, L2-miss traffic / 2), plain order otherwise
   if (g.group_m == 0) g.group_m = gm_env >= 0 ? gm_env : (g.M >= 8192 ? 4 : 1);
+  // stream-K on request of the caller (GemmCore.sk_variant + workspace): only where the schedule applies (launch_skrs checks the share
+  // sizes), otherwise the plain heuristic
+  if (variant < 0 && g.sk_ws && g.sk_variant && batch == 1 && g.M > 1024 && op != OP_F32) {
+    const hipError_t r = op == OP_F16 ? launch_tiled<f16, 1, Epi>(g, e, batch, g.sk_variant, s) : launch_tiled<f16, 3, Epi>(g, e, batch, g.sk_variant, s);
+    if (r != hipErrorInvalidValue) return r;
+  }
   switch (op) {
     case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, variant, s);
     case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, variant, s);

@@ -1,5 +1,7 @@
 // microbench.cpp — kernel-level measurement entry points of the C ABI (f5hip_bench_*): time ONE kernel of the hot path on
 // synthetic operands with HIP events on the launch stream.  Used by tools/kernel_bench.py to tune tile variants; no model state.
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -87,10 +89,11 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   g.A = op == OP_F32 ? (const void*)a32 : (const void*)ah;
   g.W = op == OP_F32 ? (const void*)w32 : (const void*)wh;
   g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
-  if (variant == 40 || variant == 41) {  // stream-K: private workspace (grid x 128 KB slots + flags + error word), zeroed flags
+  const size_t sk_slots_per_wg = (variant == 42 || variant == 43) ? 2 : 1;  // gemm_skrs.h: slot A + slot B, and two flags, per workgroup
+  if (variant >= 40 && variant <= 43) {  // stream-K: private workspace (slots of 128 KB + flags + error word), zeroed flags
     const char* gv = getenv("KB_SKGRID");
     g.sk_grid = gv ? atoi(gv) : 256;
-    const size_t slots = (size_t)g.sk_grid * 131072, total = slots + ((size_t)g.sk_grid + 2) * sizeof(int) + (size_t)g.sk_grid * 64;
+    const size_t slots = (size_t)g.sk_grid * sk_slots_per_wg * 131072, total = slots + ((size_t)g.sk_grid * sk_slots_per_wg + 2) * sizeof(int) + (size_t)g.sk_grid * 64;
     char* ws = t.get<char>(total);
     if (!ws || hipMemsetAsync(ws + slots, 0, total - slots, s) != hipSuccess) return F5HIP_ERR_HIP;
     g.sk_ws = ws;
@@ -120,12 +123,30 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
       for (size_t i = 0; i < nb; ++i)
         if (ref[i] != got[i]) { if (!bad) first = i; ++bad; }
       int errw = 0;
-      if (g.sk_ws) (void)hipMemcpy(&errw, reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * 131072 + (size_t)g.sk_grid * sizeof(int), sizeof(int), hipMemcpyDeviceToHost);
-      fprintf(stderr, "KB_CHECK variant %d rep %d: %zu of %zu bytes differ from variant 1 (first at %zu), sk err word %d\n", variant, rep, bad, nb, first, errw);
+      if (g.sk_ws) (void)hipMemcpy(&errw, reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * sk_slots_per_wg * 131072 + (size_t)g.sk_grid * sk_slots_per_wg * sizeof(int), sizeof(int), hipMemcpyDeviceToHost);
+      // stream-K sums the k-tiles of a tile in a different (fixed) association than one workgroup does: report the numeric distance too
+      double maxd = 0.0, maxv = 0.0;
+      if (op == OP_F32) {
+        const float* a = reinterpret_cast<const float*>(ref.data());
+        const float* b = reinterpret_cast<const float*>(got.data());
+        for (size_t i = 0; i < nb / 4; ++i) { maxd = std::max(maxd, (double)fabsf(a[i] - b[i])); maxv = std::max(maxv, (double)fabsf(a[i])); }
+      } else {
+        const f16* a = reinterpret_cast<const f16*>(ref.data());
+        const f16* b = reinterpret_cast<const f16*>(got.data());
+        for (size_t i = 0; i < nb / 2; ++i) { maxd = std::max(maxd, (double)fabsf((float)a[i] - (float)b[i])); maxv = std::max(maxv, (double)fabsf((float)a[i])); }
+      }
+      int flags_set = 0;
+      if (g.sk_ws) {
+        std::vector<int> fl((size_t)g.sk_grid * sk_slots_per_wg);
+        (void)hipMemcpy(fl.data(), reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * sk_slots_per_wg * 131072, fl.size() * sizeof(int), hipMemcpyDeviceToHost);
+        for (int v : fl) flags_set += v != 0;
+      }
+      fprintf(stderr, "KB_CHECK variant %d rep %d: %zu of %zu bytes differ from variant 1 (first at %zu), max |diff| %.3g of max |value| %.3g, sk err word %d, flags left set %d\n",
+              variant, rep, bad, nb, first, maxd, maxv, errw, flags_set);
     }
   }
   const int rc = time_it([&] { return launch_gemm_store_variant(op, g, e, 1, variant, s); }, iters, s, avg_ms);
-  if (g.sk_ws && getenv("F5HIP_SK_DEBUG")) {  // phase stamps of the last launch (10 ns ticks relative to the earliest start)
+  if (g.sk_ws && sk_slots_per_wg == 1 && getenv("F5HIP_SK_DEBUG")) {  // phase stamps of the last launch (10 ns ticks relative to the earliest start)
     std::vector<long long> st((size_t)g.sk_grid * 8);
     (void)hipMemcpy(st.data(), reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * 131072 + ((size_t)g.sk_grid + 2) * sizeof(int), st.size() * 8, hipMemcpyDeviceToHost);
     long long t0 = st[0];

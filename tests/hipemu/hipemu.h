@@ -273,6 +273,67 @@ inline void run_block(dim3 block, Idx bidx, size_t lds_bytes, const std::functio
   blk = prev;
 }
 
+// ---- cooperative launch: ALL blocks alive at once (fibers of one OS thread), for kernels whose blocks talk to each other through
+// global memory (stream-K: flag spins).  A spinning thread calls spin_yield(); the scheduler then runs everybody else.
+inline thread_local long spin_count = 0;
+inline void spin_yield() {
+  if (++spin_count > 50000000L) { fprintf(stderr, "hipemu: spin limit (a flag that is never set?)\n"); abort(); }
+  blk->cur->wait_bar = nullptr;
+  yield_to_scheduler();
+}
+inline void launch_coop(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn, size_t stack_bytes = 64 * 1024) {
+  const int nt = (int)(block.x * block.y * block.z), nw = (nt + 63) / 64;
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  std::unique_ptr<char[]> stacks(new char[(size_t)nblocks * nt * stack_bytes + 64]);
+  std::vector<std::unique_ptr<BlockCtx>> ctxs;
+  for (long b = 0; b < nblocks; ++b) {
+    ctxs.emplace_back(new BlockCtx());
+    BlockCtx& ctx = *ctxs.back();
+    ctx.bar.expected = nt;
+    ctx.waves.resize(nw);
+    for (int w = 0; w < nw; ++w) ctx.waves[w].bar.expected = std::min(64, nt - 64 * w);
+    ctx.lds.resize(lds_bytes + 64);
+    ctx.fibers.resize(nt);
+    ctx.bidx = {(unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y))};
+    ctx.fn = &fn;
+    for (int t = 0; t < nt; ++t) {
+      Fiber& f = ctx.fibers[t];
+      f.tidx = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y, (unsigned)t / (block.x * block.y)};
+      f.lane = t & 63;
+      f.wave = t >> 6;
+      uintptr_t top = (reinterpret_cast<uintptr_t>(stacks.get()) + ((size_t)b * nt + t + 1) * stack_bytes) & ~uintptr_t(15);
+      void** sp = reinterpret_cast<void**>(top);
+      *--sp = nullptr;
+      *--sp = reinterpret_cast<void*>(&fiber_entry);
+      for (int r = 0; r < 6; ++r) *--sp = nullptr;
+      f.sp = sp;
+    }
+  }
+  b_dim = {block.x, block.y, block.z};
+  g_dim = {grid.x, grid.y, grid.z};
+  spin_count = 0;
+  BlockCtx* prev = blk;
+  long remaining = nblocks * nt;
+  while (remaining) {
+    bool progressed = false;
+    for (long b = 0; b < nblocks; ++b) {
+      BlockCtx& ctx = *ctxs[b];
+      for (int t = 0; t < nt; ++t) {
+        Fiber& f = ctx.fibers[t];
+        if (f.done || (f.wait_bar && f.wait_bar->gen == f.wait_gen)) continue;
+        f.wait_bar = nullptr;
+        blk = &ctx;
+        ctx.cur = &f;
+        hipemu_switch(&ctx.sched_sp, f.sp);
+        progressed = true;
+        if (f.done) --remaining;
+      }
+    }
+    if (!progressed) { fprintf(stderr, "hipemu: deadlock (every live thread waits at a barrier)\n"); abort(); }
+  }
+  blk = prev;
+}
+
 // run fn() once per HIP thread of a grid x block launch; every block has completed when this returns
 inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn) {
   const int nt = (int)(block.x * block.y * block.z);

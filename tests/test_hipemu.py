@@ -313,3 +313,48 @@ def test_emulated_library_rejects_what_the_real_one_rejects(emu_lib):
     assert emu_lib.f5hip_bigvgan_forward(ctx, C.c_void_p(x.data_ptr()), 1, 1, 1, 0, C.c_void_p(x.data_ptr()), None) == 3  # not finalised
     assert emu_lib.f5hip_bigvgan_set_option(ctx, b"conv_impl", 7) == 1
     emu_lib.f5hip_bigvgan_destroy(ctx)
+
+
+# ---- stream-K GEMM with the reduce-scattered epilogue (csrc/gemm_skrs.h): all workgroups alive at once, talking through flags ----------
+def _gelu_tanh(x):
+    return 0.5 * x * (1.0 + np.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+@pytest.mark.parametrize("case", [
+    # op, rows256, M, N, K, grid, act       what the share layout exercises
+    (OP_F16X3, 1, 1280, 1024, 160, 24, 0),  # 5 tiles per class, KT 5, shares 8/8/9: TAIL + FULL + HEAD inside one share
+    (OP_F16, 0, 300, 520, 200, 16, 0),      # 128x256 tiles, ragged M / N / K, classes with 1-2 tiles, HEAD + TAIL
+    (OP_F32, 1, 256, 1024, 224, 32, 3),     # one tile per class, KT 7 over 4 workgroups: HEAD + MIDDLE + MIDDLE + TAIL, tanh-GELU epilogue
+], ids=["x3_multi_tile_shares", "f16_ragged", "f32_middles_gelu"])
+def test_streamk_reduce_scatter_kernel(exe, tmp_path, case):
+    op, rows256, Mr, N, K, grid, act = case
+    rng = np.random.default_rng(Mr + N)
+    A = rng.standard_normal((Mr, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((Mr, N)).astype(np.float32)
+    run(exe, tmp_path, "skrs", op, Mr, N, K, rows256, grid, 1, act, 2, 0, A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias, res=res)
+    got = np.frombuffer(open(os.path.join(tmp_path, "out.bin"), "rb").read(), dtype="<f4").reshape(Mr, N)
+    again = np.frombuffer(open(os.path.join(tmp_path, "out2.bin"), "rb").read(), dtype="<f4").reshape(Mr, N)
+    status = np.frombuffer(open(os.path.join(tmp_path, "status.bin"), "rb").read(), dtype="<i4")
+    assert status.tolist() == [0, 0, 0, 0], "flags left set / spin time-out (per launch: non-zero flags, err word)"
+    pre = operand_values(A, op) @ operand_values(W, op).T + bias
+    want = (_gelu_tanh(pre) if act == 3 else pre) + res
+    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+    assert np.array_equal(got, again), "a second launch over the same workspace must reproduce the first bit for bit"
+
+
+def test_streamk_reduce_scatter_kernel_writes_the_next_gemms_operand_planes(exe, tmp_path):
+    """The FF1 epilogue through the stream-K kernel: bias + tanh-GELU, then the packed fp16 hi/lo operand rows FF2 reads."""
+    op, Mr, N, K, grid = OP_F16X3, 300, 256, 192, 16
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((Mr, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    run(exe, tmp_path, "skrs", op, Mr, N, K, 1, grid, 0, 3, 2, 1, A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias)
+    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Mr, N, OP_F16X3)
+    status = np.frombuffer(open(os.path.join(tmp_path, "status.bin"), "rb").read(), dtype="<i4")
+    assert status.tolist() == [0, 0, 0, 0]
+    want = _gelu_tanh(operand_values(A, op) @ operand_values(W, op).T + bias)
+    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
+    assert open(os.path.join(tmp_path, "out.bin"), "rb").read() == open(os.path.join(tmp_path, "out2.bin"), "rb").read()

@@ -78,9 +78,10 @@ def test_partition_invariants(tiles, KT, G):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# Protocol model of the NEXT step: stream-K with the epilogue reduce-scattered over a tile's contributors.
-# Each contributor publishes its partial sums and finishes the accumulator units it owns (unit q of every wave belongs to contributor
-# q % c); the head owner does so at once, the others at the END of their share (their partner's sums only exist then).  The model
+# Protocol model of f5-tts_amd/csrc/gemm_skrs.h (variants 42 / 43): stream-K with the epilogue reduce-scattered over a tile's
+# contributors.  Each contributor publishes its partial sums and finishes the accumulator units it owns (unit u of every lane belongs to
+# contributor u % c) at the END of its share — the head owner right after its head (its last segment), the others after their whole
+# share (their partners' sums only exist then).  tests/test_hipemu.py runs the kernel source itself on the CPU; this model
 # checks, under random speeds and limited residency with in-order dispatch, that the protocol never deadlocks, finishes every unit
 # exactly once from all c partial sums, and leaves every flag at zero.
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -95,7 +96,7 @@ def simulate_reduce_scatter(tiles, KT, gx, resident, seed):
     ix = tiles * KT
     assert ix >= gx
     sb = lambda i: ix * i // gx  # noqa: E731
-    UNITS = 4
+    UNITS = 16
     ready = {}         # (wg, slot) -> True once published
     readers_left = {}  # (wg, slot) -> external readers still to come
     finished = {}      # (tile, unit) -> list of contributor partials summed

@@ -13,7 +13,7 @@ from f5_tts_amd import config  # noqa: E402
 from f5_tts_amd.binding import PRECISIONS  # noqa: E402
 from f5_tts_amd.engine import F5HipEngine  # noqa: E402
 
-VARIANTS = {-1: "auto", 0: "64x128", 1: "128x64", 2: "128x128", 3: "256x128", 4: "128x256", 5: "256x256", 6: "glds128x64", 7: "glds128x128", 8: "64x64", 10: "128x192", 13: "glds256x128w4", 21: "glds256sq_w8a", 22: "glds256sq_w8b", 23: "glds256sq_prio", 26: "glds128x64w2", 27: "glds128x64w2s2", 28: "glds128x128s2", 29: "glds64x128w2", 30: "glds256x128w8", 31: "glds128x256w8", 40: "sk256x128", 41: "sk128x256", 24: "glds128x64_2of3", 25: "glds256sq_2of3", 14: "glds128x256w4", 9: "noLoad", 10: "noLdsSt", 11: "noLd+noSt", 12: "noMFMA", 15: "noAll", 17: "s:noEpi", 18: "s:noMFMA", 19: "s:noAll", 20: "s:noStage"}
+VARIANTS = {-1: "auto", 0: "64x128", 1: "128x64", 2: "128x128", 3: "256x128", 4: "128x256", 5: "256x256", 6: "glds128x64", 7: "glds128x128", 8: "64x64", 10: "128x192", 13: "glds256x128w4", 21: "glds256sq_w8a", 22: "glds256sq_w8b", 23: "glds256sq_prio", 26: "glds128x64w2", 27: "glds128x64w2s2", 28: "glds128x128s2", 29: "glds64x128w2", 30: "glds256x128w8", 31: "glds128x256w8", 40: "sk256x128", 41: "sk128x256", 42: "skrs256x128", 43: "skrs128x256", 24: "glds128x64_2of3", 25: "glds256sq_2of3", 14: "glds128x256w4", 9: "noLoad", 10: "noLdsSt", 11: "noLd+noSt", 12: "noMFMA", 15: "noAll", 17: "s:noEpi", 18: "s:noMFMA", 19: "s:noAll", 20: "s:noStage"}
 
 
 def main():
