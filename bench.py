@@ -143,6 +143,7 @@ def main():
     eng.set_option("branch_streams", a.branch_streams)
     if os.environ.get("F5HIP_BENCH_STREAMK"):  # experiment switch (tools/r2_first_call.sh): DiT block GEMMs through gemm_skrs.h
         eng.set_option("gemm_streamk", int(os.environ["F5HIP_BENCH_STREAMK"]))
+        eng.set_option("gemm_streamk_split", int(os.environ.get("F5HIP_BENCH_STREAMK_SPLIT", "0")))
     if big:  # the generator is a context of its own (as in the reference); every rank builds the same seeded weights
         from f5_tts_amd.bigvgan import F5HipBigVGAN
 

@@ -303,9 +303,14 @@ GemmCore core(const void* A, int64_t lda, const void* Wt, int64_t ldw, int M, in
 }
 // stream-K (option "gemm_streamk"): hand the launch heuristic the context's workspace; it falls back to the plain tiling when the shape
 // does not suit the schedule.  Only for launches that have the GPU to themselves (the packed schedule on one stream).
-constexpr int SK_GRID = 256;
+constexpr int SK_GRID = 256;  // one 144 KB workgroup per CU; the two-chain schedule gives each chain half (its own half of the workspace)
+constexpr size_t SK_WS_BYTES = (size_t)SK_GRID * 2 * 131072 + ((size_t)SK_GRID * 2 + 4) * sizeof(int);
 GemmCore sk_attach(f5hip_ctx* ctx, GemmCore g) {
-  if (ctx->sk_now) { g.sk_ws = ctx->sk_ws.p; g.sk_grid = SK_GRID; g.sk_variant = ctx->gemm_sk; }
+  if (ctx->sk_now) {
+    g.sk_ws = ctx->sk_ws.as<char>() + (ctx->sk_chain > 0 ? SK_WS_BYTES : 0);
+    g.sk_grid = ctx->sk_chain >= 0 ? SK_GRID / 2 : SK_GRID;
+    g.sk_variant = ctx->gemm_sk;
+  }
   return g;
 }
 EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_NONE) {
@@ -654,8 +659,7 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
 int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_attn) {
   if (ctx->gemm_sk && !ctx->sk_ws.p) {  // stream-K workspace: [grid][2] slots of 128 KB + [grid][2] flags + error word, zeroed once (the
                                         // flags clean themselves: gemm_skrs.h)
-    const size_t bytes = (size_t)SK_GRID * 2 * 131072 + ((size_t)SK_GRID * 2 + 4) * sizeof(int);
-    HIPCHK(ctx->sk_ws.ensure(bytes, nullptr, true));
+    HIPCHK(ctx->sk_ws.ensure(2 * SK_WS_BYTES, nullptr, true));  // one per kernel chain
   }
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
@@ -888,7 +892,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   const float* cconst = ctx->cconst.as<float>() + r0 * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int npl = op == OP_F16X3 ? 3 : 1;
-  ctx->sk_now = ctx->gemm_sk != 0 && br < 0 && op != OP_F32 && ctx->sk_ws.p;  // workspace: ensure_workspace (never inside a capture)
+  // stream-K only for launches whose workgroups can all be resident: the packed chain alone (grid 256), or — option "gemm_streamk_split" —
+  // the two concurrent chains with half the CUs each (grid 128 + 128).  Workspace: ensure_workspace (never inside a capture).
+  ctx->sk_now = ctx->gemm_sk != 0 && (br < 0 || ctx->gemm_sk_split) && op != OP_F32 && ctx->sk_ws.p;
+  ctx->sk_chain = br;
 
   {  // InputEmbedding.proj: only the x columns are per-step (dit.py:162); cond/text part is in cconst
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
@@ -1338,7 +1345,7 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && !ctx->gemm_sk && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
+  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (!ctx->gemm_sk || ctx->gemm_sk_split) && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1505,6 +1512,7 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
     ctx->gemm_sk = (int)value;
     ctx->ws_epoch++;
   }
+  else if (k == "gemm_streamk_split") { ctx->gemm_sk_split = value != 0; ctx->ws_epoch++; }  // stream-K also under the two-chain schedule
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
   return F5HIP_OK;
 }

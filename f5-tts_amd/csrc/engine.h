@@ -180,7 +180,9 @@ struct f5hip_ctx {
   // option "gemm_streamk": 0 off, 42 / 43 = DiT block GEMMs of the packed schedule through gemm_skrs.h; sk_now = set while run_step
   // enqueues launches that have the GPU to themselves; sk_ws = its workspace (slots + self-cleaning flags)
   int gemm_sk = 0;
+  bool gemm_sk_split = false;  // allow it under the two-chain schedule too (each chain: half the grid, its own workspace half)
   bool sk_now = false;
+  int sk_chain = -1;           // the chain run_step is enqueueing (-1 packed, 0 / 1 cond / uncond)
   DevBuf sk_ws;
   // cond / uncond branches on two streams (small batches): -1 auto, 0 off, 1 on
   int branch_streams = -1;

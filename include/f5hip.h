@@ -209,7 +209,8 @@ int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value);
  * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
  * "gemm_streamk" (0 off (default) / 42 / 43: the DiT block GEMMs of the packed schedule through the stream-K kernel with the
- * reduce-scattered epilogue, csrc/gemm_skrs.h, 256x128 / 128x256 tiles; implies one kernel chain). */
+ * reduce-scattered epilogue, csrc/gemm_skrs.h, 256x128 / 128x256 tiles; implies one kernel chain unless "gemm_streamk_split" is 1: then the two chains
+ * each get half the grid). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
 /* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
  * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */

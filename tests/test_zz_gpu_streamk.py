@@ -88,6 +88,13 @@ def test_full_size_model_with_streamk_block_gemms():
                 assert torch.equal(a, b), "deterministic summation order + clean workspace"
                 assert (a.cpu() - gold)[:, 468:].abs().max().item() < 1e-3
                 assert (a - base).abs().max().item() < 5e-4
+        # the two-chain schedule with half the grid per chain
+        eng.set_option("branch_streams", 1)
+        eng.set_option("gemm_streamk_split", 1)
+        eng.set_option("gemm_streamk", 42)
+        a, _ = model.sample(wav.cuda(), text, duration, **c["kw"])
+        b, _ = model.sample(wav.cuda(), text, duration, **c["kw"])
+        assert torch.equal(a, b) and (a.cpu() - gold)[:, 468:].abs().max().item() < 1e-3
         eng.set_option("gemm_streamk", 0)
     finally:
         eng.close()
