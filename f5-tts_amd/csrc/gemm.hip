@@ -261,7 +261,25 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   // stream-K on request of the caller (GemmCore.sk_variant + workspace): only where the schedule applies (launch_skrs checks the share
   // sizes), otherwise the plain heuristic
   if (variant < 0 && g.sk_ws && g.sk_variant && batch == 1 && g.M > 1024 && op != OP_F32) {
-    const hipError_t r = op == OP_F16 ? launch_tiled<f16, 1, Epi>(g, e, batch, g.sk_variant, s) : launch_tiled<f16, 3, Epi>(g, e, batch, g.sk_variant, s);
+    hipError_t r = hipErrorInvalidValue;
+    bool done = false;
+    if constexpr (std::is_same<Epi, EpiStore>::value) {  // the two DiT shapes have branch-free epilogues (gemm.h EpiFF1 / EpiGateRes)
+      static const bool generic = getenv("F5HIP_SK_GENERIC_EPI") != nullptr;  // A/B switch
+      const bool rows256 = g.sk_variant == 42;
+      if (!generic && op == OP_F16X3 && e.act == ACT_GELU_TANH && e.alpha == 1.f && e.bias && e.out16 && e.out16_lo == e.out16 + 32 && e.pk16 && e.ldo16 &&
+          !e.out32 && !e.res && !e.colscale && !e.rowmask && !e.out2 && !e.zdiv) {
+        const EpiFF1 f{e.bias, e.out16, e.ldo16};
+        r = rows256 ? launch_skrs<f16, 3, EpiFF1, true>(g, f, s) : launch_skrs<f16, 3, EpiFF1, false>(g, f, s);
+        done = true;
+      } else if (!generic && e.act == ACT_NONE && e.alpha == 1.f && e.bias && e.colscale && e.out32 && e.res == e.out32 && e.ldres == e.ldo && !e.out16 &&
+                 !e.out2 && !e.zdiv && (!e.rowmask || (e.mask_mode == 1 && e.smask == 0))) {
+        const EpiGateRes f{e.bias, e.colscale, e.rowmask, e.out32, e.ldo};
+        if (op == OP_F16) r = rows256 ? launch_skrs<f16, 1, EpiGateRes, true>(g, f, s) : launch_skrs<f16, 1, EpiGateRes, false>(g, f, s);
+        else r = rows256 ? launch_skrs<f16, 3, EpiGateRes, true>(g, f, s) : launch_skrs<f16, 3, EpiGateRes, false>(g, f, s);
+        done = true;
+      }
+    }
+    if (!done) r = op == OP_F16 ? launch_tiled<f16, 1, Epi>(g, e, batch, g.sk_variant, s) : launch_tiled<f16, 3, Epi>(g, e, batch, g.sk_variant, s);
     if (r != hipErrorInvalidValue) return r;
   }
   switch (op) {

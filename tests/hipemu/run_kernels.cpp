@@ -121,8 +121,11 @@ int main(int argc, char** argv) {
       default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
     }
     wr("out.bin", out);
-  } else if (mode == "skrs") {  // op M N K rows256 grid has_res act launches pk_out
+  } else if (mode == "skrs") {  // op M N K rows256 grid has_res act launches pk_out special(0 EpiStore, 1 EpiFF1, 2 EpiGateRes)
     const int op = A(0), M = A(1), N = A(2), K = A(3), rows256 = A(4), grid = A(5), has_res = A(6), act = A(7), launches = A(8), pk_out = A(9);
+    const int special = argc > 13 ? A(10) : 0;
+    auto gate = rd<float>("gate.bin", true);
+    auto rowmask = rd<uint8_t>("rowmask.bin", true);
     auto Ab = rd<char>("A.bin"), Wb = rd<char>("W.bin");
     auto bias = rd<float>("bias.bin"), res = rd<float>("res.bin", true);
     std::vector<float> out((size_t)M * N, -777.f);
@@ -150,12 +153,25 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < launches; ++rep) {
       std::fill(out.begin(), out.end(), -777.f);
       std::fill(out16.begin(), out16.end(), (f16)-7.f);
+      if (special == 2 || (has_res && !gate.empty())) {  // gated residual, in place: out starts as the residual stream
+        std::copy(res.begin(), res.end(), out.begin());
+        e.res = out.data();
+        e.colscale = gate.data();
+        e.rowmask = rowmask.empty() ? nullptr : rowmask.data();
+        e.mask_mode = 1;
+      }
       auto body = [&](auto tag_t, auto tag_ns) {
         using T = decltype(tag_t);
         constexpr int NS = decltype(tag_ns)::value;
         const int lds = gemm_lds_bytes<T, NS, 2, 2, 2, 4>() / 2 * 3;  // 3 stages of (BM + BN) x 128 B
-        if (rows256) hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, EpiStore, 4, 2>(g, e, sk); });
-        else hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, EpiStore, 2, 4>(g, e, sk); });
+        auto go = [&](auto epi) {
+          using E = decltype(epi);
+          if (rows256) hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, E, 4, 2>(g, epi, sk); });
+          else hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, E, 2, 4>(g, epi, sk); });
+        };
+        if (special == 1) go(EpiFF1{bias.data(), out16.data(), 2 * (int64_t)N});
+        else if (special == 2) go(EpiGateRes{bias.data(), gate.data(), rowmask.empty() ? nullptr : rowmask.data(), out.data(), (int64_t)N});
+        else go(e);
       };
       if (op == OP_F32) body(float{}, std::integral_constant<int, 1>{});
       else if (op == OP_F16) body(f16{}, std::integral_constant<int, 1>{});

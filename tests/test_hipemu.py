@@ -358,3 +358,33 @@ def test_streamk_reduce_scatter_kernel_writes_the_next_gemms_operand_planes(exe,
     want = _gelu_tanh(operand_values(A, op) @ operand_values(W, op).T + bias)
     assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
     assert open(os.path.join(tmp_path, "out.bin"), "rb").read() == open(os.path.join(tmp_path, "out2.bin"), "rb").read()
+
+
+@pytest.mark.parametrize("special", [1, 2])
+def test_specialised_epilogues_equal_the_generic_one(exe, tmp_path, special):
+    """EpiFF1 / EpiGateRes (gemm.h: the two DiT shapes with every run-time decision of EpiStore fixed at compile time) through the
+    stream-K kernel against EpiStore configured the same way."""
+    op, Mr, N, K, grid = OP_F16X3, 300, 256, 192, 16
+    rng = np.random.default_rng(special)
+    A = rng.standard_normal((Mr, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    files = dict(A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias)
+    if special == 1:
+        args = (op, Mr, N, K, 1, grid, 0, 3, 1, 1)  # GELU, packed operand output
+    else:
+        files.update(res=rng.standard_normal((Mr, N)).astype(np.float32), gate=rng.standard_normal(N).astype(np.float32),
+                     rowmask=(rng.random(Mr) > 0.3).astype(np.uint8))
+        args = (op, Mr, N, K, 1, grid, 1, 0, 1, 0)
+    run(exe, tmp_path, "skrs", *args, 0, **files)
+    generic = open(os.path.join(tmp_path, "out.bin"), "rb").read()
+    run(exe, tmp_path, "skrs", *args, special, **files)
+    fast = open(os.path.join(tmp_path, "out.bin"), "rb").read()
+    if special == 1:
+        assert generic == fast
+    else:
+        a, b = np.frombuffer(generic, dtype="<f4"), np.frombuffer(fast, dtype="<f4")
+        assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()  # an fma contraction may differ by one rounding
+        pre = (operand_values(A, op) @ operand_values(W, op).T + bias) * files["gate"]
+        want = np.where(files["rowmask"][:, None] != 0, pre, 0.0) + files["res"]
+        assert np.abs(b.reshape(Mr, N) - want).max() < 3e-5 * np.abs(want).max()

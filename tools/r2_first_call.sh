@@ -19,8 +19,9 @@ for g in 128 192 256; do KB_SKGRID=$g KB_EPI=2 timeout 120 python tools/kernel_b
 timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_e2_bigvgan_b8.json 2> $out/bench_e2_bigvgan_b8.err
 # 3b. the headline with the stream-K block GEMMs (packed schedule) against the default two-chain schedule
 for sk in 42 43; do F5HIP_BENCH_STREAMK=$sk timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk$sk.json 2> $out/bench_b1_sk$sk.err; done
+F5HIP_SK_GENERIC_EPI=1 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_generic_epi.json 2> $out/bench_b1_sk42_generic_epi.err
 F5HIP_BENCH_STREAMK=42 F5HIP_BENCH_STREAMK_SPLIT=1 timeout 600 python bench.py --branch-streams 1 --no-cpu-baseline > $out/bench_b1_sk42_split.json 2> $out/bench_b1_sk42_split.err
 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_packed.json 2> $out/bench_b1_packed.err
 # 4. the headline, unchanged code path (regression check of the header refactors: F5_DYN_LDS macro, split headers)
 timeout 600 python bench.py > $out/bench_b1.json 2> $out/bench_b1.err
-tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_split.json $out/bench_b1_packed.json $out/bench_b1.json
+tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_packed.json $out/bench_b1.json $out/bench_b1.json
