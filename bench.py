@@ -141,6 +141,8 @@ def main():
     if not a.no_graph:
         eng.set_option("use_graph", 1)
     eng.set_option("branch_streams", a.branch_streams)
+    if os.environ.get("F5HIP_BENCH_KVSPLIT"):  # experiment switch: key-split flash attention
+        eng.set_option("attn_kv_split", int(os.environ["F5HIP_BENCH_KVSPLIT"]))
     if os.environ.get("F5HIP_BENCH_STREAMK"):  # experiment switch (tools/r2_first_call.sh): DiT block GEMMs through gemm_skrs.h
         eng.set_option("gemm_streamk", int(os.environ["F5HIP_BENCH_STREAMK"]))
         eng.set_option("gemm_streamk_split", int(os.environ.get("F5HIP_BENCH_STREAMK_SPLIT", "0")))

@@ -664,6 +664,11 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_at
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
   const bool unett = c.backbone == 1, mmdit = c.backbone == 2;
+  if (ctx->attn_kv_split > 1 && !exact_attn && !mmdit) {  // partial results of the key-split attention: [sequences * heads * tokens, parts, 64 + 2]
+    bool moved = false;
+    HIPCHK(ctx->attn_part.ensure((size_t)2 * B * c.heads * (n + 1) * ctx->attn_kv_split * 66 * sizeof(float), &moved));
+    if (moved) ctx->ws_epoch++;
+  }
   // tokens per sequence inside the backbone: UNetT prepends the time token; MMDiT attends over audio frames + text tokens jointly
   // (its row-wise buffers hold the audio rows of all sequences first, then the text rows)
   const int ns = n + (unett ? 1 : mmdit ? nt : 0);
@@ -827,7 +832,9 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
                                  ctx->k16.as<f16>() + qoff, x3 ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
                                  x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
-                                 kvlen2, seg2_off));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
+                                 kvlen2, seg2_off, 1, ctx->attn_part.p ? ctx->attn_kv_split : 1,
+                                 ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 : nullptr,
+                                 ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
                                                       // (the two chains are rarely in attention at the same time)
       }
     }
@@ -1445,7 +1452,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
-                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->sk_ws};
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->sk_ws, &ctx->attn_part};
   for (DevBuf* b : bufs) b->release();
   if (ctx->blob) (void)hipFree(ctx->blob);
   delete ctx;
@@ -1510,6 +1517,11 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "gemm_streamk") {  // 0 = off; 42 / 43 = the DiT block GEMMs of the PACKED schedule through gemm_skrs.h (256x128 / 128x256 tiles)
     if (value != 0 && value != 42 && value != 43) FAIL(F5HIP_ERR_INVALID, "gemm_streamk must be 0, 42 or 43");
     ctx->gemm_sk = (int)value;
+    ctx->ws_epoch++;
+  }
+  else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
+    if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
+    ctx->attn_kv_split = (int)value;
     ctx->ws_epoch++;
   }
   else if (k == "gemm_streamk_split") { ctx->gemm_sk_split = value != 0; ctx->ws_epoch++; }  // stream-K also under the two-chain schedule

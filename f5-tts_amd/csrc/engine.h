@@ -179,6 +179,8 @@ struct f5hip_ctx {
   hipStream_t cap_stream = nullptr;
   // option "gemm_streamk": 0 off, 42 / 43 = DiT block GEMMs of the packed schedule through gemm_skrs.h; sk_now = set while run_step
   // enqueues launches that have the GPU to themselves; sk_ws = its workspace (slots + self-cleaning flags)
+  int attn_kv_split = 1;       // option "attn_kv_split": key ranges per query block in the flash kernel (1 = off); attn_part = its scratch
+  DevBuf attn_part;
   int gemm_sk = 0;
   bool gemm_sk_split = false;  // allow it under the two-chain schedule too (each chain: half the grid, its own workspace half)
   bool sk_now = false;

@@ -92,7 +92,10 @@ bool flash_attn_available();
 hipError_t init_attention_kernels();
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s,
-                             int o_packed = 0, const int32_t* kvlen2 = nullptr, int seg2_off = 0, int co_launches = 1);
+                             int o_packed = 0, const int32_t* kvlen2 = nullptr, int seg2_off = 0, int co_launches = 1, int kv_split = 1,
+                             float* part_o = nullptr, float* part_ml = nullptr);
+// kv_split > 1: every query block is cut into kv_split workgroups over contiguous key ranges (small batches: more, shorter workgroups);
+// part_o [Bp*heads*n, kv_split, 64] / part_ml [Bp*heads*n, kv_split, 2] fp32 scratch for the unnormalised partial results
 // co_launches: how many identical launches run concurrently on other streams (the cond / uncond chains): enters the block-size choice
 // kvlen2 / seg2_off: a second run of valid keys [seg2_off, seg2_off + kvlen2[b']) behind [0, kvlen[b']) (MMDiT joint attention mask)
 

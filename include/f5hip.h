@@ -208,6 +208,8 @@ int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value);
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel
  * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
+ * "attn_kv_split" (1 off (default) / 2..8: flash attention with every query block cut into that many key ranges + a merge kernel —
+ * shorter workgroups for small batches, csrc/attention_kernel.h),
  * "gemm_streamk" (0 off (default) / 42 / 43: the DiT block GEMMs of the packed schedule through the stream-K kernel with the
  * reduce-scattered epilogue, csrc/gemm_skrs.h, 256x128 / 128x256 tiles; implies one kernel chain unless "gemm_streamk_split" is 1: then the two chains
  * each get half the grid). */

@@ -3,6 +3,7 @@
 #include "hipemu.h"
 // kernel sources, exactly as hipcc sees them
 #include "bigvgan_kernels.h"
+#include "attention_kernel.h"
 #include "conv_gemm.h"
 #include "gemm_skrs.h"
 
@@ -121,6 +122,41 @@ int main(int argc, char** argv) {
       default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
     }
     wr("out.bin", out);
+  } else if (mode == "attn") {  // nsplit(1|2|3) Bp heads n kv_split o_packed has_kvlen
+    const int nsplit = A(0), Bp = A(1), heads = A(2), n = A(3), kvs = A(4), o_packed = A(5), has_kvlen = A(6);
+    const int bh = Bp * heads, ldv = (n + 7) & ~7;
+    auto q = rd<f16>("q.bin"), ql = rd<f16>("q_lo.bin", true), k = rd<f16>("k.bin"), kl = rd<f16>("k_lo.bin", true);
+    auto vt = rd<f16>("vt.bin"), vtl = rd<f16>("vt_lo.bin", true);
+    auto kvlen = rd<int32_t>("kvlen.bin", true);
+    const int64_t ow = (int64_t)heads * 64 * (o_packed ? 2 : 1);
+    std::vector<f16> o((size_t)Bp * n * ow, (f16)-7.f), olo(o_packed ? 0 : o.size(), (f16)-7.f);
+    std::vector<float> part_o((size_t)bh * n * kvs * 64, -777.f), part_ml((size_t)bh * n * kvs * 2, -777.f);
+    FlashArgs a{};
+    a.q = q.data(); a.q_lo = ql.empty() ? nullptr : ql.data(); a.k = k.data(); a.k_lo = kl.empty() ? nullptr : kl.data();
+    a.vt = vt.data(); a.vt_lo = vtl.empty() ? nullptr : vtl.data();
+    a.o = o.data(); a.o_lo = o_packed ? o.data() + 32 : olo.data();
+    a.kvlen = has_kvlen ? kvlen.data() : nullptr;
+    a.n = n; a.ldv = ldv; a.heads = heads; a.o_packed = o_packed;
+    a.kv_split = kvs; a.part_o = part_o.data(); a.part_ml = part_ml.data();
+    a.nqb = (n + QB - 1) / QB; a.nwg = bh * a.nqb * (kvs > 1 ? kvs : 1);
+    auto go = [&](auto ns, auto pv) {
+      constexpr int NS = decltype(ns)::value, PV = decltype(pv)::value;
+      const int lds = flash_lds_bytes<NS, PV>();
+      if (kvs > 1) {
+        hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<NS, PV, 4, true>(a); });
+        const int64_t rows = (int64_t)bh * n;
+        hipemu::launch(dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, [&] { flash_combine_kernel(a, rows); });
+      } else {
+        hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<NS, PV, 4, false>(a); });
+      }
+    };
+    using I1 = std::integral_constant<int, 1>;
+    using I3 = std::integral_constant<int, 3>;
+    if (nsplit == 3) go(I3{}, I3{});
+    else if (nsplit == 2) go(I3{}, I1{});
+    else go(I1{}, I1{});
+    wr("out.bin", o);
+    if (!o_packed) wr("out_lo.bin", olo);
   } else if (mode == "skrs") {  // op M N K rows256 grid has_res act launches pk_out special(0 EpiStore, 1 EpiFF1, 2 EpiGateRes)
     const int op = A(0), M = A(1), N = A(2), K = A(3), rows256 = A(4), grid = A(5), has_res = A(6), act = A(7), launches = A(8), pk_out = A(9);
     const int special = argc > 13 ? A(10) : 0;

@@ -388,3 +388,47 @@ def test_specialised_epilogues_equal_the_generic_one(exe, tmp_path, special):
         pre = (operand_values(A, op) @ operand_values(W, op).T + bias) * files["gate"]
         want = np.where(files["rowmask"][:, None] != 0, pre, 0.0) + files["res"]
         assert np.abs(b.reshape(Mr, N) - want).max() < 3e-5 * np.abs(want).max()
+
+
+# ---- flash attention (csrc/attention_kernel.h): the GPU-proven kernel through the shim, then its key-split variant ---------------------
+def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None):
+    bh = Bp * heads
+    q = (rng.standard_normal((bh, n, 64)) * 0.5 / 8.0).astype(np.float32)  # pre-scaled by 1/sqrt(64), as the QKV epilogue leaves it
+    k = (rng.standard_normal((bh, n, 64)) * 1.5).astype(np.float32)
+    v = rng.standard_normal((bh, n, 64)).astype(np.float32)
+    ldv = (n + 7) & ~7
+    vt = np.zeros((bh, 64, ldv), dtype=np.float32)
+    vt[:, :, :n] = v.transpose(0, 2, 1)
+    hi = lambda x: x.astype(np.float16)  # noqa: E731
+    lo = lambda x: (x - x.astype(np.float16).astype(np.float32)).astype(np.float16)  # noqa: E731
+    files = dict(q=hi(q), k=hi(k), vt=hi(vt))
+    if nsplit >= 2:
+        files.update(q_lo=lo(q), k_lo=lo(k))
+    if nsplit == 3:
+        files.update(vt_lo=lo(vt))
+    if kvlen is not None:
+        files["kvlen"] = np.asarray(kvlen, dtype=np.int32)
+    val = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit >= 2 else (lambda x: hi(x).astype(np.float64))
+    vval = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit == 3 else (lambda x: hi(x).astype(np.float64))
+    s = val(q) @ val(k).transpose(0, 2, 1)
+    if kvlen is not None:
+        for b in range(Bp):
+            s[b * heads:(b + 1) * heads, :, kvlen[b]:] = -np.inf
+    p = np.exp(s - s.max(-1, keepdims=True))
+    want = (p / p.sum(-1, keepdims=True)) @ vval(v)  # [bh, n, 64]
+    want = want.reshape(Bp, heads, n, 64).transpose(0, 2, 1, 3).reshape(Bp, n, heads * 64)
+    return files, want
+
+
+@pytest.mark.parametrize("nsplit,kvs,n,kvlen", [(2, 1, 200, None), (1, 1, 70, None), (3, 1, 130, [130, 77]),
+                                                (2, 2, 200, None), (2, 3, 333, None), (1, 4, 70, None), (3, 2, 130, [130, 77]), (2, 8, 64, None)])
+def test_flash_attention_kernel_and_its_key_split_variant(exe, tmp_path, nsplit, kvs, n, kvlen):
+    """kvs == 1: the kernel the DiT parity suite has proven on the GPU, run through the shim (validates the shim on __shfl_xor, V^T
+    tiles, online softmax).  kvs > 1: the key-split variant + merge kernel written without a GPU, against the same softmax."""
+    rng = np.random.default_rng(n + kvs)
+    Bp, heads = 2, 2
+    files, want = _attn_case(rng, Bp, heads, n, nsplit, kvlen)
+    run(exe, tmp_path, "attn", nsplit, Bp, heads, n, kvs, 1, int(kvlen is not None), **files)
+    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
+    tol = 3e-3 if nsplit < 3 else 2e-5  # P (and V) rounded to fp16 in the PV product unless everything is split
+    assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())

@@ -98,3 +98,30 @@ def test_full_size_model_with_streamk_block_gemms():
         eng.set_option("gemm_streamk", 0)
     finally:
         eng.close()
+
+
+@direct
+def test_key_split_attention_on_the_full_size_model():
+    """option "attn_kv_split" (flash attention with every query block cut into 2 / 3 key ranges + a merge kernel, attention_kernel.h):
+    against the reference-minted golden and the unsplit path, both schedules."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+    from oracle import make_golden as MG
+
+    c = MG.FULL_CASES["base_v1_cfg1"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    gold = torch.as_tensor(np.load(os.path.join(ROOT, "tests", "golden", "base_v1_cfg1.npz"))["out"])
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    try:
+        model = F5HipCFM(eng, precision="fp16x3")
+        base, _ = model.sample(wav.cuda(), text, duration, **c["kw"])
+        for streams in (1, 0):
+            eng.set_option("branch_streams", streams)
+            for kvs in (2, 3):
+                eng.set_option("attn_kv_split", kvs)
+                a, _ = model.sample(wav.cuda(), text, duration, **c["kw"])
+                assert (a.cpu() - gold)[:, 468:].abs().max().item() < 1e-3
+                assert (a - base).abs().max().item() < 5e-4
+        eng.set_option("attn_kv_split", 1)
+    finally:
+        eng.close()

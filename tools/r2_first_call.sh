@@ -22,8 +22,10 @@ for sk in 42 43; do F5HIP_BENCH_STREAMK=$sk timeout 600 python bench.py --branch
 F5HIP_SK_GENERIC_EPI=1 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_generic_epi.json 2> $out/bench_b1_sk42_generic_epi.err
 F5HIP_BENCH_STREAMK=42 F5HIP_BENCH_STREAMK_SPLIT=1 timeout 600 python bench.py --branch-streams 1 --no-cpu-baseline > $out/bench_b1_sk42_split.json 2> $out/bench_b1_sk42_split.err
 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_packed.json 2> $out/bench_b1_packed.err
+for kvs in 2 3; do F5HIP_BENCH_KVSPLIT=$kvs timeout 600 python bench.py --no-cpu-baseline > $out/bench_b1_kvsplit$kvs.json 2> $out/bench_b1_kvsplit$kvs.err; done
+F5HIP_BENCH_KVSPLIT=2 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_kvsplit2.json 2> $out/bench_b1_sk42_kvsplit2.err
 # 3c. calibration: the vendor library on a PLAIN fp16 GEMM at the same shapes (what the part does vs what our fused k-loop loses)
 timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
 # 4. the headline, unchanged code path (regression check of the header refactors: F5_DYN_LDS macro, split headers)
 timeout 600 python bench.py > $out/bench_b1.json 2> $out/bench_b1.err
-cat $out/hipblaslt_ref.log; tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_packed.json $out/bench_b1.json $out/bench_b1.json
+cat $out/hipblaslt_ref.log; tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_kvsplit2.json $out/bench_b1_kvsplit3.json $out/bench_b1_sk42_kvsplit2.json $out/bench_b1_packed.json $out/bench_b1.json $out/bench_b1.json
