@@ -168,6 +168,13 @@ hipError_t launch_skrs(const GemmCore& g, const Epi& e, hipStream_t s) {
     attr_done = true;
   }
   if (!g.sk_ws || g.sk_grid < 8 || (g.sk_grid & 7)) return hipErrorInvalidValue;
+  // every workgroup must be able to be resident (one 144 KB workgroup per CU): never more workgroups than the device has CUs
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  if (g.sk_grid > cus) return hipErrorInvalidValue;
   if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
     return hipErrorInvalidValue;
   SkrsArgs sk{};
