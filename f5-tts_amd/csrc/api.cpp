@@ -308,7 +308,7 @@ constexpr size_t SK_WS_BYTES = (size_t)SK_GRID * 2 * 131072 + ((size_t)SK_GRID *
 GemmCore sk_attach(f5hip_ctx* ctx, GemmCore g) {
   if (ctx->sk_now) {
     g.sk_ws = ctx->sk_ws.as<char>() + (ctx->sk_chain > 0 ? SK_WS_BYTES : 0);
-    g.sk_grid = ctx->sk_chain >= 0 ? SK_GRID / 2 : SK_GRID;
+    g.sk_grid = ctx->sk_chain >= 0 ? ctx->sk_grid / 2 : ctx->sk_grid;
     g.sk_variant = ctx->gemm_sk;
   }
   return g;
@@ -1522,6 +1522,11 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
     if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
     ctx->attn_kv_split = (int)value;
+    ctx->ws_epoch++;
+  }
+  else if (k == "gemm_streamk_grid") {  // resident workgroups the stream-K launches spread over (default: one per CU)
+    if (value < 16 || value > SK_GRID || value % 16) FAIL(F5HIP_ERR_INVALID, "gemm_streamk_grid must be a multiple of 16 in [16, %d]", SK_GRID);
+    ctx->sk_grid = (int)value;
     ctx->ws_epoch++;
   }
   else if (k == "gemm_streamk_split") { ctx->gemm_sk_split = value != 0; ctx->ws_epoch++; }  // stream-K also under the two-chain schedule

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
                                                       const float* __restrict__ bias, const uint8_t* __restrict__ rowvalid,
                                                       const float* __restrict__ residual, int n, int D, int K, float* out, int out_n, int out_off) {
   using C = ConvCfg<T, NPL, CPG>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  F5_DYN_LDS(char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * C::BMR, g = blockIdx.y, s = blockIdx.z;
   const int halo = K / 2;

@@ -183,6 +183,7 @@ struct f5hip_ctx {
   DevBuf attn_part;
   int gemm_sk = 0;
   bool gemm_sk_split = false;  // allow it under the two-chain schedule too (each chain: half the grid, its own workspace half)
+  int sk_grid = 256;           // option "gemm_streamk_grid"
   bool sk_now = false;
   int sk_chain = -1;           // the chain run_step is enqueueing (-1 packed, 0 / 1 cond / uncond)
   DevBuf sk_ws;

@@ -1,9 +1,12 @@
 // gemm.hip — instantiations and launch heuristics of the MFMA GEMM (gemm.h)
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
-#include "gemm_sk.h"
+#ifndef F5_HIPEMU
+#include "gemm_sk.h"  // inline asm: not part of the host-shim build (tests/hipemu)
+#endif
 #include "gemm_skrs.h"
 
 namespace {
@@ -105,6 +108,7 @@ int pick_variant(const GemmCore& g, int batch) {
   return (g.N <= 1024 && g.M > 256 && batch == 1) ? 6 : 1;
 }
 
+#ifndef F5_HIPEMU
 // direct-to-LDS ring variants (variant ids 6 = 128x64, 7 = 128x128, 3-stage ring)
 template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3, int PRIO = 0>
 hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
@@ -154,12 +158,16 @@ hipError_t launch_sk(const GemmCore& g, const Epi& e, hipStream_t s) {
   return hipGetLastError();
 }
 
+#else
+constexpr int64_t SK_SLOT_BYTES = 512 * 4 * 16 * 4;
+#endif  // F5_HIPEMU
+
 // stream-K with the reduce-scattered epilogue (gemm_skrs.h).  Workspace (caller-owned, private to one stream, flags zeroed once):
 // [grid][2] slots of 128 KB, then [grid][2] int flags, then the error word.
 template <typename T, int NSPLIT, typename Epi, bool ROWS256>
 hipError_t launch_skrs(const GemmCore& g, const Epi& e, hipStream_t s) {
   constexpr int WGM = ROWS256 ? 4 : 2, WGN = ROWS256 ? 2 : 4, BM = 64 * WGM, BN = 64 * WGN;
-  constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, 2, 2, WGM, WGN, 3>();
+  constexpr int lds = 3 * (BM + BN) * GEMM_KTB;  // the 3-stage ring of the LDS-DMA variants
   auto kern = gemm_skrs_kernel<T, NSPLIT, Epi, WGM, WGN>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -188,7 +196,12 @@ hipError_t launch_skrs(const GemmCore& g, const Epi& e, hipStream_t s) {
   // every share must be non-empty and at least an eighth of a tile long: a tile then has at most 9 contributors (16 units to deal out)
   const int64_t min_class_iters = (int64_t)(sk.tiles / 8) * sk.kt, gx = g.sk_grid >> 3;
   if (min_class_iters < gx || min_class_iters / gx < (sk.kt + 7) / 8) return hipErrorInvalidValue;
+#ifdef F5_HIPEMU  // all workgroups alive at once (they talk through flags)
+  if (getenv("F5HIP_SK_TRACE")) fprintf(stderr, "skrs M=%d N=%d K=%d grid=%d\n", g.M, g.N, g.K, g.sk_grid);
+  hipemu::launch_coop(dim3(g.sk_grid), dim3(512), lds, [=] { kern(g, e, sk); });
+#else
   hipLaunchKernelGGL(kern, dim3(g.sk_grid), dim3(512), lds, s, g, e, sk);
+#endif
   return hipGetLastError();
 }
 
@@ -215,6 +228,7 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 3: return launch_one<T, NSPLIT, 3, Epi>(g, e, batch, s);
     case 4: return launch_one<T, NSPLIT, 4, Epi>(g, e, batch, s);
     case 5: return launch_one<T, NSPLIT, 5, Epi>(g, e, batch, s);
+#ifndef F5_HIPEMU
     case 6: return launch_glds<T, NSPLIT, 2, 1, Epi>(g, e, batch, s);
     case 7: return launch_glds<T, NSPLIT, 2, 2, Epi>(g, e, batch, s);
     case 13: return launch_glds<T, NSPLIT, 4, 2, Epi>(g, e, batch, s);  // 256x128, 4 waves of 128x64
@@ -230,11 +244,17 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
     case 31: return launch_glds<T, NSPLIT, 2, 2, Epi, 2, 4, 3>(g, e, batch, s);  // 128x256, 8 waves of 64x64, 3-stage ring
     case 40: return launch_sk<T, NSPLIT, Epi, true>(g, e, s);   // stream-K, 256x128 tiles
     case 41: return launch_sk<T, NSPLIT, Epi, false>(g, e, s);  // stream-K, 128x256 tiles
+#else  // the host shim runs the register-staged kernel at the LDS-DMA variants' call sites (same tile or the nearest one)
+    case 6: case 26: case 27: case 24: return launch_one<T, NSPLIT, 1, Epi>(g, e, batch, s);
+    case 7: case 13: case 14: case 21: case 22: case 23: case 25: case 28: case 29: case 30: case 31: return launch_one<T, NSPLIT, 2, Epi>(g, e, batch, s);
+#endif
     case 42: return launch_skrs<T, NSPLIT, Epi, true>(g, e, s);   // stream-K, reduce-scattered epilogue, 256x128 tiles
     case 43: return launch_skrs<T, NSPLIT, Epi, false>(g, e, s);  // stream-K, reduce-scattered epilogue, 128x256 tiles
+#ifndef F5_HIPEMU
     case 24: return launch_glds<T, NSPLIT, 2, 1, Epi, 2, 2, 3, 2>(g, e, batch, s);     // ablation: variant 6 with 2 of the 3 fp16x3 products
     case 25: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 2>(g, e, batch, s);     // ablation: variant 21 with 2 of the 3 fp16x3 products
     case 23: return launch_glds<T, NSPLIT, 4, 2, Epi, 2, 4, 2, 1>(g, e, batch, s);  // variant 21 + s_setprio around the MFMA clusters
+#endif
     case 8: return launch_one<T, NSPLIT, 8, Epi>(g, e, batch, s);
     case 10: return launch_one<T, NSPLIT, 10, Epi>(g, e, batch, s);
     default: break;
@@ -267,7 +287,7 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   if (g.group_m == 0) g.group_m = gm_env >= 0 ? gm_env : (g.M >= 8192 ? 4 : 1);
   // stream-K on request of the caller (GemmCore.sk_variant + workspace): only where the schedule applies (launch_skrs checks the share
   // sizes), otherwise the plain heuristic
-  if (variant < 0 && g.sk_ws && g.sk_variant && batch == 1 && g.M > 1024 && op != OP_F32) {
+  if (variant < 0 && g.sk_ws && g.sk_variant && batch == 1 && g.M > 256 && op != OP_F32) {  // launch_skrs decides whether the shape suits the grid
     hipError_t r = hipErrorInvalidValue;
     bool done = false;
     if constexpr (std::is_same<Epi, EpiStore>::value) {  // the two DiT shapes have branch-free epilogues (gemm.h EpiFF1 / EpiGateRes)

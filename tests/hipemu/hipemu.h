@@ -28,6 +28,11 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+// a kernel's static LDS array: one block at a time runs on an OS thread (hipemu::launch), so per-thread storage is per-block storage
+// (NOT valid under launch_coop, whose kernels use dynamic LDS only)
+#define __shared__ static thread_local
+static inline unsigned __brev(unsigned x) { return __builtin_bitreverse32(x); }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
@@ -85,6 +90,30 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+// streams / events / graphs: everything runs synchronously on the calling thread; graph capture is not emulated (the engine's
+// "use_graph" option stays off under the shim)
+typedef void* hipGraph_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipStreamCaptureModeThreadLocal = 1, hipErrorNotSupported = 801 };
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(uintptr_t(1)); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(uintptr_t(1)); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
 using std::max;
 using std::min;
 
@@ -134,7 +163,7 @@ inline thread_local Idx b_dim, g_dim;
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);
 asm(R"(
 .text
-.globl hipemu_switch
+.weak hipemu_switch
 .type hipemu_switch,@function
 hipemu_switch:
   pushq %rbp
@@ -364,7 +393,7 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
 #define blockDim hipemu::b_dim
 #define gridDim hipemu::g_dim
 #define __syncthreads() hipemu::barrier_wait(hipemu::blk->bar)
-#define __shfl_xor(v, m, w) hipemu::shfl_xor((v), (m), (w))
+#define __shfl_xor(v, m, ...) hipemu::shfl_xor((v), (m), 64)
 #define __amdgpu_buffer_rsrc_t hipemu::Rsrc
 #define __builtin_amdgcn_make_buffer_rsrc hipemu::make_rsrc
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu::raw_buffer_load_b128

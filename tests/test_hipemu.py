@@ -432,3 +432,106 @@ def test_flash_attention_kernel_and_its_key_split_variant(exe, tmp_path, nsplit,
     got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
     tol = 3e-3 if nsplit < 3 else 2e-5  # P (and V) rounded to fp16 in the PV product unless everything is split
     assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
+
+
+# ---- the DiT engine itself (api.cpp + every kernel translation unit) on the CPU: the product's own host classes over the shim ------------
+@pytest.fixture(scope="module")
+def engine_emu_lib():
+    import ctypes as C
+
+    import f5_tts_amd  # noqa: F401
+    from f5_tts_amd import binding
+
+    out_dir = os.path.join(ROOT, "tests", "c_abi", "_build", "engine_emu")
+    os.makedirs(out_dir, exist_ok=True)
+    csrc, emu = os.path.join(ROOT, "f5-tts_amd", "csrc"), os.path.join(ROOT, "tests", "hipemu")
+    deps = [os.path.join(emu, "hipemu.h"), os.path.join(ROOT, "include", "f5hip.h")] + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")]
+    objs = []
+    for src in ("gemm.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp"):
+        obj = os.path.join(out_dir, src + ".o")
+        objs.append(obj)
+        sp = os.path.join(csrc, src)
+        if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps + [sp]):
+            r = subprocess.run([CLANG, "-x", "c++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-DF5_HIPEMU", "-I", emu, "-I", csrc, "-Wno-unknown-pragmas",
+                                "-Wno-pass-failed", "-Wno-psabi", "-c", sp, "-o", obj], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+    path = os.path.join(out_dir, "libf5hip_engine_emu.so")
+    if not os.path.exists(path) or any(os.path.getmtime(o) > os.path.getmtime(path) for o in objs):
+        r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", path] + objs, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+    for name, (res, args) in binding.SYMBOLS.items():
+        if hasattr(lib, name):  # the microbenchmark / BigVGAN entry points are not part of this build
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    return lib
+
+
+@pytest.fixture()
+def emu_engine(engine_emu_lib, monkeypatch):
+    """F5HipEngine / F5HipCFM (the product's host classes, unmodified) over the emulated library: "device" tensors are CPU tensors."""
+    import contextlib
+    import types
+
+    from f5_tts_amd import engine as E
+
+    monkeypatch.setattr(E, "load_library", lambda *a, **k: engine_emu_lib)
+    monkeypatch.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))
+    made = []
+
+    def make(cfg, vcfg=None):
+        eng = E.F5HipEngine(cfg, vcfg, device="cuda:0")  # a descriptor only; no GPU is touched
+        eng.device = torch.device("cpu")
+        made.append(eng)
+        return eng
+
+    yield make
+    for eng in made:
+        eng.close()
+
+
+def test_engine_on_the_shim_matches_the_oracle_and_the_experimental_switches_change_nothing(emu_engine, capfd, monkeypatch):
+    """The tiny DiT through api.cpp and every kernel translation unit on the CPU: fp32 against the oracle (what smoke() checks on the
+    GPU), then fp16x3 with each switch written without GPU minutes — stream-K block GEMMs through the real dispatch (both tile shapes,
+    the branch-free epilogues, one chain / two chains), key-split attention — against the default path."""
+    from f5_tts_amd import config, synth
+    from f5_tts_amd.engine import F5HipCFM
+    from oracle import f5_oracle as O
+
+    monkeypatch.setenv("F5HIP_SK_TRACE", "1")
+    cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
+    sd, vsd = synth.synth_dit_state_dict(cfg, seed=1), synth.synth_vocos_state_dict(vcfg, seed=1)
+    eng = emu_engine(cfg, vcfg)
+    eng.load_state_dict({**sd, **vsd})
+    B, n = 2, 200
+    wav = synth.synth_wave(256 * 40, seed=3, batch=B)
+    text = synth.synth_text_ids(B, 30, cfg.text_num_embeds, seed=2)
+    dur = torch.tensor([n, n - 37])  # ragged: row masks, padded keys
+    kw = dict(steps=1, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
+    ref, _ = O.cfm_sample(sd, cfg, wav, text, dur, **kw)
+    out, _ = F5HipCFM(eng, precision="fp32").sample(wav, text, dur, **kw)
+    assert (out - ref).abs().max().item() < 1e-4
+    gen = out[:1, 40:, :].permute(0, 2, 1)
+    assert (eng.vocos_decode(gen.contiguous()) - O.vocos_decode(vsd, gen, vcfg.num_layers)).abs().max().item() < 1e-3
+    model = F5HipCFM(eng, precision="fp16x3")
+    base, _ = model.sample(wav, text, dur, **kw)
+    assert (base - ref).abs().max().item() < 5e-4
+    capfd.readouterr()
+    eng.set_option("gemm_streamk_grid", 16)
+    # (options, rows per launch, stream-K launches expected: 2 blocks x the block GEMMs whose tile count suits the 16-workgroup grid)
+    cases = [(dict(gemm_streamk=42, branch_streams=0), 800, 8), (dict(gemm_streamk=43, attn_kv_split=3, branch_streams=0), 800, 4),
+             (dict(gemm_streamk=42, gemm_streamk_split=1, gemm_streamk_grid=32, attn_kv_split=2, branch_streams=1), 400, 8)]
+    for i, (opts, rows, launches) in enumerate(cases):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        got, _ = model.sample(wav, text, dur, **kw)
+        assert (got - base).abs().max().item() < 2e-4, opts
+        trace = capfd.readouterr().err
+        assert trace.count(f"skrs M={rows} ") == launches, (opts, trace)  # the real dispatch took the stream-K path (incl. EpiFF1 / EpiGateRes)
+        if i == 0:
+            again, _ = model.sample(wav, text, dur, **kw)
+            assert torch.equal(got, again)
+            capfd.readouterr()
+        for k in opts:
+            eng.set_option(k, {"branch_streams": -1, "attn_kv_split": 1, "gemm_streamk_grid": 16}.get(k, 0))

@@ -1,0 +1,65 @@
+"""The GPU parity tests' own assertions (tests/test_gpu_parity.py: reference-minted goldens through the product's host classes and the
+C ABI), executed on the CPU: libf5hip's engine — api.cpp and every kernel translation unit — is built for the host through
+tests/hipemu/hipemu.h and driven by the unmodified F5HipEngine / F5HipCFM.  A cross-section of the goldens that finishes in a minute:
+every backbone (DiT, UNetT, MMDiT), ragged batches with row / key masks, qk RMSNorm, long skip, average upsampling, the midpoint
+solver — in the exact-fp32 and the fp16x3 operand modes.  The whole matrix (all goldens, all modes, full size) is the `-m gpu` suite."""
+import contextlib
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as G  # noqa: E402
+from test_hipemu import CLANG, engine_emu_lib  # noqa: E402,F401  (the fixture that builds the emulated library)
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
+
+CASES = ["tiny_qknorm", "tiny_longskip", "tiny_avgup", "tiny_v1_midpoint", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2", "tiny_v1_nocfg_b2"]
+
+
+@pytest.fixture(scope="module")
+def shim_engines(engine_emu_lib):  # noqa: F811
+    """What test_gpu_parity's `engines` fixture returns, over the emulated library ("device" tensors are CPU tensors)."""
+    from f5_tts_amd import config, synth
+    from f5_tts_amd import engine as E
+
+    mp = pytest.MonkeyPatch()
+    mp.setattr(E, "load_library", lambda *a, **k: engine_emu_lib)
+    mp.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
+    mp.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))
+    mp.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    cache = {}
+
+    def get(preset, wseed, vocos=False):
+        key = (preset, wseed, vocos)
+        if key not in cache:
+            cfg = config.PRESETS[preset]
+            sd = synth.synth_dit_state_dict(cfg, seed=wseed)
+            vcfg = config.VOCOS_TINY if vocos else None
+            eng = E.F5HipEngine(cfg, vcfg, device="cuda:0")  # a descriptor only
+            eng.device = torch.device("cpu")
+            if vocos:
+                sd = {**sd, **synth.synth_vocos_state_dict(vcfg, seed=1)}
+            eng.load_state_dict(sd)
+            cache[key] = eng
+        return cache[key]
+
+    yield get
+    for e in cache.values():
+        e.close()
+    mp.undo()
+
+
+@pytest.mark.parametrize("name,prec,tol", [(n, "fp32", G.TIGHT) for n in CASES] +
+                         [(n, "fp16x3", G.X3TOL) for n in ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2")])
+def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
+    G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
+
+
+def test_mel_front_ends_on_the_shim(shim_engines):
+    G.test_mel_matches_reference_golden(shim_engines)
