@@ -206,10 +206,20 @@ def main():
     # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager pass -------
     eng.set_option("profile", 1)
     eng.reset_kernel_stats()
+    if big:
+        voc.set_option("profile", 1)
+        voc.reset_kernel_stats()
     one_pass()
     torch.cuda.synchronize(dev)
     stats = eng.kernel_stats()
     eng.set_option("profile", 0)
+    if big:  # the generator's own kernel classes (its context is separate from the backbone's)
+        voc.set_option("profile", 0)
+        res["vocoder_classes"] = {
+            k: {"calls": v["calls"], "ms": round(v["ms"], 3),
+                **({"tflops": round(v["flops"] / (1e-3 * v["ms"]) / 1e12, 1)} if v["flops"] and v["ms"] > 0 else {}),
+                **({"gbps": round(v["bytes"] / (1e-3 * v["ms"]) / 1e9, 1)} if v["bytes"] and v["ms"] > 0 else {})}
+            for k, v in voc.kernel_stats().items() if v["calls"]}
     g = stats["gemm_block"]
     if g["calls"]:
         avg_s = 1e-3 * g["ms"] / g["calls"]

@@ -174,6 +174,19 @@ class F5HipBigVGAN:
     def set_option(self, key: str, value: int):
         self._chk(self.lib.f5hip_bigvgan_set_option(self._ctx, key.encode(), int(value)))
 
+    def kernel_stats(self) -> Dict[str, dict]:
+        """Per-kernel-class calls / milliseconds / algorithmic FLOPs and bytes accumulated while option "profile" is on."""
+        out = {}
+        name, calls = C.c_char_p(), C.c_int64()
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        for i in range(self.lib.f5hip_bigvgan_num_kernel_stats(self._ctx)):
+            self._chk(self.lib.f5hip_bigvgan_kernel_stat(self._ctx, i, C.byref(name), C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by)))
+            out[name.value.decode()] = dict(calls=calls.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return out
+
+    def reset_kernel_stats(self):
+        self._chk(self.lib.f5hip_bigvgan_reset_kernel_stats(self._ctx))
+
     def stage_tensor(self, x: torch.Tensor, stage: int) -> torch.Tensor:
         """Parity tap (tests): the channels-last tensor [b, L_k, C_k] after conv_pre (stage 0) / after upsampling stage k."""
         x = x.to(device=self.device, dtype=torch.float32).contiguous()

@@ -70,6 +70,10 @@ SYMBOLS = {
     "f5hip_bigvgan_finalize": (C.c_int, [_P]),
     "f5hip_bigvgan_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "f5hip_bigvgan_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "f5hip_bigvgan_num_kernel_stats": (C.c_int, [_P]),
+    "f5hip_bigvgan_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "f5hip_bigvgan_reset_kernel_stats": (C.c_int, [_P]),
     "f5hip_bench_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

@@ -70,6 +70,10 @@ struct f5hip_bigvgan {
   float filt[12];
   // workspace (grow-only)
   DevBuf xa, xb, tt, yy, col, rr[4];
+  // measurement: option "profile" times every launch with HIP events on the launch stream, per kernel class
+  bool profile = false;
+  KStat stats[4];             // BV_* classes
+  std::vector<ProfRec> prof;
   int conv_impl = 0;          // 0 = tap-gathered operand + plain GEMM, 1 = implicit GEMM with tap-shifted rows (conv_gemm.h),
                               // 2 = 1 + Activation1d writes the conv's operand copy itself
   int stop_after_stage = -1;  // parity tap (tests): >= 0 makes forward() return the channels-last stage tensor instead of the waveform
@@ -101,6 +105,42 @@ namespace {
     int _r = (expr);                \
     if (_r != F5HIP_OK) return _r;  \
   } while (0)
+
+enum { BV_GEMM = 0, BV_ACT = 1, BV_OPERAND = 2, BV_OTHER = 3, BV_COUNT = 4 };
+const char* const BV_NAMES[BV_COUNT] = {"conv_gemm", "activation1d", "operand", "other"};
+struct BvProf {  // as Prof in api.cpp: events around one launch, resolved after the forward pass
+  f5hip_bigvgan* v;
+  hipStream_t s;
+  ProfRec rec{};
+  BvProf(f5hip_bigvgan* v_, hipStream_t st, int kclass, double flops, double bytes) : v(v_), s(st) {
+    if (v->profile) {
+      rec.kclass = kclass; rec.flops = flops; rec.bytes = bytes;
+      (void)hipEventCreate(&rec.e0);
+      (void)hipEventCreate(&rec.e1);
+      (void)hipEventRecord(rec.e0, s);
+    }
+  }
+  ~BvProf() {
+    if (v->profile) {
+      (void)hipEventRecord(rec.e1, s);
+      v->prof.push_back(rec);
+    }
+  }
+};
+void bv_collect(f5hip_bigvgan* v, hipStream_t s) {
+  if (v->prof.empty()) return;
+  (void)hipStreamSynchronize(s);
+  for (auto& r : v->prof) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      KStat& k = v->stats[r.kclass];
+      k.calls += 1; k.ms += ms; k.flops += r.flops; k.bytes += r.bytes;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  v->prof.clear();
+}
 
 int rup32(int x) { return (x + 31) / 32 * 32; }
 
@@ -270,10 +310,15 @@ int run_conv(f5hip_bigvgan* v, const ConvW& cw, int op, const float* src, int64_
   const int mul = op == OP_F16X3 ? 2 : 1;
   const bool implicit = can_implicit(v, cw, op);
   const int64_t ld = (int64_t)(implicit ? cw.cpad : cw.K) * mul;
+  const double esz = op == OP_F16 ? 2.0 : 4.0;  // operand bytes per element (packed hi/lo = 4)
   if (!src) {  // the operand copy is already in v->col (fused emission)
     if (!implicit) FAIL(F5HIP_ERR_STATE, "internal: fused operand without the implicit-GEMM path");
-  } else if (implicit) HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, 1, 0, 1, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
-  else HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
+  } else {
+    const int taps = implicit ? 1 : cw.ntaps;
+    BvProf pr(v, st, BV_OPERAND, 0, (double)B * L * ((double)cw.cin * 4.0 + (double)taps * cw.cpad * esz));
+    if (implicit) HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, 1, 0, 1, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
+    else HIPCHK(launch_im2col_taps(src, sb, sl, sc, B, L, cw.cin, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, op, v->col.p, ld, (int64_t)L * ld, st));
+  }
   GemmCore g{};
   g.A = v->col.p;
   g.W = op == OP_F32 ? (const void*)cw.w32.p : op == OP_F16 ? (const void*)cw.w16.p : (const void*)cw.wpk.p;
@@ -282,8 +327,12 @@ int run_conv(f5hip_bigvgan* v, const ConvW& cw, int op, const float* src, int64_
   EpiStore e{};
   e.alpha = 1.f; e.act = ACT_NONE; e.bias = cw.bias.as<float>(); e.out32 = dst; e.ldo = cw.N; e.ldres = cw.N; e.res = res;
   e.zdiv = 1; e.so1 = (int64_t)L * cw.N; e.so2 = 0;
-  if (implicit) HIPCHK(launch_conv_gemm(op, g, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, e, B, st));
-  else HIPCHK(launch_gemm_store_variant(op, g, e, B, cw.N <= 64 ? 1 : -1, st));  // narrow outputs (48 / 24 channels): the 128x64 tile
+  {  // algorithmic work: 2 L N (taps cin) FLOP; bytes: the operand as read + weights + result (+ residual)
+    BvProf pr(v, st, BV_GEMM, 2.0 * B * L * cw.N * (double)cw.ntaps * cw.cin,
+              (double)B * L * ((implicit ? cw.cpad : cw.K) * esz + cw.N * 4.0 * (res ? 2 : 1)) + (double)cw.N * cw.K * esz);
+    if (implicit) HIPCHK(launch_conv_gemm(op, g, cw.ntaps, cw.shift0, cw.dstep, cw.cpad, e, B, st));
+    else HIPCHK(launch_gemm_store_variant(op, g, e, B, cw.N <= 64 ? 1 : -1, st));  // narrow outputs (48 / 24 channels): the 128x64 tile
+  }
   return F5HIP_OK;
 }
 
@@ -292,11 +341,17 @@ int run_act_conv(f5hip_bigvgan* v, const ActW& a, const ConvW& cw, int op, const
                  hipStream_t st) {
   const int ls = v->cfg.snake_logscale;
   if (v->conv_impl == 2 && can_implicit(v, cw, op)) {
-    HIPCHK(launch_aa_snake(x, nullptr, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st, v->col.p, op, cw.cpad));
+    {
+      BvProf pr(v, st, BV_ACT, 0, (double)B * L * (C * 4.0 + cw.cpad * (op == OP_F16 ? 2.0 : 4.0)));
+      HIPCHK(launch_aa_snake(x, nullptr, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st, v->col.p, op, cw.cpad));
+    }
     return run_conv(v, cw, op, nullptr, 0, 0, 0, B, L, dst, res, st);
   }
   float* y = v->yy.as<float>();
-  HIPCHK(launch_aa_snake(x, y, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st));
+  {
+    BvProf pr(v, st, BV_ACT, 0, (double)B * L * C * 8.0);
+    HIPCHK(launch_aa_snake(x, y, a.alpha.as<float>(), a.beta.as<float>(), v->filt, B, L, C, ls, st));
+  }
   return run_conv(v, cw, op, y, (int64_t)L * C, C, 1, B, L, dst, res, st);
 }
 
@@ -357,14 +412,23 @@ int forward_impl(f5hip_bigvgan* v, const float* mel, int B, int T, int channel_m
       }
       rptr[j] = rj;
     }
-    HIPCHK(launch_mean_streams(rptr, c.num_kernels, (int64_t)B * sb, x, st));  // x = xs / num_kernels
+    {
+      BvProf pr(v, st, BV_OTHER, 0, (double)B * sb * 4.0 * (c.num_kernels + 1));
+      HIPCHK(launch_mean_streams(rptr, c.num_kernels, (int64_t)B * sb, x, st));  // x = xs / num_kernels
+    }
     if (v->stop_after_stage == i + 1) {
       HIPCHK(hipMemcpyAsync(out, x, (size_t)B * sb * sizeof(float), hipMemcpyDeviceToDevice, st));
       return F5HIP_OK;
     }
   }
-  HIPCHK(launch_aa_snake(x, y, v->act_post.alpha.as<float>(), v->act_post.beta.as<float>(), v->filt, B, L, C, c.snake_logscale, st));
-  HIPCHK(launch_conv_post(y, v->post_w7.as<float>(), c.use_bias_at_final ? v->post_bias.as<float>() : nullptr, B, L, C, c.use_tanh_at_final, out, st));
+  {
+    BvProf pr(v, st, BV_ACT, 0, (double)B * L * C * 8.0);
+    HIPCHK(launch_aa_snake(x, y, v->act_post.alpha.as<float>(), v->act_post.beta.as<float>(), v->filt, B, L, C, c.snake_logscale, st));
+  }
+  {
+    BvProf pr(v, st, BV_OTHER, 2.0 * B * L * 7.0 * C, (double)B * L * (C + 1) * 4.0);
+    HIPCHK(launch_conv_post(y, v->post_w7.as<float>(), c.use_bias_at_final ? v->post_bias.as<float>() : nullptr, B, L, C, c.use_tanh_at_final, out, st));
+  }
   return F5HIP_OK;
 }
 
@@ -470,12 +534,32 @@ int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value) {
     v->stop_after_stage = (int)value;
     return F5HIP_OK;
   }
+  if (!strcmp(key, "profile")) { v->profile = value != 0; return F5HIP_OK; }
   if (!strcmp(key, "conv_impl")) {
     if (value < 0 || value > 2) FAIL(F5HIP_ERR_INVALID, "conv_impl must be 0, 1 or 2");
     v->conv_impl = (int)value;
     return F5HIP_OK;
   }
   FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
+}
+
+int f5hip_bigvgan_num_kernel_stats(const f5hip_bigvgan*) { return BV_COUNT; }
+
+int f5hip_bigvgan_kernel_stat(const f5hip_bigvgan* v, int i, const char** name, int64_t* calls, double* ms, double* flops, double* bytes) {
+  if (!v || i < 0 || i >= BV_COUNT) return F5HIP_ERR_INVALID;
+  if (name) *name = BV_NAMES[i];
+  if (calls) *calls = v->stats[i].calls;
+  if (ms) *ms = v->stats[i].ms;
+  if (flops) *flops = v->stats[i].flops;
+  if (bytes) *bytes = v->stats[i].bytes;
+  return F5HIP_OK;
+}
+
+int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v) {
+  if (!v) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(v->mu);
+  for (auto& k : v->stats) k = KStat{};
+  return F5HIP_OK;
 }
 
 int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int frames, int channel_major, int precision, float* out,
@@ -486,7 +570,9 @@ int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int fra
   if (!mel || !out || batch <= 0 || frames <= 0) FAIL(F5HIP_ERR_INVALID, "bad argument: mel/out null or batch/frames <= 0");
   if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
   HIPCHK(hipSetDevice(v->device));
-  return forward_impl(v, mel, batch, frames, channel_major, precision, out, reinterpret_cast<hipStream_t>(stream));
+  const int rc = forward_impl(v, mel, batch, frames, channel_major, precision, out, reinterpret_cast<hipStream_t>(stream));
+  bv_collect(v, reinterpret_cast<hipStream_t>(stream));
+  return rc;
 }
 
 }  // extern "C"

@@ -198,11 +198,17 @@ int f5hip_bigvgan_finalize(f5hip_bigvgan* v);
  * out: device fp32 [batch, frames * prod(upsample_rates)] (the reference's [batch, 1, T*hop] without the singleton axis). */
 int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int frames, int channel_major, int precision, float* out,
                           void* stream);
-/* key/value options: "conv_impl" (0 = every conv as a tap-gathered operand + the plain MFMA GEMM; 1 = one operand copy + the
+/* key/value options: "profile" (0/1, see f5hip_bigvgan_kernel_stat), "conv_impl" (0 = every conv as a tap-gathered operand + the plain MFMA GEMM; 1 = one operand copy + the
  * implicit-GEMM kernel with tap-shifted rows, csrc/conv_gemm.h; 2 = 1 with the operand copy written by the Activation1d kernel itself); "stop_after_stage" (parity tap for the tests; -1 = off): k >= 0 makes f5hip_bigvgan_forward write the
  * channels-last fp32 tensor [batch, L_k, C_k] after conv_pre (k = 0) / after upsampling stage k (k >= 1: L_k = frames * prod(rates[:k]),
  * C_k = upsample_initial_channel >> k) into `out` instead of the waveform. */
 int f5hip_bigvgan_set_option(f5hip_bigvgan* v, const char* key, int64_t value);
+/* Per-kernel-class statistics accumulated while option "profile" is 1 (HIP events on the launch stream around every launch; the call then
+ * synchronises the stream): classes "conv_gemm" (algorithmic FLOPs 2 L N taps Cin), "activation1d", "operand" (tap-gathered / operand
+ * emission), "other" (mean over resblocks, conv_post) with their algorithmic bytes.  Same shape as f5hip_kernel_stat. */
+int f5hip_bigvgan_num_kernel_stats(const f5hip_bigvgan* v);
+int f5hip_bigvgan_kernel_stat(const f5hip_bigvgan* v, int index, const char** name, int64_t* calls, double* total_ms, double* flops, double* bytes);
+int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
 
 /* ---- engine options / measurement ---------------------------------------------------------------- */
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel

@@ -284,7 +284,19 @@ def test_whole_generator_through_the_product_orchestration_code(emu_lib, name):
         got = voc.forward(mel, out_shape=(2, ref.shape[2], ref.shape[1])).transpose(1, 2)
         assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), f"stage {k}"
     voc.option("stop_after_stage", -1)
+    voc.option("profile", 1)
     base = voc.forward(mel)
+    voc.option("profile", 0)
+    import ctypes as C
+
+    name, calls, ms, fl, by = C.c_char_p(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+    stats = {}
+    for i in range(emu_lib.f5hip_bigvgan_num_kernel_stats(voc.ctx)):
+        assert emu_lib.f5hip_bigvgan_kernel_stat(voc.ctx, i, C.byref(name), C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by)) == 0
+        stats[name.value.decode()] = (calls.value, fl.value, by.value)
+    nconv = 1 + len(cfg.upsample_rates) + sum((2 if cfg.resblock == "1" else 1) * len(d) for d in cfg.resblock_dilation_sizes) * len(cfg.upsample_rates)
+    assert stats["conv_gemm"][0] == nconv == stats["operand"][0] and stats["conv_gemm"][1] > 0  # one GEMM + one operand emission per conv
+    assert stats["activation1d"][0] == nconv - 1 - len(cfg.upsample_rates) + 1 and stats["other"][0] == len(cfg.upsample_rates) + 1
     assert (base - want[:, 0]).abs().max().item() < 3e-5
     assert (voc.forward(mel.transpose(1, 2).contiguous(), channel_major=False) - base).abs().max().item() == 0.0
     for impl in (1, 2):
