@@ -12,7 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
-from typing import Dict, Optional, Union
+from typing import Dict, Union
 
 import torch
 

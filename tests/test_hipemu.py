@@ -41,7 +41,6 @@ def exe():
 
 def run(exe, d, mode, *args, **files):
     for name, arr in files.items():
-        (arr if isinstance(arr, bytes) else np.ascontiguousarray(arr).tobytes())
         with open(os.path.join(d, name + ".bin"), "wb") as f:
             f.write(arr if isinstance(arr, bytes) else np.ascontiguousarray(arr).tobytes())
     r = subprocess.run([exe, str(d), mode] + [str(int(a)) for a in args], capture_output=True, text=True, timeout=600)

@@ -5,7 +5,6 @@ FIRST LIGHT: written without GPU minutes; the kernel source has been executed on
 results, self-cleaning flags, run-to-run determinism) but never on an MI355X, and it synchronises workgroups through global memory
 (bounded spins).  Same isolation as tests/test_zz_gpu_bigvgan.py: the direct tests run only with F5HIP_STREAMK_GPU=1;
 `test_first_light_in_a_subprocess` runs them in a child with a time limit and turns anything but a green child into an xfail."""
-import ctypes as C
 import os
 import subprocess
 import sys
@@ -17,7 +16,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import f5_tts_amd  # noqa: E402,F401
-from f5_tts_amd import config, synth  # noqa: E402
+from f5_tts_amd import synth  # noqa: E402
 
 pytestmark = [pytest.mark.gpu]
 direct = pytest.mark.skipif(os.environ.get("F5HIP_STREAMK_GPU") != "1",
