@@ -33,6 +33,13 @@ def shim_engines(engine_emu_lib):  # noqa: F811
     mp.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
     mp.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))
     mp.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    orig_init = E.F5HipEngine.__init__
+
+    def init_on_cpu(self, dit_cfg, vocos_cfg=None, device=0):  # tests that build their own engine: a cuda descriptor in, CPU tensors after
+        orig_init(self, dit_cfg, vocos_cfg, device="cuda:0" if not isinstance(device, int) else device)
+        self.device = torch.device("cpu")
+
+    mp.setattr(E.F5HipEngine, "__init__", init_on_cpu)
     cache = {}
 
     def get(preset, wseed, vocos=False):
@@ -41,8 +48,7 @@ def shim_engines(engine_emu_lib):  # noqa: F811
             cfg = config.PRESETS[preset]
             sd = synth.synth_dit_state_dict(cfg, seed=wseed)
             vcfg = config.VOCOS_TINY if vocos else None
-            eng = E.F5HipEngine(cfg, vcfg, device="cuda:0")  # a descriptor only
-            eng.device = torch.device("cpu")
+            eng = E.F5HipEngine(cfg, vcfg, device=0)  # a descriptor only (init_on_cpu)
             if vocos:
                 sd = {**sd, **synth.synth_vocos_state_dict(vcfg, seed=1)}
             eng.load_state_dict(sd)
@@ -63,3 +69,22 @@ def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
 
 def test_mel_front_ends_on_the_shim(shim_engines):
     G.test_mel_matches_reference_golden(shim_engines)
+
+
+# the rest of the GPU suite's tiny-model tests, verbatim (each is one call into tests/test_gpu_parity.py)
+ENGINE_TESTS = ["test_bigvgan_mel_matches_reference_golden", "test_mel_too_short_raises", "test_text_longer_than_frames_and_unknown_ids",
+                "test_edit_mask_and_no_ref_audio", "test_vocos_decode_matches_oracle_golden", "test_vocos_batch_and_min_frames",
+                "test_flash_attention_equals_materialised_attention", "test_invalid_arguments_raise", "test_speech_edit_matches_oracle",
+                "test_all_padding_text_and_single_frame_prompt"]
+if os.environ.get("F5HIP_SHIM_FULL") == "1":  # 15-25 s each on the shim; pass as well (the CPU suite keeps to a few minutes without them)
+    ENGINE_TESTS += ["test_bigvgan_type_sampler_and_glue", "test_text_embedding_and_velocity_taps", "test_determinism_and_batch_consistency"]
+
+
+@pytest.mark.parametrize("fn", ENGINE_TESTS)
+def test_gpu_suite_function_on_the_shim(shim_engines, fn):
+    getattr(G, fn)(shim_engines)
+
+
+@pytest.mark.parametrize("nw", [513, 256 * 20 + 255])
+def test_mel_edge_lengths_on_the_shim(shim_engines, nw):
+    G.test_mel_edge_lengths(shim_engines, nw)
