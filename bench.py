@@ -186,7 +186,8 @@ def main():
 
     if rank != 0:
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier()  # rank 0 is still profiling / printing; leave together
+            torch.distributed.destroy_process_group()
         return
     ms_per_step = 1e3 * dt / a.steps
     frames = world * B * t_gen
@@ -248,6 +249,7 @@ def main():
     print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

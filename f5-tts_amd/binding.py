@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
 
-ABI_VERSION = 4  # F5HIP_ABI_VERSION in include/f5hip.h
+ABI_VERSION = 5  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 
@@ -49,6 +49,8 @@ SYMBOLS = {
     "f5hip_tensor_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "f5hip_weight_blob": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "f5hip_mark_all_loaded": (C.c_int, [_P]),
+    "f5hip_loaded_mask": (C.c_int, [_P, _P, C.c_int]),
+    "f5hip_set_loaded_mask": (C.c_int, [_P, _P, C.c_int]),
     "f5hip_finalize_weights": (C.c_int, [_P]),
     "f5hip_mel": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, C.c_int, C.c_int, _P]),
     "f5hip_sample": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float,

@@ -1499,6 +1499,23 @@ int f5hip_mark_all_loaded(f5hip_ctx* ctx) {
   return F5HIP_OK;
 }
 
+int f5hip_loaded_mask(f5hip_ctx* ctx, uint8_t* mask, int n) {
+  if (!ctx || !mask) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n != (int)ctx->slots.size()) FAIL(F5HIP_ERR_INVALID, "loaded mask: %d entries for %d tensors", n, (int)ctx->slots.size());
+  for (int i = 0; i < n; ++i) mask[i] = ctx->slots[i].loaded ? 1 : 0;
+  return F5HIP_OK;
+}
+
+int f5hip_set_loaded_mask(f5hip_ctx* ctx, const uint8_t* mask, int n) {
+  if (!ctx || !mask) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (n != (int)ctx->slots.size()) FAIL(F5HIP_ERR_INVALID, "loaded mask: %d entries for %d tensors", n, (int)ctx->slots.size());
+  for (int i = 0; i < n; ++i) ctx->slots[i].loaded = mask[i] != 0;
+  ctx->finalized = false;
+  return F5HIP_OK;
+}
+
 int f5hip_finalize_weights(f5hip_ctx* ctx) {
   if (!ctx) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);

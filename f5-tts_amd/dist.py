@@ -68,8 +68,12 @@ def broadcast_engine_weights(engine, src: int = 0) -> None:
     """Rank `src` has loaded the state dict; everyone else receives the blob and finalises."""
     blob = engine.weight_blob()
     broadcast_blob(blob, src=src)
-    if dist.is_initialized() and dist.get_rank() != src:
-        engine.mark_all_loaded()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        # which entries the sender actually read (a checkpoint's optional buffers travel in the blob; the mask says to use them)
+        mask = engine.loaded_mask().to(blob.device)
+        dist.broadcast(mask, src=src)
+        if dist.get_rank() != src:
+            engine.set_loaded_mask(mask)
     engine.finalize()
 
 

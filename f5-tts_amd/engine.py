@@ -145,6 +145,19 @@ class F5HipEngine:
     def mark_all_loaded(self):
         self._chk(self.lib.f5hip_mark_all_loaded(self._ctx))
 
+    def loaded_mask(self) -> torch.Tensor:
+        """uint8 [num_tensors] (tensor_table order): which state-dict entries this context has received."""
+        n = self.lib.f5hip_num_tensors(self._ctx)
+        m = torch.zeros(n, dtype=torch.uint8)
+        self._chk(self.lib.f5hip_loaded_mask(self._ctx, C.c_void_p(m.data_ptr()), n))
+        return m
+
+    def set_loaded_mask(self, mask: torch.Tensor):
+        """Receiver side of the weight broadcast: adopt the sender's mask (optional buffers included)."""
+        m = mask.detach().to(device="cpu", dtype=torch.uint8).contiguous()
+        self._chk(self.lib.f5hip_set_loaded_mask(self._ctx, C.c_void_p(m.data_ptr()), m.numel()))
+        self.finalized = False
+
     def finalize(self):
         with torch.cuda.device(self.device):
             self._chk(self.lib.f5hip_finalize_weights(self._ctx))
@@ -226,7 +239,10 @@ def _as_tensor(ptr: int, numel: int, device: torch.device) -> torch.Tensor:
 
     h = _Holder()
     h.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-    return torch.as_tensor(h, device=device)
+    t = torch.as_tensor(h, device=device)
+    if t.data_ptr() != ptr or t.device != device:  # a silent copy would make a broadcast fill the copy, not the engine's blob
+        raise binding.F5HipError(f"could not alias device memory at {ptr:#x} on {device} (got {t.device}, {t.data_ptr():#x})")
+    return t
 
 
 # -------------------------------------------------------------------------------------------------

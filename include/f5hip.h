@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 4
+#define F5HIP_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -103,6 +103,11 @@ int f5hip_tensor_info(const f5hip_ctx* ctx, int index, const char** name, int64_
 int f5hip_weight_blob(f5hip_ctx* ctx, void** device_ptr, int64_t* bytes);
 /* Mark every tensor as loaded (used after the blob was filled by a broadcast instead of load_tensor). */
 int f5hip_mark_all_loaded(f5hip_ctx* ctx);
+/* Which tensors have been loaded, in f5hip_tensor_info order (n = f5hip_num_tensors): the sender of the blob reads its mask, the
+ * receivers set it, so a checkpoint's OPTIONAL buffers (rotary inv_freq, text freqs_cis, the iSTFT window — recomputed when absent)
+ * are honoured on every rank exactly as on the rank that read the file.  Setting a mask un-finalises the context. */
+int f5hip_loaded_mask(f5hip_ctx* ctx, uint8_t* mask, int n);
+int f5hip_set_loaded_mask(f5hip_ctx* ctx, const uint8_t* mask, int n);
 /* Build derived device layouts (fp16 hi/lo operand copies, fused QKV, per-tap conv weights, FFT/mel
  * tables).  Must be called after all tensors are loaded and before any compute call.  Synchronous. */
 int f5hip_finalize_weights(f5hip_ctx* ctx);

@@ -9,6 +9,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def test_shard_contiguous_partitions_everything():
@@ -68,3 +69,72 @@ def test_world2_gloo_broadcast_and_timing():
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [2.0, 2.0]  # MAX over ranks
     assert res[0][3] == [0, 1, 2] and res[1][3] == [3, 4]
+
+
+# ---- the real engine under the real broadcast: libf5hip's host code and kernels built for the CPU (tests/hipemu), two gloo ranks ---------
+from test_hipemu import CLANG, engine_emu_lib  # noqa: E402,F401  (fixture: builds tests/c_abi/_build/engine_emu/libf5hip_engine_emu.so)
+
+
+def _engine_worker(rank, world, port, lib_path, q):
+    import contextlib
+    import ctypes as C
+    import types
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import f5_tts_amd  # noqa: F401
+    from f5_tts_amd import binding, config, synth
+    from f5_tts_amd import dist as fd
+    from f5_tts_amd import engine as E
+    from test_hipemu import host_alias
+
+    lib = C.CDLL(lib_path, mode=C.RTLD_LOCAL)
+    for name, (res, args) in binding.SYMBOLS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    E.load_library = lambda *a, **k: lib
+    E._as_tensor = host_alias
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    torch.cuda.current_stream = lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0)
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fd.init_distributed(backend="gloo")
+    cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
+    eng = E.F5HipEngine(cfg, vcfg, device="cuda:0")  # a descriptor only on the shim
+    eng.device = torch.device("cpu")
+    if rank == 0:  # bench.py's protocol: rank 0 reads the checkpoint (here one that carries an optional buffer), nobody else does
+        sd = {**synth.synth_dit_state_dict(cfg, seed=5), **synth.synth_vocos_state_dict(vcfg, seed=5)}
+        half = cfg.dim_head // 2
+        sd["transformer.rotary_embed.inv_freq"] = 1.0 / (9000.0 ** (torch.arange(half).float() / half))
+        eng.load_state_dict(sd, finalize=False)
+    fd.broadcast_engine_weights(eng, src=0)
+    wav = synth.synth_wave(256 * 30, seed=2, batch=1)
+    text = synth.synth_text_ids(1, 25, cfg.text_num_embeds, seed=4)
+    out, _ = E.F5HipCFM(eng, precision="fp32").sample(wav, text, 80, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    wave = eng.vocos_decode(out[:, 30:, :].contiguous(), channel_major=False)
+    dist.barrier()
+    q.put((rank, int(eng.loaded_mask().sum()), out.numpy(), wave.numpy()))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
+def test_world2_gloo_engine_weight_broadcast(engine_emu_lib):  # noqa: F811
+    """bench.py's N>1 start-up with real contexts: rank 0 loads, `broadcast_engine_weights` ships blob + loaded mask, rank 1 finalises
+    from what it received; both ranks then run the sampler and the vocoder and must agree bit for bit."""
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29811 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_engine_worker, args=(r, 2, port, engine_emu_lib._name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] > 0
+    assert np.isfinite(res[0][2]).all() and np.abs(res[0][2]).max() > 0
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])

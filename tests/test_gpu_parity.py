@@ -377,6 +377,49 @@ def test_small_models_golden(name):
         eng.close()
 
 
+def test_weight_blob_receiver_equals_the_rank_that_loaded(engines):
+    """The N>1 path of bench.py / dist.broadcast_engine_weights from the receiver's side, in one process: a context that never saw a
+    state dict gets the packed blob and the sender's loaded mask, finalises, and must produce the sender's bits — with a checkpoint
+    that carries an OPTIONAL buffer (rotary inv_freq, deliberately not the recomputed values) so the mask matters."""
+    from f5_tts_amd import binding
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
+    sd = {**synth.synth_dit_state_dict(cfg, seed=5), **synth.synth_vocos_state_dict(vcfg, seed=5)}
+    half = cfg.dim_head // 2
+    sd["transformer.rotary_embed.inv_freq"] = 1.0 / (9000.0 ** (torch.arange(half).float() / half))
+    a, b, c = (F5HipEngine(cfg, vcfg, device=0) for _ in range(3))
+    try:
+        a.load_state_dict(sd, finalize=False)  # what rank 0 does in bench.py
+        blob = a.weight_blob()
+        assert blob.data_ptr() == a.weight_blob().data_ptr() and blob.dtype == torch.float32  # an alias of the context's memory, not a copy
+        names = [n for n, _, _ in a.tensor_table()]
+        mask = a.loaded_mask()
+        assert mask.numel() == len(names) and mask[names.index("transformer.rotary_embed.inv_freq")] == 1
+        assert int(mask.sum()) == len(sd) and int(b.loaded_mask().sum()) == 0
+        with pytest.raises(binding.F5HipError):
+            b.finalize()  # nothing received yet: fails loudly instead of running on an empty blob
+        for recv in (b, c):
+            recv.weight_blob().copy_(blob)  # the broadcast
+        b.set_loaded_mask(mask)
+        c.mark_all_loaded()  # the pre-mask protocol: optional buffers are recomputed on the receiver
+        for e in (a, b, c):
+            e.finalize()
+        wav = synth.synth_wave(256 * 30, seed=2, batch=2).cuda()
+        text = synth.synth_text_ids(2, 25, cfg.text_num_embeds, seed=4)
+        kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+        outs = [F5HipCFM(e, precision="fp16x3").sample(wav, text, 90, **kw)[0] for e in (a, b, c)]
+        assert torch.equal(outs[0], outs[1])
+        assert not torch.equal(outs[0], outs[2])  # c rotated with the recomputed base-10000 table: the mask is what carries the buffer
+        gen = outs[0][:, 30:, :].contiguous()
+        assert torch.equal(a.vocos_decode(gen, channel_major=False), b.vocos_decode(gen, channel_major=False))
+        with pytest.raises(ValueError):
+            b.set_loaded_mask(mask[:-1])
+    finally:
+        for e in (a, b, c):
+            e.close()
+
+
 def test_invalid_arguments_raise(engines):
     from f5_tts_amd.engine import F5HipCFM
 

@@ -478,6 +478,13 @@ def engine_emu_lib():
     return lib
 
 
+def host_alias(ptr, numel, _device=None):
+    """engine._as_tensor for the shim: its "device" pointers are host pointers, so the alias is a torch view of that memory."""
+    import ctypes as C
+
+    return torch.frombuffer((C.c_float * numel).from_address(ptr), dtype=torch.float32)
+
+
 @pytest.fixture()
 def emu_engine(engine_emu_lib, monkeypatch):
     """F5HipEngine / F5HipCFM (the product's host classes, unmodified) over the emulated library: "device" tensors are CPU tensors."""
@@ -487,6 +494,7 @@ def emu_engine(engine_emu_lib, monkeypatch):
     from f5_tts_amd import engine as E
 
     monkeypatch.setattr(E, "load_library", lambda *a, **k: engine_emu_lib)
+    monkeypatch.setattr(E, "_as_tensor", host_alias)
     monkeypatch.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))
     made = []

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as G  # noqa: E402
-from test_hipemu import CLANG, engine_emu_lib  # noqa: E402,F401  (the fixture that builds the emulated library)
+from test_hipemu import CLANG, engine_emu_lib, host_alias  # noqa: E402,F401  (the fixture that builds the emulated library)
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
 
@@ -30,6 +30,7 @@ def shim_engines(engine_emu_lib):  # noqa: F811
 
     mp = pytest.MonkeyPatch()
     mp.setattr(E, "load_library", lambda *a, **k: engine_emu_lib)
+    mp.setattr(E, "_as_tensor", host_alias)
     mp.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
     mp.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))
     mp.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
@@ -75,7 +76,7 @@ def test_mel_front_ends_on_the_shim(shim_engines):
 ENGINE_TESTS = ["test_bigvgan_mel_matches_reference_golden", "test_mel_too_short_raises", "test_text_longer_than_frames_and_unknown_ids",
                 "test_edit_mask_and_no_ref_audio", "test_vocos_decode_matches_oracle_golden", "test_vocos_batch_and_min_frames",
                 "test_flash_attention_equals_materialised_attention", "test_invalid_arguments_raise", "test_speech_edit_matches_oracle",
-                "test_all_padding_text_and_single_frame_prompt"]
+                "test_all_padding_text_and_single_frame_prompt", "test_weight_blob_receiver_equals_the_rank_that_loaded"]
 if os.environ.get("F5HIP_SHIM_FULL") == "1":  # 15-25 s each on the shim; pass as well (the CPU suite keeps to a few minutes without them)
     ENGINE_TESTS += ["test_bigvgan_type_sampler_and_glue", "test_text_embedding_and_velocity_taps", "test_determinism_and_batch_consistency"]
 
