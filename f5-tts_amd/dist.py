@@ -66,9 +66,9 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20
 
 def broadcast_engine_weights(engine, src: int = 0) -> None:
     """Rank `src` has loaded the state dict; everyone else receives the blob and finalises."""
-    blob = engine.weight_blob()
-    broadcast_blob(blob, src=src)
     if dist.is_initialized() and dist.get_world_size() > 1:
+        blob = engine.weight_blob()  # an alias of the context's device memory (engine._as_tensor refuses to hand out a copy)
+        broadcast_blob(blob, src=src)
         # which entries the sender actually read (a checkpoint's optional buffers travel in the blob; the mask says to use them)
         mask = engine.loaded_mask().to(blob.device)
         dist.broadcast(mask, src=src)

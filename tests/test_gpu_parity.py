@@ -377,6 +377,12 @@ def test_small_models_golden(name):
         eng.close()
 
 
+# written without GPU minutes: executed on the CPU shim (tests/test_parity_on_shim.py) and under a real gloo broadcast (tests/test_dist_cpu.py);
+# on a GPU it runs in a child process first (tests/test_zz_gpu_first_light.py) so that it cannot turn the established suite red
+first_light = pytest.mark.skipif(os.environ.get("F5HIP_FIRST_LIGHT_GPU") != "1", reason="run by tests/test_zz_gpu_first_light.py in a child process")
+
+
+@first_light
 def test_weight_blob_receiver_equals_the_rank_that_loaded(engines):
     """The N>1 path of bench.py / dist.broadcast_engine_weights from the receiver's side, in one process: a context that never saw a
     state dict gets the packed blob and the sender's loaded mask, finalises, and must produce the sender's bits — with a checkpoint
