@@ -30,6 +30,8 @@ import f5_tts_amd  # noqa: E402,F401
 from f5_tts_amd import config, synth  # noqa: E402
 from f5_tts_amd import dist as fdist  # noqa: E402
 
+PROBE_CMD = [sys.executable, os.path.abspath(__file__)]  # the schedule-probing child (tests swap in a harness that runs this file on the CPU shim)
+DEVICE_TYPE = "cuda"  # the engine refuses anything else; only the CPU-shim harness (which also swaps the library) changes it
 PEAK_TFLOPS_FP16_DENSE = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16/fp16 MFMA
 HOP, SR = 256, 24000
 
@@ -48,6 +50,15 @@ def parse():
     ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
                     help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "default"],
+                    help="auto: at start-up, kernel schedules that are off by default (stream-K block GEMMs, key-split attention) are tried in a "
+                         "child process on this GPU at this workload, parity-checked against the default path and timed; one is adopted only if "
+                         "it is verified and faster, again checked in this process.  default: the default schedule, no probing")
+    ap.add_argument("--tiny", action="store_true",
+                    help="NOT a benchmark: the tiny model / Vocos at 120 frames (what smoke() runs), so that this file's own logic — rank protocol, "
+                         "schedule probing, JSON assembly — can be executed end to end, including on the CPU shim (tests/test_bench_on_shim.py)")
+    ap.add_argument("--probe", default=None, choices=["sk", "kv"], help="internal: run as the schedule-probing child for one option group")
+    ap.add_argument("--probe-device", type=int, default=0, help="internal: HIP device of the probing child")
     return ap.parse_args()
 
 
@@ -89,7 +100,7 @@ def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen, bigvgan=No
     else:
         O.vocos_decode(vsd, gen, vcfg.num_layers)
     t3 = time.perf_counter()
-    per_step = ((t2 - t1) - (t1 - t0)) / probe
+    per_step = max(((t2 - t1) - (t1 - t0)) / probe, 0.0)
     setup = max((t1 - t0) - per_step, 0.0)
     total = setup + nfe * per_step + (t3 - t2) * voc_scale
     cpu_name = ""
@@ -120,16 +131,115 @@ def pmc_traffic(a, B):
     return None
 
 
+# ---- schedule selection by measurement ------------------------------------------------------------------------------------------------
+# Option sets that are OFF by default in the engine (written after the GPU budget of their round was spent).  Each is tried in
+# a child process first, so that a kernel that has never run on this GPU cannot take the benchmark down with it.
+SCHEDULE_GROUPS = {
+    "sk": [{"gemm_streamk": 42}, {"gemm_streamk": 43},
+           {"gemm_streamk": 42, "gemm_streamk_split": 1, "branch_streams": 1}, {"gemm_streamk": 43, "gemm_streamk_split": 1, "branch_streams": 1}],
+    "kv": [{"attn_kv_split": 2}, {"attn_kv_split": 3}, {"attn_kv_split": 4}],
+}
+SCHEDULE_OFF = {"gemm_streamk": 0, "gemm_streamk_split": 0, "attn_kv_split": 1}
+SCHEDULE_TOL = 5e-4  # max-abs on the mel between two schedules of the same precision mode (summation order only); parity mode bound is 1e-3
+
+
+def set_schedule(eng, opts, branch_streams):
+    for k, v in {**SCHEDULE_OFF, "branch_streams": branch_streams, **opts}.items():
+        eng.set_option(k, v)
+
+
+def try_schedule(eng, opts, branch_streams, run, dev, base_mel, reps=4):
+    """Apply `opts`, check the generated mel against the default schedule's (and run-to-run), time `reps` passes.  Always restores the default."""
+    res = {"options": opts, "ok": False}
+    try:
+        set_schedule(eng, opts, branch_streams)
+        m1, m2 = run(mel=True), run(mel=True)
+        torch.cuda.synchronize(dev)
+        err = float((m1 - base_mel).abs().max())
+        res.update(max_abs_vs_default=err, deterministic=bool(torch.equal(m1, m2)), finite=bool(torch.isfinite(m1).all()))
+        res["ok"] = res["finite"] and res["deterministic"] and err < SCHEDULE_TOL
+        if res["ok"]:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize(dev)
+            res["ms"] = 1e3 * (time.perf_counter() - t0) / reps
+    except Exception as e:  # an option the engine refuses, a failed launch
+        res["error"] = repr(e)[:300]
+    finally:
+        set_schedule(eng, {}, branch_streams)
+    return res
+
+
+def time_default(eng, branch_streams, run, dev, reps=4):
+    set_schedule(eng, {}, branch_streams)
+    base = run(mel=True).clone()
+    run()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize(dev)
+    return base, 1e3 * (time.perf_counter() - t0) / reps
+
+
+def probe_child(a, eng, run, dev):
+    """--probe GROUP: the child's whole job.  One JSON line {"probe": ...} on stdout."""
+    reps = 1 if a.tiny else 4
+    base, t_base = time_default(eng, a.branch_streams, run, dev, reps)
+    out = {"group": a.probe, "default_ms": t_base,
+           "candidates": [try_schedule(eng, o, a.branch_streams, run, dev, base, reps) for o in SCHEDULE_GROUPS[a.probe]]}
+    print(json.dumps({"probe": out}), flush=True)
+
+
+def probe_in_children(a, local):
+    """Rank 0: one child per option group on this rank's GPU (same workload flags), bounded in time; returns the verified winners."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE")
+           and not k.startswith("TORCHELASTIC")}
+    report, winners = {}, []
+    for group in SCHEDULE_GROUPS:
+        cmd = PROBE_CMD + (["--tiny"] if a.tiny else []) + (["--no-graph"] if a.no_graph else []) + ["--probe", group, "--probe-device", str(local), "--batch", str(a.batch), "--nfe", str(a.nfe),
+               "--precision", a.precision, "--model", a.model, "--vocoder", a.vocoder, "--branch-streams", str(a.branch_streams), "--no-cpu-baseline"]
+        try:
+            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"probe"')), None)
+            if line is None:
+                report[group] = {"error": f"child exit {r.returncode}: {(r.stdout + r.stderr)[-400:]}"}
+                continue
+            pr = json.loads(line)["probe"]
+        except subprocess.TimeoutExpired:
+            report[group] = {"error": "child timed out"}
+            continue
+        except Exception as e:  # pragma: no cover
+            report[group] = {"error": repr(e)[:300]}
+            continue
+        report[group] = pr
+        good = [c for c in pr["candidates"] if c.get("ok") and c.get("ms") and c["ms"] < 0.98 * pr["default_ms"]]
+        if good:
+            winners.append(min(good, key=lambda c: c["ms"])["options"])
+    return report, winners
+
+
 def main():
     a = parse()
+    if a.probe:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            os.environ.pop(k, None)
+        os.environ["LOCAL_RANK"] = str(a.probe_device)
     rank, local, world = fdist.init_distributed()
     assert world == max(a.gpus, 1) or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     from f5_tts_amd.engine import F5HipCFM, F5HipEngine, F5HipVocos
 
-    dev = torch.device("cuda", local)
+    dev = torch.device(DEVICE_TYPE, local) if DEVICE_TYPE == "cuda" else torch.device(DEVICE_TYPE)
     torch.cuda.set_device(dev)
     big = a.vocoder == "bigvgan"
     cfg, vcfg = config.PRESETS[a.model], (None if big else config.VOCOS_MEL_24K)
+    if a.tiny:
+        assert not big, "--tiny is the Vocos pairing only"
+        a.model, cfg, vcfg = "tiny", config.DIT_TINY, config.VOCOS_TINY
     eng = F5HipEngine(cfg, vcfg, device=dev)
     sd = vsd = None
     if rank == 0:  # rank 0 "reads the checkpoint"; the packed blob travels over RCCL/xGMI
@@ -157,18 +267,52 @@ def main():
         model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
 
     B, nw, nt, duration = a.batch, 120000, 220, 1406
+    if a.tiny:
+        nw, nt, duration = 256 * 40, 30, 120
     wav = synth.synth_wave(nw, seed=1000 * rank, batch=B).to(dev)  # resident in HBM before the timed region
     text = synth.synth_text_ids(B, nt, cfg.text_num_embeds, seed=rank)
     ref_len = nw // HOP  # 468 (utils_infer.py:486)
     t_gen = duration - ref_len  # 938 vocoded frames per utterance
     kw = dict(steps=a.nfe, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)
 
-    def one_pass():
+    def one_pass(mel=False):
         out, _ = model.sample(wav, text, duration, **kw)
         gen = out[:, ref_len:, :]  # [B, 938, 100] view; the engine takes frame-major directly
         if big:  # vocoder(mel[b, 100, T]) as at reference utils_infer.py:509-513
-            return voc(gen.permute(0, 2, 1))[:, 0]
-        return eng.vocos_decode(gen.contiguous(), channel_major=False)
+            wave = voc(gen.permute(0, 2, 1))[:, 0]
+        else:
+            wave = eng.vocos_decode(gen.contiguous(), channel_major=False)
+        return out if mel else wave
+
+    if a.probe:
+        probe_child(a, eng, one_pass, dev)
+        return
+    forced = any(os.environ.get(k) for k in ("F5HIP_BENCH_KVSPLIT", "F5HIP_BENCH_STREAMK"))
+    schedule = {"selected": {}, "how": "default schedule" + (" (switches forced by the environment)" if forced else "")}
+    if a.schedule == "auto" and not forced:
+        report, cands = probe_in_children(a, local) if rank == 0 else ({}, [])
+        if world > 1:  # every rank runs what rank 0's children verified
+            box = [cands]
+            torch.distributed.broadcast_object_list(box, src=0)
+            cands = box[0]
+        if len(cands) == 2:
+            cands = [{**cands[0], **cands[1]}] + cands  # the combination first, then each alone
+        schedule["probe"] = report
+        if cands:  # second check, in this process: parity and time against the default, the same decision on every rank
+            reps = 1 if a.tiny else 4
+            base, t_def = time_default(eng, a.branch_streams, one_pass, dev, reps)
+            tried = [try_schedule(eng, o, a.branch_streams, one_pass, dev, base, reps) for o in cands]
+            ms = torch.tensor([t_def] + [t["ms"] if t["ok"] else float("inf") for t in tried], dtype=torch.float64, device=dev)
+            if world > 1:
+                torch.distributed.all_reduce(ms, op=torch.distributed.ReduceOp.MAX)
+            ms = ms.tolist()
+            best = min(range(1, len(ms)), key=lambda i: ms[i])
+            schedule.update(default_ms=ms[0], tried=[{**t, "ms_max_over_ranks": m} for t, m in zip(tried, ms[1:])])
+            if ms[best] < 0.99 * ms[0]:
+                schedule["selected"] = cands[best - 1]
+                schedule["how"] = ("measured at start-up: verified and timed in a child process, then parity-checked (max-abs on the mel < "
+                                   f"{SCHEDULE_TOL}) and timed again here against the default schedule")
+        set_schedule(eng, schedule["selected"], a.branch_streams)
 
     for _ in range(a.warmup):
         one_pass()
@@ -199,10 +343,12 @@ def main():
         "dtype": {"fp16x3": "fp16x3 (fp16 hi/lo split MFMA operands, fp32 accumulate/state)", "fp16": "fp16 (fp32 accumulate/state)",
                   "fp32": "fp32"}[a.precision],
         "data": "synthetic (seeded 0.1*N(0,1) prompts, uniform token ids, random-init weights of the named architecture)",
-        "config": {"workload": f"{a.model} + {'BigVGAN-v2 (24 kHz, 100 band, 256x)' if big else 'Vocos'}, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
+        "config": {"workload": f"NOT A BENCHMARK (--tiny): tiny model + tiny Vocos, {duration} frames, NFE={a.nfe}" if a.tiny else
+                               f"{a.model} + {'BigVGAN-v2 (24 kHz, 100 band, 256x)' if big else 'Vocos'}, batch {B}/GPU, 5 s ref + 10 s gen (N=1406 frames, 938 vocoded), NFE={a.nfe}, "
                                f"sway -1, CFG 2.0, euler (BASELINE.json configs[{1 if B == 1 else 2}])",
                    "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
-                   "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via},
+                   "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via,
+                   "schedule": schedule},
     }
     # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager pass -------
     eng.set_option("profile", 1)
@@ -222,12 +368,12 @@ def main():
                 **({"gbps": round(v["bytes"] / (1e-3 * v["ms"]) / 1e9, 1)} if v["bytes"] and v["ms"] > 0 else {})}
             for k, v in voc.kernel_stats().items() if v["calls"]}
     g = stats["gemm_block"]
-    if g["calls"]:
+    if g["calls"] and g["ms"] > 0:
         avg_s = 1e-3 * g["ms"] / g["calls"]
         ach = g["flops"] / g["calls"] / avg_s / 1e12
-        res["roofline"] = {"kernel": "gemm_kernel (DiT block QKV/out/FF1/FF2)", "bound": "mfma", "achieved": ach,
+        res["roofline"] = {"kernel": ("gemm_skrs_kernel, stream-K" if schedule["selected"].get("gemm_streamk") else "gemm_kernel") + " (DiT block QKV/out/FF1/FF2)", "bound": "mfma", "achieved": ach,
                            "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE,
-                           "traffic": pmc_traffic(a, B), "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
+                           "traffic": None if schedule["selected"] else pmc_traffic(a, B), "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
                            "mfma_issue_tflops": ach * (3 if a.precision == "fp16x3" else 1),
                            "note": "achieved = algorithmic FLOPs (2MNK, SURVEY.md 8d) / avg launch duration, HIP events on the launch "
                                    "stream; fp16x3 issues 3 fp16 MFMAs per algorithmic product (mfma_issue_tflops = 3x achieved); "

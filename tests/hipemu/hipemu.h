@@ -11,6 +11,7 @@
 // Not emulated: inline asm (LDS-DMA ring / stream-K kernels are compiled out under F5_HIPEMU), timing, caches, memory ordering.
 #pragma once
 #define F5_HIPEMU 1
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -99,12 +100,19 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(uintptr_t(1)); return hipSuccess; }
+// launches run synchronously on the shim, so an event's "completion time" is the host clock at the moment it is recorded
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0.0); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
-static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete static_cast<double*>(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  *static_cast<double*>(e) = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  return hipSuccess;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = (float)(*static_cast<double*>(b) - *static_cast<double*>(a));
+  return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }

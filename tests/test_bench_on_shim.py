@@ -1,0 +1,65 @@
+"""bench.py executed end to end without a GPU: its main() over libf5hip built for the host (tests/hipemu) on the --tiny workload — the
+single-rank flow with the schedule-probing children, and the two-rank flow under torch.distributed.run (gloo): weight broadcast from rank 0,
+the probe on rank 0 only and its result shared, max-over-ranks timing, one JSON line from rank 0.  Numbers printed here mean nothing; the
+contract fields and the rank protocol are what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_hipemu import CLANG, engine_emu_lib  # noqa: E402,F401
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
+HARNESS = os.path.join(ROOT, "tests", "bench_shim_harness.py")
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+
+
+def run(cmd, lib, timeout=900):
+    env = dict(os.environ, F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def check_probe_report(sched):
+    for group, n in (("sk", 4), ("kv", 3)):  # both children ran every candidate against the default path
+        pr = sched["probe"][group]
+        assert "error" not in pr and pr["default_ms"] > 0 and len(pr["candidates"]) == n
+        for c in pr["candidates"]:
+            assert c["ok"] and c["deterministic"] and c["max_abs_vs_default"] < 5e-4 and c["ms"] > 0, c
+    for k in sched["selected"]:  # whatever was adopted went through the in-process check as well
+        assert any(t["ok"] and k in t["options"] and t["ms_max_over_ranks"] >= t["ms"] for t in sched["tried"])
+
+
+@pytest.mark.skipif(os.environ.get("F5HIP_SHIM_FULL") != "1", reason="2 min on the shim; the two-rank test below covers the same code plus the rank protocol")
+def test_single_rank_with_schedule_probe(engine_emu_lib):  # noqa: F811
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib)
+    assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
+    check_probe_report(d["config"]["schedule"])
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_default_schedule_flag_skips_the_probe(engine_emu_lib):  # noqa: F811
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "2", "--steps", "1", "--warmup", "0", "--schedule", "default"], engine_emu_lib)
+    assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
+    assert d["config"]["schedule"] == {"selected": {}, "how": "default schedule"}
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_two_ranks_under_torch_distributed_run(engine_emu_lib):  # noqa: F811
+    port = 29911 + (os.getpid() % 80)
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+             HARNESS, "--gpus", "2", "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
+    assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
+    check_probe_report(d["config"]["schedule"])  # rank 0's children; the decision is shared and re-checked on both ranks
