@@ -18,8 +18,8 @@ HARNESS = os.path.join(ROOT, "tests", "bench_shim_harness.py")
 CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
 
 
-def run(cmd, lib, timeout=900):
-    env = dict(os.environ, F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2")
+def run(cmd, lib, timeout=900, **extra_env):
+    env = dict(os.environ, F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2", **extra_env)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -59,7 +59,11 @@ def test_default_schedule_flag_skips_the_probe(engine_emu_lib):  # noqa: F811
 def test_two_ranks_under_torch_distributed_run(engine_emu_lib):  # noqa: F811
     port = 29911 + (os.getpid() % 80)
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-             HARNESS, "--gpus", "2", "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200)
+             HARNESS, "--gpus", "2", "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200,
+            F5HIP_BENCH_ADOPT_RATIO="100")  # timing on the shim is noise: adopt whatever verifies, so that the adoption path runs too
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
     assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
-    check_probe_report(d["config"]["schedule"])  # rank 0's children; the decision is shared and re-checked on both ranks
+    sched = d["config"]["schedule"]
+    check_probe_report(sched)  # rank 0's children; the decision is shared and re-checked on both ranks
+    assert sched["selected"] and sched["how"].startswith("measured at start-up") and len(sched["tried"]) == 3  # combination, stream-K alone, key-split alone
+    assert d["roofline"]["traffic"] is None  # the committed PMC pass describes the default schedule only

@@ -26,6 +26,9 @@ for kvs in 2 3; do F5HIP_BENCH_KVSPLIT=$kvs timeout 600 python bench.py --no-cpu
 F5HIP_BENCH_KVSPLIT=2 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_kvsplit2.json 2> $out/bench_b1_sk42_kvsplit2.err
 # 3c. calibration: the vendor library on a PLAIN fp16 GEMM at the same shapes (what the part does vs what our fused k-loop loses)
 timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
+# 3d. the bench as the driver runs it (--schedule auto: children probe the switches above, see config.schedule in the line) and the receiver-path first light
+timeout 900 python bench.py > $out/bench_b1_auto.json 2> $out/bench_b1_auto.err
+F5HIP_FIRST_LIGHT_GPU=1 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k receiver > $out/first_light_tests.log 2>&1; echo "first-light tests exit $?" | tee -a $out/summary.txt
 # 4. the headline, unchanged code path (regression check of the header refactors: F5_DYN_LDS macro, split headers)
-timeout 600 python bench.py > $out/bench_b1.json 2> $out/bench_b1.err
+timeout 600 python bench.py --schedule default > $out/bench_b1.json 2> $out/bench_b1.err
 cat $out/hipblaslt_ref.log; tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_kvsplit2.json $out/bench_b1_kvsplit3.json $out/bench_b1_sk42_kvsplit2.json $out/bench_b1_packed.json $out/bench_b1.json $out/bench_b1.json
