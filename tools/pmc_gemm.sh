@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $out/p$i -o p$i -- env KB_EPI=0 python $GRAFT_REPO_ROOT/tools/kernel_bench.py "$@" > $out/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $out/p$i -o p$i -- env KB_EPI=0 python $GRAFT_REPO_ROOT/tools/kernel_bench.py --schedule default "$@" > $out/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

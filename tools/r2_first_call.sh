@@ -16,12 +16,12 @@ for epi in 1 2; do for shape in "2816 1024 1024" "2816 1024 2048" "2816 2048 102
 done; done > $out/skrs_time.log 2>&1
 for g in 128 192 256; do KB_SKGRID=$g KB_EPI=2 timeout 120 python tools/kernel_bench.py one fp16x3 42 2816 1024 2048 20 2>&1 | grep -E "^gemm" | sed "s/^/grid$g /"; done >> $out/skrs_time.log 2>&1
 # 3. BASELINE configs[4] as named (E2-TTS Base + BigVGAN, batch 8), the three conv implementations are a context option: default (0) only here
-timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_e2_bigvgan_b8.json 2> $out/bench_e2_bigvgan_b8.err
+timeout 600 python bench.py --schedule default --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_e2_bigvgan_b8.json 2> $out/bench_e2_bigvgan_b8.err
 # 3b. the headline with the stream-K block GEMMs (packed schedule) against the default two-chain schedule
 for sk in 42 43; do F5HIP_BENCH_STREAMK=$sk timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk$sk.json 2> $out/bench_b1_sk$sk.err; done
 F5HIP_SK_GENERIC_EPI=1 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_generic_epi.json 2> $out/bench_b1_sk42_generic_epi.err
 F5HIP_BENCH_STREAMK=42 F5HIP_BENCH_STREAMK_SPLIT=1 timeout 600 python bench.py --branch-streams 1 --no-cpu-baseline > $out/bench_b1_sk42_split.json 2> $out/bench_b1_sk42_split.err
-timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_packed.json 2> $out/bench_b1_packed.err
+timeout 600 python bench.py --schedule default --branch-streams 0 --no-cpu-baseline > $out/bench_b1_packed.json 2> $out/bench_b1_packed.err
 for kvs in 2 3; do F5HIP_BENCH_KVSPLIT=$kvs timeout 600 python bench.py --no-cpu-baseline > $out/bench_b1_kvsplit$kvs.json 2> $out/bench_b1_kvsplit$kvs.err; done
 F5HIP_BENCH_KVSPLIT=2 F5HIP_BENCH_STREAMK=42 timeout 600 python bench.py --branch-streams 0 --no-cpu-baseline > $out/bench_b1_sk42_kvsplit2.json 2> $out/bench_b1_sk42_kvsplit2.err
 # 3c. calibration: the vendor library on a PLAIN fp16 GEMM at the same shapes (what the part does vs what our fused k-loop loses)
