@@ -77,17 +77,17 @@ def host_cores():
 
 def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen, bigvgan=None):
     """Oracle (port of the reference CPU path) on the host cores, bounded sample (~10-30 s of CPU work): mel + text-embed +
-    1 ODE step, then 1 + `probe` steps, + the vocoder, all at full size; per-step time extrapolated to `nfe` steps (every
-    step does identical work)."""
+    1 ODE step, then 1 + `probe` steps (probe = 2..8, sized from the first run), + the vocoder, all at full size; per-step time
+    extrapolated to `nfe` steps (every step does identical work)."""
     from oracle import f5_oracle as O
 
-    probe = 2
     cores = host_cores()
     torch.set_num_threads(cores)
     kw = dict(cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, use_epss=False)
     t0 = time.perf_counter()
     O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1, **kw)
     t1 = time.perf_counter()
+    probe = max(2, min(8, int(15.0 / max(t1 - t0, 1e-3)) - 2))  # sized from the first measurement so that the whole sample is ~10-30 s of CPU work
     out, _ = O.cfm_sample(sd, cfg, wav[:1], text[:1], duration, steps=1 + probe, **kw)
     t2 = time.perf_counter()
     gen = out[:, wav.shape[-1] // HOP:, :].permute(0, 2, 1)
