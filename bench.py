@@ -291,7 +291,11 @@ def main():
         return
     forced = any(os.environ.get(k) for k in ("F5HIP_BENCH_KVSPLIT", "F5HIP_BENCH_STREAMK"))
     schedule = {"selected": {}, "how": "default schedule" + (" (switches forced by the environment)" if forced else "")}
-    if a.schedule == "auto" and not forced:
+    if a.schedule == "auto" and not forced and B * duration > 6144:
+        # the probed schedules exist for latency-bound launches (few, short workgroups per kernel); at large batch every launch is many
+        # rounds of tiles deep and they have nothing to offer — not worth minutes of probing
+        schedule["how"] = "default schedule (probing applies to small batches only: B x N <= 6144 rows)"
+    elif a.schedule == "auto" and not forced:
         report, cands = probe_in_children(a, local) if rank == 0 else ({}, [])
         if world > 1:  # every rank runs what rank 0's children verified
             box = [cands]
