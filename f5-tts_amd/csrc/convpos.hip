@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
   constexpr int WCH = CPG * CPG * (int)sizeof(T) / 16;    // 16-byte chunks per tap tile
   constexpr int CPR = CPG * (int)sizeof(T) / 16;          // chunks per row
   constexpr int WPT = (WCH + 255) / 256;
-  uint4 rw[NPL][WPT];
+  // plain vector-typed temporaries: an array of HIP's uint4 CLASS here is not scalarised by the compiler and ends up in scratch (every
+  // tap's weight chunks went global -> scratch -> LDS; found by tests/test_isa_hazards.py), an array of ext_vector_type values stays in VGPRs
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 rw[NPL][WPT];
   const int64_t wtile = (int64_t)CPG * CPG;
   auto load_w = [&](int tap) {
     const T* src = w + ((int64_t)g * K + tap) * wtile;
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
     for (int i = 0; i < WPT; ++i) {
       const int c = tid + i * 256;
       if (c < WCH) {
-        rw[0][i] = reinterpret_cast<const uint4*>(src)[c];
-        if constexpr (NPL == 2) rw[1][i] = reinterpret_cast<const uint4*>(src_lo)[c];
+        rw[0][i] = reinterpret_cast<const u32x4*>(src)[c];
+        if constexpr (NPL == 2) rw[1][i] = reinterpret_cast<const u32x4*>(src_lo)[c];
       }
     }
   };
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ 
         const int r = c / CPR, cc = c - r * CPR;
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
-          *reinterpret_cast<uint4*>(sW + stage * C::WSTAGE + p * C::WPLANE + r * C::WROWB + ((C::WSWZ ? (cc ^ (r & 7)) : cc) << 4)) = rw[p][i];
+          *reinterpret_cast<u32x4*>(sW + stage * C::WSTAGE + p * C::WPLANE + r * C::WROWB + ((C::WSWZ ? (cc ^ (r & 7)) : cc) << 4)) = rw[p][i];
       }
     }
   };
