@@ -50,6 +50,4 @@ def install():
 
 
 if __name__ == "__main__":
-    if "--no-graph" not in sys.argv:  # the shim has no stream capture; everything else in bench.py runs as written
-        sys.argv.append("--no-graph")
     install().main()

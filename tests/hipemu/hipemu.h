@@ -56,6 +56,11 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 // every allocation sits between two 4 KiB guard zones of a known pattern, checked when it is freed: a kernel that WRITES outside its
 // buffers aborts the test instead of silently corrupting a neighbour (reads outside surface as wrong results)
 namespace hipemu {
+// stream capture: while a capture is open on this thread, launches and async copies are RECORDED (closures over their by-value
+// arguments, exactly what a graph node holds) instead of executed; hipGraphLaunch runs the record in order.  Serial replay is one valid
+// schedule of the captured graph — fork / join through events (the two-chain schedule) therefore needs nothing extra.
+struct GraphRec { std::vector<std::function<void()>> nodes; };
+inline thread_local GraphRec* capturing = nullptr;
 constexpr size_t kGuard = 4096;
 struct AllocHdr { size_t n; };
 inline void check_guards(void* p) {
@@ -82,17 +87,21 @@ static inline hipError_t hipFree(void* p) {
   free(static_cast<char*>(p) - hipemu::kGuard);
   return hipSuccess;
 }
-static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+// (a synchronous copy inside a thread-local capture is an error on the GPU as well: hipErrorStreamCaptureImplicit)
+static inline hipError_t hipMemset(void* p, int v, size_t n) { if (hipemu::capturing) return 906; memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (hipemu::capturing) return 906; memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  if (hipemu::capturing) hipemu::capturing->nodes.push_back([=] { memcpy(d, s, n); });
+  else memcpy(d, s, n);
+  return hipSuccess;
+}
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu error"; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
-// streams / events / graphs: everything runs synchronously on the calling thread; graph capture is not emulated (the engine's
-// "use_graph" option stays off under the shim)
+// streams / events / graphs: everything runs synchronously on the calling thread; stream capture records closures (hipemu::GraphRec)
 typedef void* hipGraph_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipStreamCaptureModeThreadLocal = 1, hipErrorNotSupported = 801 };
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
@@ -113,13 +122,34 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
   *ms = (float)(*static_cast<double*>(b) - *static_cast<double*>(a));
   return hipSuccess;
 }
-static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
-static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
-static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
-static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
-static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  if (hipemu::capturing) hipemu::capturing->nodes.push_back([=] { memset(p, v, n); });
+  else memset(p, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) {
+  if (hipemu::capturing) return hipErrorInvalidValue;
+  hipemu::capturing = new hipemu::GraphRec();
+  return hipSuccess;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+  if (!hipemu::capturing) return hipErrorInvalidValue;
+  *g = hipemu::capturing;
+  hipemu::capturing = nullptr;
+  return hipSuccess;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) {
+  if (!g) return hipErrorInvalidValue;
+  *e = new hipemu::GraphRec(*static_cast<hipemu::GraphRec*>(g));
+  return hipSuccess;
+}
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  if (!e || hipemu::capturing) return hipErrorInvalidValue;
+  for (auto& node : static_cast<hipemu::GraphRec*>(e)->nodes) node();
+  return hipSuccess;
+}
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete static_cast<hipemu::GraphRec*>(g); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete static_cast<hipemu::GraphRec*>(e); return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }
 using std::max;
@@ -319,6 +349,10 @@ inline void spin_yield() {
   yield_to_scheduler();
 }
 inline void launch_coop(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn, size_t stack_bytes = 64 * 1024) {
+  if (capturing) {
+    capturing->nodes.push_back([=] { launch_coop(grid, block, lds_bytes, fn, stack_bytes); });
+    return;
+  }
   const int nt = (int)(block.x * block.y * block.z), nw = (nt + 63) / 64;
   const long nblocks = (long)grid.x * grid.y * grid.z;
   std::unique_ptr<char[]> stacks(new char[(size_t)nblocks * nt * stack_bytes + 64]);
@@ -373,6 +407,11 @@ inline void launch_coop(dim3 grid, dim3 block, size_t lds_bytes, const std::func
 
 // run fn() once per HIP thread of a grid x block launch; every block has completed when this returns
 inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& fn) {
+  if (capturing) {  // a kernel node: its arguments were captured by value in fn
+    GraphRec* rec = capturing;
+    rec->nodes.push_back([=] { launch(grid, block, lds_bytes, fn); });  // replay happens with no capture open
+    return;
+  }
   const int nt = (int)(block.x * block.y * block.z);
   const long nblocks = (long)grid.x * grid.y * grid.z;
   const int nworkers = (int)std::max(1L, std::min<long>(nblocks, std::min(8u, std::max(1u, std::thread::hardware_concurrency()))));

@@ -62,6 +62,7 @@ def test_two_ranks_under_torch_distributed_run(engine_emu_lib):  # noqa: F811
              HARNESS, "--gpus", "2", "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200,
             F5HIP_BENCH_ADOPT_RATIO="100")  # timing on the shim is noise: adopt whatever verifies, so that the adoption path runs too
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
+    assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim) while the probe flips schedules
     assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
     sched = d["config"]["schedule"]
     check_probe_report(sched)  # rank 0's children; the decision is shared and re-checked on both ranks
