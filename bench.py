@@ -13,6 +13,11 @@ per-GPU batch on its own utterances; weights are broadcast once from rank 0 over
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).  `roofline` is measured live for the dominant
 kernel (the DiT block GEMM) with HIP events on the launch stream in an extra, untimed, eager pass; `cpu_baseline` is
 the oracle (a restatement of the reference's CPU path) timed on the host cores on a bounded sample.
+
+Before the warm-up, `--schedule auto` (default, small batches only) lets rank 0 try the engine's off-by-default kernel schedules in child
+processes on its GPU (parity against the default path + time), shares what verified with all ranks, re-checks it in-process, and runs the
+timed region with a schedule only if it is verified on every rank and faster; the mel is compared with the default path's again afterwards.
+Everything that happened is reported under `config.schedule`.  `--schedule default` = no probing.
 """
 import argparse
 import json
