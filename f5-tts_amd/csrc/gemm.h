@@ -147,7 +147,11 @@ struct EpiGateRes {   // attention out-projection / FeedForward second linear: x
 //   half mode  (q16 != null): q16/k16 [B'*H, nseq, dh] f16, vt16 [B'*H, dh, ldvt] f16 (V transposed for the
 //                              flash kernel's V^T tiles); optional *_lo planes (fp16 hi/lo split)
 //   float mode (q32 != null): q32/k32 [B'*H, nseq, dh] f32, vt32 [B'*H, dh, ldvt] f32 (V transposed)
-struct EpiQKV {
+template <bool B, typename T, typename F> struct f5_conditional { typedef T type; };
+template <typename T, typename F> struct f5_conditional<false, T, F> { typedef F type; };
+
+template <bool FAST>  // FAST: the division-free, 32-bit index path (a kernel of its own: see EpiQKVFast below)
+struct EpiQKVT {
   const float* bias;    // [3*inner]
   const float* rope_cs; // [nseq, dh/2, 2] (cos, sin) fp32
   int nseq, heads, dh;
@@ -161,55 +165,110 @@ struct EpiQKV {
                         // land at token pos_off + pos (rope still uses pos); slab_n == 0 means slab_n = nseq, pos_off = 0
   int qk_raw;           // qk_norm variant: q and k leave as fp32 rows holding Wx + b only (q32/k32); qk_norm_rope_kernel finishes them
 
-  __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
-    const int inner = heads * dh;
-    const int which = n / inner;
-    const int c = n - which * inner;
-    const int hh = c / dh, d = c - hh * dh;
-    const int bp = m / nseq, pos = m - bp * nseq;
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-    float x[4] = {v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w};
+  // Fast index path (EpiQKVFast, chosen by launch_gemm_qkv when epi_qkv_prepare() accepts: dh a power of two and every element index
+  // of the slabs within 31 bits — all shipped configurations): the general path spends ~400 quarter-rate integer multiplies and 24
+  // integer divisions per 128x64 tile on (n / inner, c / dh, m / nseq) and 64-bit offset products — more VALU time than the tile's
+  // MFMAs.  Here: `which` by two comparisons, head / channel by shift and mask, sequence / position by an invariant multiplier, 32-bit
+  // offsets.  Same indices, same arithmetic on the values (tests/hipemu/qkv_index_check.cpp compares every store of both paths byte for
+  // byte at the full sizes).  A compile-time choice: both paths inlined into one epilogue stopped the big tiles' epilogue loops from
+  // unrolling (accumulators in scratch; caught by tests/test_isa_hazards.py).
+  int fast;             // set by epi_qkv_prepare (host bookkeeping; the kernels do not read it)
+  int inner_;           // heads * dh
+  int dh_shift;         // log2(dh)
+  uint32_t nseq_magic;  // m / nseq == mulhi(m, nseq_magic) >> nseq_shift for 0 <= m < 2^31
+  int nseq_shift;
+
+  __device__ __forceinline__ void store(int which, int hh, int d, int bp, int pos, float (&x)[4]) const {
+    using I = typename f5_conditional<FAST, int, int64_t>::type;  // offset arithmetic: 32-bit on the fast path
+    auto mul_dh = [&](I t) -> I { return FAST ? (I)(t << dh_shift) : (I)(t * dh); };
     const int sn = slab_n ? slab_n : nseq, tokp = pos_off + pos;  // slab length, token index inside the slab
     if (qk_raw && which < 2) {
-      float* dst = (which == 0 ? q32 : k32) + (((int64_t)bp * heads + hh) * sn + tokp) * dh + d;
+      float* dst = (which == 0 ? q32 : k32) + (mul_dh(((I)bp * heads + hh) * sn + tokp) + d);
       *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
       return;
     }
     if (which < 2 && (pe_heads < 0 || hh < pe_heads)) {
-      const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((int64_t)pos * (dh / 2) + d / 2) * 2);
+      const float4 cs = *reinterpret_cast<const float4*>(rope_cs + ((FAST ? (I)((I)pos << (dh_shift - 1)) : (I)pos * (dh / 2)) + d / 2) * 2);
       const float a0 = x[0] * cs.x - x[1] * cs.y, a1 = x[1] * cs.x + x[0] * cs.y;
       const float a2 = x[2] * cs.z - x[3] * cs.w, a3 = x[3] * cs.z + x[2] * cs.w;
       x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
     }
     if (which == 0) { x[0] *= qscale; x[1] *= qscale; x[2] *= qscale; x[3] *= qscale; }
-    const int64_t bh = (int64_t)bp * heads + hh;
+    const I bh = (I)bp * heads + hh;
+    const I ldv = (I)ldvt;
     if (q16) {
       f16x4 hv, lv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hv[e] = h; lv[e] = l; }
       if (which < 2) {
-        const int64_t off = (bh * sn + tokp) * dh + d;
+        const I off = mul_dh(bh * sn + tokp) + d;
         *reinterpret_cast<f16x4*>((which == 0 ? q16 : k16) + off) = hv;
         if (q16_lo) *reinterpret_cast<f16x4*>((which == 0 ? q16_lo : k16_lo) + off) = lv;
       } else {
-        const int64_t off = (bh * dh + d) * ldvt + tokp;
+        const I off = (mul_dh(bh) + d) * ldv + tokp;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          vt16[off + e * ldvt] = hv[e];
-          if (vt16_lo) vt16_lo[off + e * ldvt] = lv[e];
+          vt16[off + e * ldv] = hv[e];
+          if (vt16_lo) vt16_lo[off + e * ldv] = lv[e];
         }
       }
     } else {
       if (which < 2) {
-        float* dst = (which == 0 ? q32 : k32) + (bh * sn + tokp) * dh + d;
+        float* dst = (which == 0 ? q32 : k32) + (mul_dh(bh * sn + tokp) + d);
         *reinterpret_cast<float4*>(dst) = make_float4(x[0], x[1], x[2], x[3]);
       } else {
-        float* dst = vt32 + (bh * dh + d) * ldvt + tokp;
-        dst[0] = x[0]; dst[ldvt] = x[1]; dst[2 * ldvt] = x[2]; dst[3 * ldvt] = x[3];
+        float* dst = vt32 + ((mul_dh(bh) + d) * ldv + tokp);
+        dst[0] = x[0]; dst[ldv] = x[1]; dst[2 * ldv] = x[2]; dst[3 * ldv] = x[3];
       }
     }
   }
+
+  __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
+    const float4 b = *reinterpret_cast<const float4*>(bias + n);
+    float x[4] = {v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w};
+    if constexpr (FAST) {
+      const int which = (n >= inner_ ? 1 : 0) + (n >= 2 * inner_ ? 1 : 0);
+      const int c = n - (which == 0 ? 0 : which == 1 ? inner_ : 2 * inner_);
+      const int hh = c >> dh_shift, d = c & (dh - 1);
+      const int bp = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift), pos = m - bp * nseq;
+      store(which, hh, d, bp, pos, x);
+    } else {
+      const int inner = heads * dh;
+      const int which = n / inner;
+      const int c = n - which * inner;
+      const int hh = c / dh, d = c - hh * dh;
+      const int bp = m / nseq, pos = m - bp * nseq;
+      store(which, hh, d, bp, pos, x);
+    }
+  }
 };
+typedef EpiQKVT<false> EpiQKV;      // what the host code fills in
+typedef EpiQKVT<true> EpiQKVFast;   // same fields, same layout; launch_gemm_qkv converts when epi_qkv_prepare() accepts
+
+// Host side of the fast index path: fill the derived fields for a GEMM of M rows, or leave fast = 0 when a precondition fails.
+inline void epi_qkv_prepare(EpiQKV& e, int M) {
+  e.fast = 0;
+  const int dh = e.dh, nseq = e.nseq;
+  if (dh < 2 || (dh & (dh - 1)) || nseq < 2 || M <= 0 || e.heads <= 0) return;
+  const int64_t bp_max = (M + nseq - 1) / nseq, sn = e.slab_n ? e.slab_n : nseq;
+  const int64_t lim = (int64_t)1 << 31;
+  // largest offsets any store can form: the q / k slabs, the V^T slab (one row past the last channel for the e * ldvt steps), the rope table
+  if (bp_max * e.heads * sn * dh >= lim || (bp_max * e.heads * dh + 4) * e.ldvt + sn + e.pos_off >= lim || (int64_t)nseq * dh >= lim) return;
+  if ((int64_t)3 * e.heads * dh >= lim / 2) return;
+  int s = 0;
+  while (((int64_t)2 << s) <= nseq) ++s;  // s = floor(log2(nseq))
+  if (((int64_t)1 << s) == nseq) {        // power of two: mulhi(m, 2^31) = m >> 1
+    e.nseq_magic = 0x80000000u;
+    e.nseq_shift = s - 1;
+  } else {                                // ceil(2^(32+s) / nseq) lies in (2^31, 2^32); exact for every m < 2^31 (error term < nseq < 2^(s+1))
+    e.nseq_magic = (uint32_t)((((uint64_t)1 << (32 + s)) + (uint64_t)nseq - 1) / (uint64_t)nseq);
+    e.nseq_shift = s;
+  }
+  e.inner_ = e.heads * dh;
+  e.dh_shift = 0;
+  while ((1 << e.dh_shift) < dh) ++e.dh_shift;
+  e.fast = 1;
+}
 
 constexpr int GEMM_KTB = 128;  // bytes of one operand row per k-tile = one cache line
 

@@ -1,6 +1,7 @@
 // gemm.hip — instantiations and launch heuristics of the MFMA GEMM (gemm.h)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "kernels.h"
@@ -325,10 +326,24 @@ hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int b
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   return dispatch<EpiStore>(op, g, e, batch, variant, s);
 }
-hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s) { return dispatch<EpiQKV>(op, g, e, 1, -1, s); }
+hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e0, hipStream_t s) {
+  static const bool generic = getenv("F5HIP_QKV_EPI_GENERIC") != nullptr;  // A/B switch: the general (division / 64-bit) index path
+  EpiQKV e = e0;
+  e.fast = 0;
+  if (!generic) epi_qkv_prepare(e, g.M);  // fast = 1 when its preconditions hold
+  if (e.fast) {
+    static_assert(sizeof(EpiQKVFast) == sizeof(EpiQKV), "same fields");
+    EpiQKVFast f;
+    memcpy(&f, &e, sizeof(f));
+    return dispatch<EpiQKVFast>(op, g, f, 1, -1, s);
+  }
+  return dispatch<EpiQKV>(op, g, e, 1, -1, s);
+}
 
 hipError_t init_gemm_kernels() {
   hipError_t e = set_attrs_epi<EpiStore>();
   if (e != hipSuccess) return e;
-  return set_attrs_epi<EpiQKV>();
+  e = set_attrs_epi<EpiQKV>();
+  if (e != hipSuccess) return e;
+  return set_attrs_epi<EpiQKVFast>();
 }

@@ -554,3 +554,17 @@ def test_engine_on_the_shim_matches_the_oracle_and_the_experimental_switches_cha
             capfd.readouterr()
         for k in opts:
             eng.set_option(k, {"branch_streams": -1, "attn_kv_split": 1, "gemm_streamk_grid": 16}.get(k, 0))
+
+
+def test_qkv_epilogue_fast_index_path_equals_the_general_path(tmp_path):
+    """csrc/gemm.h EpiQKVFast (no integer divisions, 32-bit offsets: the default since the end of round 1) against EpiQKV (the path every GPU
+    parity run of round 1 used): tests/hipemu/qkv_index_check.cpp pushes every (row, 4-channel unit) of full-size QKV outputs through both
+    and compares the slabs byte for byte; plus the invariant-multiplier division exhaustively and the refusal cases."""
+    exe = str(tmp_path / "qkv_index_check")
+    csrc, emu = os.path.join(ROOT, "f5-tts_amd", "csrc"), os.path.join(ROOT, "tests", "hipemu")
+    r = subprocess.run([CLANG, "-x", "c++", "-std=c++20", "-O2", "-pthread", "-DF5_HIPEMU", "-I", emu, "-I", csrc, "-Wno-unknown-pragmas", "-Wno-pass-failed",
+                        "-Wno-psabi", os.path.join(emu, "qkv_index_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe] + (["big"] if os.environ.get("F5HIP_SHIM_FULL") == "1" else []), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all ok" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:]
+    assert r.stdout.count("byte-identical") >= 8
