@@ -29,6 +29,9 @@ timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
 # 3d. the bench as the driver runs it (--schedule auto: children probe the switches above, see config.schedule in the line) and the receiver-path first light
 timeout 900 python bench.py > $out/bench_b1_auto.json 2> $out/bench_b1_auto.err
 F5HIP_FIRST_LIGHT_GPU=1 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k receiver > $out/first_light_tests.log 2>&1; echo "first-light tests exit $?" | tee -a $out/summary.txt
+# 3e. what the static fixes of the end of round 1 bought: the QKV epilogue's general index path again (the conv-pos scratch fix has no switch:
+#     compare bench_b1.json's kernel_classes.convpos with profiles/r01f_bench_b1_fp16x3.json)
+F5HIP_QKV_EPI_GENERIC=1 timeout 600 python bench.py --schedule default --no-cpu-baseline > $out/bench_b1_qkv_generic.json 2> $out/bench_b1_qkv_generic.err
 # 4. the headline, unchanged code path (regression check of the header refactors: F5_DYN_LDS macro, split headers)
 timeout 600 python bench.py --schedule default > $out/bench_b1.json 2> $out/bench_b1.err
-cat $out/hipblaslt_ref.log; tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_kvsplit2.json $out/bench_b1_kvsplit3.json $out/bench_b1_sk42_kvsplit2.json $out/bench_b1_packed.json $out/bench_b1.json $out/bench_b1.json
+cat $out/hipblaslt_ref.log; tail -3 $out/bigvgan_tests.log; cat $out/skrs_check.log; cat $out/skrs_time.log; tail -3 $out/streamk_tests.log; cat $out/bench_e2_bigvgan_b8.json $out/bench_b1_sk42.json $out/bench_b1_sk43.json $out/bench_b1_sk42_generic_epi.json $out/bench_b1_sk42_split.json $out/bench_b1_kvsplit2.json $out/bench_b1_kvsplit3.json $out/bench_b1_sk42_kvsplit2.json $out/bench_b1_packed.json $out/bench_b1_auto.json $out/bench_b1_qkv_generic.json $out/bench_b1.json
