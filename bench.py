@@ -377,6 +377,15 @@ def main():
                    "schedule": schedule},
     }
     # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager pass -------
+    # The profiled pass is serial (one chain).  An adopted two-chain stream-K schedule would therefore run its PACKED form here: allowed only
+    # if that form itself verified in the probing child; otherwise this pass describes the default kernels and says so.
+    sel = schedule["selected"]
+    prof_sel = dict(sel)
+    if sel.get("gemm_streamk_split"):
+        packed = {"gemm_streamk": sel["gemm_streamk"]}
+        if not any(c.get("ok") and c.get("options") == packed for c in schedule.get("probe", {}).get("sk", {}).get("candidates", [])):
+            prof_sel = {k: v for k, v in sel.items() if not k.startswith("gemm_streamk") and k != "branch_streams"}
+            set_schedule(eng, prof_sel, a.branch_streams)
     eng.set_option("profile", 1)
     eng.reset_kernel_stats()
     if big:
@@ -397,7 +406,8 @@ def main():
     if g["calls"] and g["ms"] > 0:
         avg_s = 1e-3 * g["ms"] / g["calls"]
         ach = g["flops"] / g["calls"] / avg_s / 1e12
-        res["roofline"] = {"kernel": ("gemm_skrs_kernel, stream-K" if schedule["selected"].get("gemm_streamk") else "gemm_kernel") + " (DiT block QKV/out/FF1/FF2)", "bound": "mfma", "achieved": ach,
+        res["roofline"] = {"kernel": ("gemm_skrs_kernel, stream-K" if prof_sel.get("gemm_streamk") else "gemm_kernel") + " (DiT block QKV/out/FF1/FF2)"
+                                     + ("" if prof_sel == sel else " — the default kernels: the adopted two-chain stream-K schedule has no verified serial form to event-time"), "bound": "mfma", "achieved": ach,
                            "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE,
                            "traffic": None if schedule["selected"] else pmc_traffic(a, B), "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
                            "mfma_issue_tflops": ach * (3 if a.precision == "fp16x3" else 1),
