@@ -211,7 +211,7 @@ def probe_in_children(a, local):
         cmd = PROBE_CMD + (["--tiny"] if a.tiny else []) + (["--no-graph"] if a.no_graph else []) + ["--probe", group, "--probe-device", str(local), "--batch", str(a.batch), "--nfe", str(a.nfe),
                "--precision", a.precision, "--model", a.model, "--vocoder", a.vocoder, "--branch-streams", str(a.branch_streams), "--no-cpu-baseline"]
         try:
-            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=150)
+            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
             line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"probe"')), None)
             if line is None:
                 report[group] = {"error": f"child exit {r.returncode}: {(r.stdout + r.stderr)[-400:]}"}

@@ -9,6 +9,7 @@ blob is broadcast once (torch.distributed backend "nccl" == RCCL over xGMI on RO
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import List, Sequence, Tuple
 
@@ -28,7 +29,8 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # generous collective timeout: rank 0 may spend minutes between two collectives (checkpoint reading, bench.py's schedule probing)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
     return rank, local, world
 
 
