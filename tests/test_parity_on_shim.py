@@ -19,7 +19,8 @@ from test_hipemu import CLANG, engine_emu_lib, host_alias  # noqa: E402,F401  (t
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
 
-CASES = ["tiny_qknorm", "tiny_longskip", "tiny_avgup", "tiny_v1_midpoint", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2", "tiny_v1_nocfg_b2"]
+ALL_CASES = os.environ.get("F5HIP_SHIM_ALL_CASES") == "1"  # every tiny golden in both modes (~10 min): run once after touching a kernel
+CASES = sorted(G.MG.CASES) if ALL_CASES else ["tiny_qknorm", "tiny_longskip", "tiny_avgup", "tiny_v1_midpoint", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2", "tiny_v1_nocfg_b2"]
 
 
 @pytest.fixture(scope="module")
@@ -63,7 +64,7 @@ def shim_engines(engine_emu_lib):  # noqa: F811
 
 
 @pytest.mark.parametrize("name,prec,tol", [(n, "fp32", G.TIGHT) for n in CASES] +
-                         [(n, "fp16x3", G.X3TOL) for n in ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2")])
+                         [(n, "fp16x3", G.X3TOL) for n in (CASES if ALL_CASES else ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2"))])
 def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
     G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
 
