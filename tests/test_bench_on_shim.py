@@ -28,7 +28,7 @@ def run(cmd, lib, timeout=900, **extra_env):
 
 
 def check_probe_report(sched):
-    for group, n in (("sk", 4), ("kv", 3)):  # both children ran every candidate against the default path
+    for group, n in (("sk", 2), ("kv", 1)):  # both children ran their candidates (--tiny: a packed and a two-chain stream-K one, one key split)
         pr = sched["probe"][group]
         assert "error" not in pr and pr["default_ms"] > 0 and len(pr["candidates"]) == n
         for c in pr["candidates"]:

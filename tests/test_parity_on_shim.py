@@ -77,10 +77,11 @@ def test_mel_front_ends_on_the_shim(shim_engines):
 ENGINE_TESTS = ["test_bigvgan_mel_matches_reference_golden", "test_mel_too_short_raises", "test_text_longer_than_frames_and_unknown_ids",
                 "test_edit_mask_and_no_ref_audio", "test_vocos_decode_matches_oracle_golden", "test_vocos_batch_and_min_frames",
                 "test_flash_attention_equals_materialised_attention", "test_invalid_arguments_raise", "test_speech_edit_matches_oracle",
-                "test_all_padding_text_and_single_frame_prompt", "test_weight_blob_receiver_equals_the_rank_that_loaded",
-                "test_graph_replay_equals_eager"]  # stream capture is emulated by recording closures (tests/hipemu/hipemu.h GraphRec)
-if os.environ.get("F5HIP_SHIM_FULL") == "1":  # 15-25 s each on the shim; pass as well (the CPU suite keeps to a few minutes without them)
-    ENGINE_TESTS += ["test_bigvgan_type_sampler_and_glue", "test_text_embedding_and_velocity_taps", "test_determinism_and_batch_consistency"]
+                "test_all_padding_text_and_single_frame_prompt", "test_weight_blob_receiver_equals_the_rank_that_loaded"]
+if os.environ.get("F5HIP_SHIM_FULL") == "1":  # 15-80 s each on the shim; pass as well (the CPU suite keeps to a few minutes without them)
+    # test_graph_replay_equals_eager: stream capture is emulated by recording closures (tests/hipemu/hipemu.h GraphRec); the default suite
+    # covers the captured path through tests/test_bench_on_shim.py
+    ENGINE_TESTS += ["test_graph_replay_equals_eager", "test_bigvgan_type_sampler_and_glue", "test_text_embedding_and_velocity_taps", "test_determinism_and_batch_consistency"]
 
 
 @pytest.mark.parametrize("fn", ENGINE_TESTS)
