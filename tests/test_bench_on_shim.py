@@ -39,7 +39,7 @@ def check_probe_report(sched):
 
 @pytest.mark.skipif(os.environ.get("F5HIP_SHIM_FULL") != "1", reason="2 min on the shim; the two-rank test below covers the same code plus the rank protocol")
 def test_single_rank_with_schedule_probe(engine_emu_lib):  # noqa: F811
-    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib)
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib)
     assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
     check_probe_report(d["config"]["schedule"])
@@ -48,7 +48,7 @@ def test_single_rank_with_schedule_probe(engine_emu_lib):  # noqa: F811
 
 
 def test_default_schedule_flag_skips_the_probe(engine_emu_lib):  # noqa: F811
-    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "2", "--steps", "1", "--warmup", "0", "--schedule", "default"], engine_emu_lib)
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0", "--schedule", "default"], engine_emu_lib)
     assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
     assert d["config"]["schedule"] == {"selected": {}, "how": "default schedule"}
@@ -59,7 +59,7 @@ def test_default_schedule_flag_skips_the_probe(engine_emu_lib):  # noqa: F811
 def test_two_ranks_under_torch_distributed_run(engine_emu_lib):  # noqa: F811
     port = 29911 + (os.getpid() % 80)
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-             HARNESS, "--gpus", "2", "--tiny", "--nfe", "2", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200,
+             HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200,
             F5HIP_BENCH_ADOPT_RATIO="100")  # timing on the shim is noise: adopt whatever verifies, so that the adoption path runs too
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
     assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim) while the probe flips schedules
