@@ -37,6 +37,30 @@ thread_local std::string g_create_err;
     if (_r != F5HIP_OK) return _r;  \
   } while (0)
 
+// typed pinned staging of the current call (engine.h HostStage): the queued copy reads it after the entry point returned
+template <typename T>
+T* stage(f5hip_ctx* ctx, size_t n) { return reinterpret_cast<T*>(ctx->stage.alloc(n * sizeof(T))); }
+#define STAGE(T, var, n)                                                    \
+  T* var = stage<T>(ctx, (n));                                              \
+  if (!var) FAIL(F5HIP_ERR_HIP, "pinned staging allocation of %zu bytes failed", (size_t)(n) * sizeof(T))
+
+// Every entry point that enqueues work calls this first: device, the staging slot of this call, and — the workspace being one per context —
+// a GPU-side wait for the previous call's work when this call arrives on a different stream (no host wait in either case).
+int call_begin(f5hip_ctx* ctx, hipStream_t st) {
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(ctx->stage.begin());
+  if (ctx->have_last && ctx->last_stream != st) HIPCHK(hipStreamWaitEvent(st, ctx->ev_last, 0));
+  return F5HIP_OK;
+}
+int call_end(f5hip_ctx* ctx, hipStream_t st) {
+  HIPCHK(ctx->stage.end(st));
+  if (!ctx->ev_last) HIPCHK(hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ctx->ev_last, st));
+  ctx->last_stream = st;
+  ctx->have_last = true;
+  return F5HIP_OK;
+}
+
 int add_slot(f5hip_ctx* ctx, const std::string& name, int64_t numel, bool optional = false) {
   Slot s;
   s.name = name;
@@ -299,18 +323,6 @@ GemmCore core(const void* A, int64_t lda, const void* Wt, int64_t ldw, int M, in
   g.A = A; g.A_lo = nullptr; g.W = Wt; g.W_lo = nullptr;
   g.lda = lda; g.ldw = ldw; g.strideA = 0; g.strideW = 0;
   g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
-  return g;
-}
-// stream-K (option "gemm_streamk"): hand the launch heuristic the context's workspace; it falls back to the plain tiling when the shape
-// does not suit the schedule.  Only for launches that have the GPU to themselves (the packed schedule on one stream).
-constexpr int SK_GRID = 256;  // one 144 KB workgroup per CU; the two-chain schedule gives each chain half (its own half of the workspace)
-constexpr size_t SK_WS_BYTES = (size_t)SK_GRID * 2 * 131072 + ((size_t)SK_GRID * 2 + 4) * sizeof(int);
-GemmCore sk_attach(f5hip_ctx* ctx, GemmCore g) {
-  if (ctx->sk_now) {
-    g.sk_ws = ctx->sk_ws.as<char>() + (ctx->sk_chain > 0 ? SK_WS_BYTES : 0);
-    g.sk_grid = ctx->sk_chain >= 0 ? ctx->sk_grid / 2 : ctx->sk_grid;
-    g.sk_variant = ctx->gemm_sk;
-  }
   return g;
 }
 EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_NONE) {
@@ -608,9 +620,14 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
   const float* t = te;
   HIPCHK(ctx->dt_dev.ensure(std::max(steps, 64) * sizeof(float)));
   HIPCHK(ctx->cfg_dev.ensure(16));
-  HIPCHK(hipMemcpyAsync(ctx->dt_dev.p, coef, steps * sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->cfg_dev.p, &cfg_strength, sizeof(float), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // coef / cfg may be temporaries of the caller
+  {  // coef / cfg / the time grid are temporaries of the caller: staged in pinned memory, copied by the stream
+    STAGE(float, hc, (size_t)steps + 1);
+    memcpy(hc, coef, steps * sizeof(float));
+    hc[steps] = cfg_strength;
+    HIPCHK(hipMemcpyAsync(ctx->dt_dev.p, hc, steps * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->cfg_dev.p, hc + steps, sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  // the tables below depend on the grid AND on the weights: t_host is cleared whenever a weight changes (invalidate_weight_caches)
   const bool same = (int)ctx->t_host.size() == steps && memcmp(ctx->t_host.data(), t, steps * sizeof(float)) == 0;
   if (same) return F5HIP_OK;
   bool moved = false;
@@ -628,7 +645,11 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
   }
   if (moved) ctx->ws_epoch++;
   ctx->t_host.assign(t, t + steps);
-  HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ctx->t_host.data(), steps * sizeof(float), hipMemcpyHostToDevice, st));
+  {
+    STAGE(float, ht, (size_t)steps);
+    memcpy(ht, t, steps * sizeof(float));
+    HIPCHK(hipMemcpyAsync(ctx->t_dev.p, ht, steps * sizeof(float), hipMemcpyHostToDevice, st));
+  }
   {
     Prof pr(ctx, st, KC_GEMM_MISC, 0, 0);
     HIPCHK(launch_time_sinus(ctx->t_dev.as<float>(), steps, 256, ctx->tsin.as<float>(), st));
@@ -657,10 +678,6 @@ int prepare_time(f5hip_ctx* ctx, const float* te, const float* coef, int steps, 
 
 // ---- workspace -----------------------------------------------------------------------------------
 int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_attn) {
-  if (ctx->gemm_sk && !ctx->sk_ws.p) {  // stream-K workspace: [grid][2] slots of 128 KB + [grid][2] flags + error word, zeroed once (the
-                                        // flags clean themselves: gemm_skrs.h)
-    HIPCHK(ctx->sk_ws.ensure(2 * SK_WS_BYTES, nullptr, true));  // one per kernel chain
-  }
   const auto& c = ctx->cfg;
   const int64_t D = c.dim, T = c.text_dim, mel = c.mel_dim, inner = (int64_t)c.heads * c.dim_head, F = c.ff_inner;
   const bool unett = c.backbone == 1, mmdit = c.backbone == 2;
@@ -727,8 +744,11 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
   const auto& c = ctx->cfg;
   const int T = c.text_dim;
   const int64_t BN = (int64_t)B * n, M = 2 * BN;
-  std::vector<int32_t> tok(BN), avg(c.text_average_upsampling ? BN : 0, -1);
-  std::vector<uint8_t> valid(BN), keep(M);
+  STAGE(int32_t, tok, (size_t)BN);
+  STAGE(int32_t, avg, (size_t)(c.text_average_upsampling ? BN : 1));
+  STAGE(uint8_t, valid, (size_t)BN);
+  STAGE(uint8_t, keep, (size_t)M);
+  if (c.text_average_upsampling) std::fill(avg, avg + BN, -1);
   std::vector<int32_t> vpos;
   for (int b = 0; b < B; ++b) {
     // DiT: per-sample valid length when a mask is passed (dit.py:295-298); UNetT: the padded frame count for every sample (unett.py:218-228)
@@ -759,11 +779,10 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
       }
     }
   }
-  if (c.text_average_upsampling) HIPCHK(hipMemcpyAsync(ctx->avgidx.p, avg.data(), BN * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok.data(), BN * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BN, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->textkeep.p, keep.data(), M, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  if (c.text_average_upsampling) HIPCHK(hipMemcpyAsync(ctx->avgidx.p, avg, BN * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok, BN * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid, BN, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->textkeep.p, keep, M, hipMemcpyHostToDevice, st));
   // algorithmic traffic of the text encoder (per ConvNeXtV2 block read x + write out + write h + read h, h = 2x) and
   // its pointwise-GEMM FLOPs, all inside this one scope
   const double x_elems = (double)M * T;
@@ -868,7 +887,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = sk_attach(ctx, core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
+    GemmCore g = (core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -899,10 +918,6 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   const float* cconst = ctx->cconst.as<float>() + r0 * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int npl = op == OP_F16X3 ? 3 : 1;
-  // stream-K only for launches whose workgroups can all be resident: the packed chain alone (grid 256), or — option "gemm_streamk_split" —
-  // the two concurrent chains with half the CUs each (grid 128 + 128).  Workspace: ensure_workspace (never inside a capture).
-  ctx->sk_now = ctx->gemm_sk != 0 && (br < 0 || ctx->gemm_sk_split) && op != OP_F32 && ctx->sk_ws.p;
-  ctx->sk_chain = br;
 
   {  // InputEmbedding.proj: only the x columns are per-step (dit.py:162); cond/text part is in cconst
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(BN, D, mel), 0);
@@ -962,7 +977,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = sk_attach(ctx, core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
+      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -973,14 +988,14 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = sk_attach(ctx, core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
+      GemmCore g = (core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = sk_attach(ctx, core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
+      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -1005,7 +1020,6 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     GemmCore g = core(A, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
     HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>() + r0 * mel, mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
-  ctx->sk_now = false;
   if (br < 0) {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
     Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
     HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
@@ -1161,18 +1175,19 @@ int run_text_embed_mmdit(f5hip_ctx* ctx, int B, int nt, const int64_t* text, hip
   const auto& c = ctx->cfg;
   const int64_t BT = (int64_t)B * nt;
   if (nt > 8192) FAIL(F5HIP_ERR_INVALID, "nt=%d exceeds the 8192-row text position table", nt);
-  std::vector<int32_t> tok(BT);
-  std::vector<uint8_t> valid(BT, 1), cm(2 * BT);
+  STAGE(int32_t, tok, (size_t)BT);
+  STAGE(uint8_t, valid, (size_t)BT);
+  STAGE(uint8_t, cm, (size_t)2 * BT);
+  memset(valid, 1, BT);
   for (int64_t i = 0; i < BT; ++i) {
     const int64_t id = text[i] + 1;  // 0 = filler / batch padding (mmdit.py:44)
     if (id < 0 || id > c.text_num_embeds) FAIL(F5HIP_ERR_INVALID, "text id %lld out of range at %lld", (long long)(id - 1), (long long)i);
     tok[i] = (int32_t)id;
     cm[i] = cm[BT + i] = id != 0;  // c_mask (mmdit.py:232)
   }
-  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok.data(), BT * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid.data(), BT, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->cmask.p, cm.data(), 2 * BT, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  HIPCHK(hipMemcpyAsync(ctx->tok.p, tok, BT * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->valid.p, valid, BT, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ctx->cmask.p, cm, 2 * BT, hipMemcpyHostToDevice, st));
   Prof pr(ctx, st, KC_TEXT, 0, 2.0 * BT * c.dim * 4.0 * 2);
   HIPCHK(launch_text_embed(ctx->tok.as<int32_t>(), ctx->valid.as<uint8_t>(), W(ctx, "transformer.text_embed.text_embed.weight"),
                            ctx->freqs_cis.as<float>(), B, nt, c.dim, c.text_mask_padding, 1, ctx->ctext0.as<float>(), st));
@@ -1352,7 +1367,7 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (!ctx->gemm_sk || ctx->gemm_sk_split) && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
+  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1452,8 +1467,10 @@ int f5hip_destroy(f5hip_ctx* ctx) {
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
-                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->sk_ws, &ctx->attn_part};
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->attn_part};
   for (DevBuf* b : bufs) b->release();
+  ctx->stage.release();
+  if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
   if (ctx->blob) (void)hipFree(ctx->blob);
   delete ctx;
   return F5HIP_OK;
@@ -1469,6 +1486,15 @@ int f5hip_tensor_info(const f5hip_ctx* ctx, int i, const char** name, int64_t* n
   return F5HIP_OK;
 }
 
+// Everything derived from the weights that is cached across calls: the per-step time-embedding / AdaLN tables are keyed on the time grid
+// (prepare_time) and must not survive a weight change, and a captured graph holds no weight-derived pointer that moves, but is dropped with
+// them for good measure.
+static void invalidate_weight_caches(f5hip_ctx* ctx) {
+  ctx->finalized = false;
+  ctx->t_host.clear();
+  ctx->ws_epoch++;
+}
+
 int f5hip_load_tensor(f5hip_ctx* ctx, const char* name, const float* data, int64_t numel) {
   if (!ctx || !name || !data) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1479,7 +1505,7 @@ int f5hip_load_tensor(f5hip_ctx* ctx, const char* name, const float* data, int64
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpy(ctx->blob + s.offset, data, numel * sizeof(float), hipMemcpyHostToDevice));
   s.loaded = true;
-  ctx->finalized = false;
+  invalidate_weight_caches(ctx);
   return F5HIP_OK;
 }
 
@@ -1495,7 +1521,7 @@ int f5hip_mark_all_loaded(f5hip_ctx* ctx) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   for (auto& s : ctx->slots)
     if (!s.optional) s.loaded = true;
-  ctx->finalized = false;
+  invalidate_weight_caches(ctx);
   return F5HIP_OK;
 }
 
@@ -1512,7 +1538,7 @@ int f5hip_set_loaded_mask(f5hip_ctx* ctx, const uint8_t* mask, int n) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (n != (int)ctx->slots.size()) FAIL(F5HIP_ERR_INVALID, "loaded mask: %d entries for %d tensors", n, (int)ctx->slots.size());
   for (int i = 0; i < n; ++i) ctx->slots[i].loaded = mask[i] != 0;
-  ctx->finalized = false;
+  invalidate_weight_caches(ctx);
   return F5HIP_OK;
 }
 
@@ -1520,6 +1546,8 @@ int f5hip_finalize_weights(f5hip_ctx* ctx) {
   if (!ctx) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCHK(hipSetDevice(ctx->device));
+  ctx->t_host.clear();  // the blob may have been written directly (f5hip_weight_blob: the RCCL receive path)
+  ctx->ws_epoch++;
   return finalize_impl(ctx);
 }
 
@@ -1531,22 +1559,11 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "profile") ctx->profile = value != 0;
   else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
   else if (k == "branch_streams") { ctx->branch_streams = (int)value; ctx->ws_epoch++; }
-  else if (k == "gemm_streamk") {  // 0 = off; 42 / 43 = the DiT block GEMMs of the PACKED schedule through gemm_skrs.h (256x128 / 128x256 tiles)
-    if (value != 0 && value != 42 && value != 43) FAIL(F5HIP_ERR_INVALID, "gemm_streamk must be 0, 42 or 43");
-    ctx->gemm_sk = (int)value;
-    ctx->ws_epoch++;
-  }
   else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
     if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
     ctx->attn_kv_split = (int)value;
     ctx->ws_epoch++;
   }
-  else if (k == "gemm_streamk_grid") {  // resident workgroups the stream-K launches spread over (default: one per CU)
-    if (value < 16 || value > SK_GRID || value % 16) FAIL(F5HIP_ERR_INVALID, "gemm_streamk_grid must be a multiple of 16 in [16, %d]", SK_GRID);
-    ctx->sk_grid = (int)value;
-    ctx->ws_epoch++;
-  }
-  else if (k == "gemm_streamk_split") { ctx->gemm_sk_split = value != 0; ctx->ws_epoch++; }  // stream-K also under the two-chain schedule
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
   return F5HIP_OK;
 }
@@ -1579,14 +1596,15 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float*
   if (nsamp < pad + 1) FAIL(F5HIP_ERR_INVALID, "reflect padding needs more than %d samples (got %lld)", pad, (long long)nsamp);
   const int frames = mel_type == 1 ? (int)((nsamp + 2 * pad - 1024) / 256) + 1 : 1 + (int)(nsamp / 256);
   if (frames <= 0) FAIL(F5HIP_ERR_INVALID, "wave of %lld samples is shorter than one frame", (long long)nsamp);
-  HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  CHK(call_begin(ctx, st));
   {
     Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
     HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(),
                       mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(), ctx->cfg.mel_dim, frame_major, pad,
                       mel_type == 1 ? 1e-9f : 0.f, out, st));
   }
+  CHK(call_end(ctx, st));
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1605,8 +1623,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
   for (int b = 0; b < B; ++b)
     if (duration[b] <= 0 || duration[b] > n) FAIL(F5HIP_ERR_INVALID, "duration[%d]=%lld outside (0, n=%d]", b, (long long)duration[b], n);
-  HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  CHK(call_begin(ctx, st));
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
   // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 modes -> flash with the mode's operands), 1 force materialised,
@@ -1637,15 +1655,17 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     // rows of the backbone's token sequences: UNetT prepends the (always valid) time token (unett.py:272-274)
     const int tok0 = c.backbone == 1 ? 1 : 0, ns = n + tok0;
     const int64_t BNs = (int64_t)B * ns;
-    std::vector<uint8_t> rv(2 * BNs);
-    std::vector<int32_t> kv(2 * B);
+    STAGE(uint8_t, rv, (size_t)2 * BNs);
+    STAGE(int32_t, kv, (size_t)2 * B);
+    STAGE(int32_t, kv2, (size_t)2 * B);
+    STAGE(uint8_t, cmk, (size_t)BN);
     for (int b = 0; b < B; ++b) {
       for (int r = 0; r < ns; ++r) rv[(int64_t)b * ns + r] = rv[BNs + (int64_t)b * ns + r] = (r < tok0 || r - tok0 < duration[b]) ? 1 : 0;
       kv[b] = kv[B + b] = (int32_t)duration[b] + tok0;
     }
-    HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv.data(), 2 * BNs, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->kvlen.p, kv.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
-    std::vector<int32_t> kv2(2 * B, 0);
+    HIPCHK(hipMemcpyAsync(ctx->rowvalid.p, rv, 2 * BNs, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->kvlen.p, kv, 2 * B * 4, hipMemcpyHostToDevice, st));
+    std::fill(kv2, kv2 + 2 * B, 0);
     if (c.backbone == 2) {  // MMDiT joint key mask = cat(audio mask, c_mask) (modules.py:643-648): the valid text tokens as a second run
       for (int b = 0; b < B; ++b) {
         int len = 0;
@@ -1656,10 +1676,10 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
               FAIL(F5HIP_ERR_UNSUPPORTED, "MMDiT with attn_mask_enabled: padding (-1) inside the text of sample %d (only trailing padding is built)", b);
         kv2[b] = kv2[B + b] = len;
       }
-      HIPCHK(hipMemcpyAsync(ctx->kvlen2.p, kv2.data(), 2 * B * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->kvlen2.p, kv2, 2 * B * 4, hipMemcpyHostToDevice, st));
     }
-    HIPCHK(hipMemcpyAsync(ctx->condmask.p, cond_mask, BN, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    memcpy(cmk, cond_mask, BN);  // cond_mask is a HOST array of the caller (include/f5hip.h): staged like the rest
+    HIPCHK(hipMemcpyAsync(ctx->condmask.p, cmk, BN, hipMemcpyHostToDevice, st));
   }
   {
     Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
@@ -1743,6 +1763,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   }
   ctx->last_B = B;
   ctx->last_n = n;
+  CHK(call_end(ctx, st));
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1775,8 +1796,8 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
   if (!ctx->has_vocos) FAIL(F5HIP_ERR_STATE, "context was created without a vocoder config");
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
   if (B <= 0 || T < 2) FAIL(F5HIP_ERR_INVALID, "vocos decode needs batch > 0 and frames >= 2");
-  HIPCHK(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  CHK(call_begin(ctx, st));
   const auto& v = ctx->vcfg;
   const int C = v.dim, I = v.intermediate_dim, Cin = v.input_channels;
   const int64_t R = (int64_t)B * T;
@@ -1832,6 +1853,25 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
     HIPCHK(launch_istft_frames(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
     HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
   }
+  CHK(call_end(ctx, st));
+  collect_prof(ctx, st);
+  return F5HIP_OK;
+}
+
+int f5hip_istft(f5hip_ctx* ctx, const float* logits, int64_t ld, int B, int T, float* out, void* stream) {
+  if (!ctx || !logits || !out) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised (the twiddle / window tables are built there)");
+  if (B <= 0 || T < 2 || ld < 1026 || (ld & 3)) FAIL(F5HIP_ERR_INVALID, "istft needs batch > 0, frames >= 2, ld >= 1026 and ld %% 4 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(call_begin(ctx, st));
+  HIPCHK(ctx->vframes.ensure((size_t)B * T * 1024 * 4));
+  {
+    Prof pr(ctx, st, KC_ISTFT, 0, (double)B * T * ld * 4 + 2.0 * B * T * 1024 * 4 + (double)B * 256.0 * (T - 1) * 4);
+    HIPCHK(launch_istft_frames(logits, ld, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
+    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
+  }
+  CHK(call_end(ctx, st));
   collect_prof(ctx, st);
   return F5HIP_OK;
 }

@@ -50,6 +50,63 @@ struct DevBuf {
   }
 };
 
+// Pinned, context-owned staging for small host inputs (masks, token ids, time tables) that a QUEUED copy reads after the entry point has
+// returned: the boundary enqueues and returns (include/f5hip.h), so nothing on the call path may wait for the stream.  A ring of slots, one per
+// call in flight; a slot is reused only after the event recorded behind its call's last copy has completed (blocks the host only when
+// RING calls are outstanding).
+struct HostStage {
+  static constexpr int RING = 4;
+  struct Chunk { char* p = nullptr; size_t cap = 0, used = 0; };
+  struct SlotS {
+    std::vector<Chunk> chunks;
+    hipEvent_t done = nullptr;
+    bool recorded = false;  // an event is pending behind this slot's copies
+    bool open = false;      // begin() without end(): an error path left copies queued without an event
+  } slot[RING];
+  int cur = -1;
+  hipError_t begin() {
+    cur = (cur + 1) % RING;
+    SlotS& s = slot[cur];
+    hipError_t e = hipSuccess;
+    if (s.open) e = hipDeviceSynchronize();
+    else if (s.recorded) e = hipEventSynchronize(s.done);
+    if (e != hipSuccess) return e;
+    s.recorded = false;
+    s.open = true;
+    for (auto& c : s.chunks) c.used = 0;
+    return hipSuccess;
+  }
+  void* alloc(size_t bytes) {
+    SlotS& s = slot[cur];
+    bytes = (bytes + 63) & ~size_t(63);
+    for (auto& c : s.chunks)
+      if (c.cap - c.used >= bytes) { void* r = c.p + c.used; c.used += bytes; return r; }
+    Chunk c;
+    c.cap = bytes > (size_t(1) << 20) ? bytes : (size_t(1) << 20);
+    if (hipHostMalloc(reinterpret_cast<void**>(&c.p), c.cap, 0) != hipSuccess) return nullptr;
+    c.used = bytes;
+    s.chunks.push_back(c);
+    return c.p;
+  }
+  hipError_t end(hipStream_t st) {
+    SlotS& s = slot[cur];
+    if (!s.done) { hipError_t e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(s.done, st);
+    if (e != hipSuccess) return e;
+    s.recorded = true;
+    s.open = false;
+    return hipSuccess;
+  }
+  void release() {
+    for (auto& s : slot) {
+      for (auto& c : s.chunks) (void)hipHostFree(c.p);
+      s.chunks.clear();
+      if (s.done) (void)hipEventDestroy(s.done);
+      s.done = nullptr;
+    }
+  }
+};
+
 struct BlockW {  // per DiT block
   const float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2;  // fp32 (blob)
   f16 *wqkv_hi, *wo_hi, *w1_hi, *w2_hi;  // plain fp16 rows [N, K]             (precision FP16)
@@ -177,16 +234,14 @@ struct f5hip_ctx {
   } graph_key;
   uint64_t ws_epoch = 0;
   hipStream_t cap_stream = nullptr;
-  // option "gemm_streamk": 0 off, 42 / 43 = DiT block GEMMs of the packed schedule through gemm_skrs.h; sk_now = set while run_step
-  // enqueues launches that have the GPU to themselves; sk_ws = its workspace (slots + self-cleaning flags)
   int attn_kv_split = 1;       // option "attn_kv_split": key ranges per query block in the flash kernel (1 = off); attn_part = its scratch
   DevBuf attn_part;
-  int gemm_sk = 0;
-  bool gemm_sk_split = false;  // allow it under the two-chain schedule too (each chain: half the grid, its own workspace half)
-  int sk_grid = 256;           // option "gemm_streamk_grid"
-  bool sk_now = false;
-  int sk_chain = -1;           // the chain run_step is enqueueing (-1 packed, 0 / 1 cond / uncond)
-  DevBuf sk_ws;
+  // host inputs of queued copies (the entry points never wait for the stream) and the ordering of calls that arrive on different streams:
+  // the workspace is one per context, so a call on a new stream first waits (on the GPU, not the host) for the previous call's work
+  HostStage stage;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev_last = nullptr;
+  bool have_last = false;
   // cond / uncond branches on two streams (small batches): -1 auto, 0 off, 1 on
   int branch_streams = -1;
   hipStream_t side_stream = nullptr;

@@ -25,12 +25,8 @@ struct GemmCore {
   int M, N, K;
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
   int w_rows;         // rows of W that exist (<= N)
+  int sk_exp;         // experiment switches (tools only)
   int group_m;        // tile rasterisation: row-tiles per group (0/1 = channel tiles fastest over the whole grid), see gemm_kernel
-  // stream-K schedule for small grids (gemm_sk.h): workspace of sk_grid x 128 KB partial-tile slots followed by sk_grid + 1 ints
-  // (flags, error word), owned by the caller and private to one stream; null = plain tiled launch only
-  void* sk_ws;
-  int sk_grid;        // resident workgroups to spread the work over (multiple of 8)
-  int sk_variant;     // which stream-K kernel the launch heuristic should try when sk_ws is set (0 = none; 42 / 43 = gemm_skrs.h)
 };
 
 // Generic store epilogue:
@@ -102,42 +98,6 @@ struct EpiStore {
       *reinterpret_cast<f16x4*>(out16 + o16) = hi;
       if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o16) = lo;
     }
-  }
-};
-
-// Specialised store epilogues: the two shapes the DiT block GEMMs use, with everything that EpiStore decides at run time (activation
-// switch, optional pointers, output kinds) fixed at compile time — no scalar branches between the VALU ops of an element.  Bit for bit
-// the arithmetic of EpiStore for the same configuration (tests/test_hipemu.py runs both).  Used by the stream-K kernel (gemm_skrs.h),
-// whose epilogue is not hidden behind other workgroups' main loops; gemm.hip converts a matching EpiStore.
-struct EpiFF1 {       // FeedForward first linear: tanh-GELU(acc + bias) -> the packed fp16 hi/lo operand rows of the second linear
-  const float* bias;
-  f16* out16;         // [M, ldo16] packed: [N/32][32 hi | 32 lo]
-  int64_t ldo16;
-  __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-    const float x[4] = {act_gelu_tanh(v.x + b.x), act_gelu_tanh(v.y + b.y), act_gelu_tanh(v.z + b.z), act_gelu_tanh(v.w + b.w)};
-    f16x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(x[e], h, l); hi[e] = h; lo[e] = l; }
-    f16* o = out16 + (int64_t)m * ldo16 + pk_off(n, 1);
-    *reinterpret_cast<f16x4*>(o) = hi;
-    *reinterpret_cast<f16x4*>(o + 32) = lo;
-  }
-};
-struct EpiGateRes {   // attention out-projection / FeedForward second linear: x[m, n] += gate[n] * (acc + bias[n]); masked rows add 0
-  const float* bias;
-  const float* gate;
-  const uint8_t* rowmask;  // or null
-  float* x;
-  int64_t ldx;
-  __device__ __forceinline__ void operator()(int m, int n, float4 v, int /*z*/) const {
-    const float4 b = *reinterpret_cast<const float4*>(bias + n);
-    const float4 c = *reinterpret_cast<const float4*>(gate + n);
-    float y[4] = {(v.x + b.x) * c.x, (v.y + b.y) * c.y, (v.z + b.z) * c.z, (v.w + b.w) * c.w};
-    if (rowmask && !rowmask[m]) { y[0] = y[1] = y[2] = y[3] = 0.f; }
-    float4* p = reinterpret_cast<float4*>(x + (int64_t)m * ldx + n);
-    const float4 r = *p;
-    *p = make_float4(y[0] + r.x, y[1] + r.y, y[2] + r.z, y[3] + r.w);
   }
 };
 

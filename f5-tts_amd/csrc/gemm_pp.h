@@ -1,0 +1,523 @@
+// gemm_pp.h — the pipelined MFMA GEMM of the DiT / UNetT block projections:  epilogue( A[M,K] . W[N,K]^T ),  fp16 or fp16x3 operands.
+//
+// What round 1's counters said about gemm.h's kernels at these shapes (profiles/r02a_*): the 4-wave 128x64 workgroup reads 1 KB of LDS
+// fragments per MFMA and stages through VGPRs with ds_write_b128 (79 B/clk/CU) — more LDS cycles than MFMA cycles per k-tile; its waves
+// sit in s_waitcnt / s_barrier 34-45 % of their time and a fifth of every launch is an epilogue that pays one L2 round trip and 2-8
+// narrow stores per 4 outputs.  This kernel is built the other way round:
+//   * k-tiles (one 128-byte line per operand row, the layout of gemm.h) arrive by LDS-DMA (`buffer_load ... lds`) into a ring of NS
+//     stages; the k offset rides in the instruction's scalar offset, so the loop has no per-lane address arithmetic;
+//   * ONE s_barrier per k-tile, placed before the tile's LAST MFMA group: by then every wave has issued and retired all its fragment
+//     reads of the tile, so the stage is refilled right behind the barrier (tile t+NS) and the next tile's first fragments are read
+//     under the last MFMA group — neither the barrier, nor the DMA wait (counted vmcnt: NS-2 tiles stay in flight across it), nor the
+//     first ds_reads of a tile are exposed;
+//   * fragments are double-buffered per "slot" (JG activation tiles x all weight tiles of one 16-wide k-step), so LDS latency hides
+//     behind the previous slot's MFMAs with 48-64 fragment VGPRs instead of 96;
+//   * wave tiles up to 128x64 / 96x96 (0.5-0.67 KB of fragments per MFMA), workgroup tiles chosen so that a launch is a whole number
+//     of rounds of the 256 CUs (192-row tiles at B = 1: 15 x 16 = 240 workgroups);
+//   * epilogues work on a whole wave tile: bias / gate / rope operands are fetched up front, rows outside M are dropped by the buffer
+//     descriptor (no branches), outputs leave as 16-byte stores (v_permlane32_swap pairs the two half-waves' 4-channel groups).
+// Fragment and accumulator layouts are those of gemm.h (weights on the MFMA "A" side: a lane owns 4 consecutive channels of one row).
+#pragma once
+#include <utility>
+
+#include "gemm.h"
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (indices usable as immediates / template arguments)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+// ---- primitives: amdgcn instructions on the GPU, plain memory operations under the host shim (tests/hipemu) ------------------------
+namespace pp {
+#ifdef F5_HIPEMU
+template <int N>
+inline void wait_vmcnt() {}  // the shim's LDS-DMA is synchronous (what it CAN show: a refill racing the reads of the stage it overwrites)
+inline void wg_barrier() { __syncthreads(); }
+inline uint32_t lds_base(char*) { return 0; }
+template <int IMM>
+inline uint4 lds_read_b128(uint32_t addr) { uint4 v; memcpy(&v, hipemu::dyn_lds() + addr + IMM, 16); return v; }
+inline void lds_wait() {}
+inline void dma_b128(BufRsrc r, char* lds_dst, uint32_t voff, uint32_t soff) {  // each lane: 16 bytes -> lds_dst + lane * 16
+  const auto v = hipemu::raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  memcpy(lds_dst + 16 * hipemu::blk->cur->lane, &v, 16);
+}
+inline int uniform(int v) { return v; }
+inline void pin() {}
+inline void swap32(uint32_t& a, uint32_t& b) { hipemu::permlane32_swap(a, b); }
+inline uint32_t xchg1(uint32_t v) { return hipemu::shfl_xor_u32(v, 1); }
+inline void store_b128(BufRsrc r, uint32_t off, uint4 v) { hipemu::raw_buffer_store(r, off, &v, 16); }
+inline void store_b32(BufRsrc r, uint32_t off, uint32_t v) { hipemu::raw_buffer_store(r, off, &v, 4); }
+inline void store_b16(BufRsrc r, uint32_t off, uint16_t v) { hipemu::raw_buffer_store(r, off, &v, 2); }
+#else
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t lds_base(char* smem) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem; }
+// inline asm: hipcc drains vmcnt(0) before any ds_read it can see while an LDS-DMA is in flight (it cannot prove they do not alias)
+template <int IMM>
+__device__ __forceinline__ uint4 lds_read_b128(uint32_t addr) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_wait() {  // every fragment read issued so far has landed; nothing may be scheduled across
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void dma_b128(BufRsrc r, char* lds_dst, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }  // nothing is scheduled across this point
+// half exchange: lanes 32-63 of a swap with lanes 0-31 of b (v_permlane32_swap)
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ uint32_t xchg1(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }  // neighbour lane (a DPP quad_perm move)
+__device__ __forceinline__ void store_b128(BufRsrc r, uint32_t off, uint4 v) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 d = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void store_b32(BufRsrc r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
+__device__ __forceinline__ void store_b16(BufRsrc r, uint32_t off, uint16_t v) { __builtin_amdgcn_raw_buffer_store_b16(v, r, (int)off, 0, 0); }
+#endif
+
+__device__ __forceinline__ uint32_t pack2(f16 a, f16 b) {
+  union { f16 h[2]; uint32_t u; } x;
+  x.h[0] = a;
+  x.h[1] = b;
+  return x.u;
+}
+// 4 floats -> 4 halves (hi) and the 4 halves of the remainders (lo), each as two packed dwords
+__device__ __forceinline__ void split4(const float (&x)[4], uint32_t (&hi)[2], uint32_t (&lo)[2]) {
+  f16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split_f16(x[e], h[e], l[e]);
+  hi[0] = pack2(h[0], h[1]); hi[1] = pack2(h[2], h[3]);
+  lo[0] = pack2(l[0], l[1]); lo[1] = pack2(l[2], l[3]);
+}
+// The four register quads q = 0..3 of a 32x32 accumulator tile hold, per lane, channels 8q + 4h + 0..3 (h = lane >> 5) of one row.
+// After swapping quads (2p, 2p+1) between the half-waves, lanes 0-31 hold channels 16p + 0..7 and lanes 32-63 channels 16p + 8..15
+// as {a[0], a[1], b[0], b[1]}: one 16-byte store per pair instead of two 8-byte ones.
+__device__ __forceinline__ uint4 widen(uint32_t (&a)[2], uint32_t (&b)[2]) {
+  swap32(a[0], b[0]);
+  swap32(a[1], b[1]);
+  return make_uint4(a[0], a[1], b[0], b[1]);
+}
+}  // namespace pp
+
+// ---- wave-tile epilogues ------------------------------------------------------------------------------------------------------------
+// tile<TM, TN>(acc, m_w, n_w, lane): the wave's accumulators cover rows m_w + 32 j + (lane & 31), channels n_w + 32 i + 8 q + 4 (lane >> 5)
+// + 0..3 (acc[j][i][4 q + e]).  Rows >= M and channels >= N fall outside the buffer descriptors / are skipped per 32-channel tile.
+
+// FeedForward first linear (modules.py:353-364): tanh-GELU(acc + bias) -> the operand rows of the second linear, packed hi/lo (PK) or plain fp16
+template <bool PK, int ACT, bool NOSTORE = false>  // NOSTORE: microbenchmark ablation (the arithmetic without the stores)
+struct PpEpiAct16 {
+  const float* bias;
+  f16* out;          // [M, ld] halves: PK: [N/32][32 hi | 32 lo], ld = 2N;  plain: [N], ld = N
+  int64_t ld;
+  int M, N;
+  template <int TM, int TN>
+  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
+    const BufRsrc R = make_rsrc(out, (uint32_t)((int64_t)M * ld * 2));
+    const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n_w + 32 * i;
+      if (nb >= N) continue;  // wave-uniform
+      float4 b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+      const uint32_t col = PK ? (uint32_t)(nb >> 5) * 128u : (uint32_t)nb * 2u;  // byte offset of the tile's 32 channels in a row
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const uint32_t row = (uint32_t)(m_w + 32 * j + r) * (uint32_t)(ld * 2);
+        uint32_t hi[4][2], lo[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x[4] = {apply_act(ACT, acc[j][i][4 * q] + b[q].x), apply_act(ACT, acc[j][i][4 * q + 1] + b[q].y),
+                              apply_act(ACT, acc[j][i][4 * q + 2] + b[q].z), apply_act(ACT, acc[j][i][4 * q + 3] + b[q].w)};
+          pp::split4(x, hi[q], lo[q]);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const uint32_t o = row + col + (uint32_t)(16 * p + 8 * h) * 2u;
+          if constexpr (NOSTORE) {
+            const uint4 a = pp::widen(hi[2 * p], hi[2 * p + 1]), b2 = pp::widen(lo[2 * p], lo[2 * p + 1]);
+            asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b2.x), "v"(b2.y), "v"(b2.z), "v"(b2.w), "v"(o));
+            continue;
+          }
+          pp::store_b128(R, o, pp::widen(hi[2 * p], hi[2 * p + 1]));
+          if constexpr (PK) pp::store_b128(R, o + 64u, pp::widen(lo[2 * p], lo[2 * p + 1]));
+        }
+      }
+    }
+  }
+};
+
+// attention out-projection / FeedForward second linear (modules.py:548-556,751,755): x[m, n] += gate[n] * (acc + bias[n]); rows whose
+// mask byte is 0 add nothing (mask_mode 1 of EpiStore).  GATE = false: no gate vector (UNetT residual adds, unett.py:300-301).
+template <bool GATE>
+struct PpEpiGateRes {
+  const float* bias;
+  const float* gate;
+  const uint8_t* rowmask;  // or null
+  float* x;
+  int64_t ldx;
+  int M, N;
+  template <int TM, int TN>
+  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
+    const BufRsrc R = make_rsrc(x, (uint32_t)((int64_t)M * ldx * 4));
+    const int h = lane >> 5, r = lane & 31;
+    bool live[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m_w + 32 * j + r;
+      live[j] = !rowmask || (m < M && rowmask[m] != 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n_w + 32 * i;
+      if (nb >= N) continue;
+      float4 b[4], c[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+        if constexpr (GATE) c[q] = *reinterpret_cast<const float4*>(gate + nb + 8 * q + 4 * h);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const uint32_t row = (uint32_t)(m_w + 32 * j + r) * (uint32_t)(ldx * 4) + (uint32_t)(nb + 4 * h) * 4u;
+        uint4 rv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rv[q] = buffer_load_b128(R, row + 32u * q);  // the four residual quads in flight together
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float y[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+          if constexpr (GATE) { y[0] *= c[q].x; y[1] *= c[q].y; y[2] *= c[q].z; y[3] *= c[q].w; }
+          if (!live[j]) { y[0] = y[1] = y[2] = y[3] = 0.f; }
+          union { uint4 u; float f[4]; } t;
+          t.u = rv[q];
+          t.f[0] += y[0]; t.f[1] += y[1]; t.f[2] += y[2]; t.f[3] += y[3];
+          pp::store_b128(R, row + 32u * q, t.u);
+        }
+      }
+    }
+  }
+};
+
+// fused to_q | to_k | to_v (modules.py:481-509): bias, rotary embedding on (2i, 2i+1) pairs of q and k (x_transformers convention, call
+// sites modules.py:503-509), q * 1/sqrt(dh), scatter into the flash kernel's layouts: q, k [B'*H, sn, 64] fp16 (+ lo planes), V^T
+// [B'*H, 64, ldvt] fp16 (+ lo).  dh = 64 and inner % 64 == 0: a 32-channel tile lies in one head of one of q / k / v, so `which`, the
+// head and the channel base are wave-uniform.  Same indices and arithmetic as EpiQKVT<true> (gemm.h), 16-byte stores for q / k, and the
+// V^T columns of two neighbouring tokens leave as one 4-byte store when nseq is even (the lane pair (2t, 2t+1) holds tokens of one sequence).
+struct PpEpiQKV {
+  const float* bias;
+  const float* rope_cs;  // [nseq, 32, 2]
+  f16 *q16, *k16, *vt16, *q16_lo, *k16_lo, *vt16_lo;  // lo planes may be null
+  int nseq, heads, pe_heads, slab_n, pos_off, ldvt;
+  float qscale;
+  uint32_t nseq_magic;
+  int nseq_shift, inner;
+  int M, N;
+  uint32_t qk_bytes, vt_bytes;  // sizes of the q / k planes and of the V^T planes in bytes (< 2^31)
+  int exp;                      // experiment switches (tools): bit 0 = scalar V^T stores
+  template <int TM, int TN>
+  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
+    const int h = lane >> 5, r = lane & 31;
+    const int sn = slab_n ? slab_n : nseq;
+    int bp[TM], pos[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m_w + 32 * j + r;
+      bp[j] = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift);
+      pos[j] = m - bp[j] * nseq;
+    }
+    const bool pair_ok = !(nseq & 1) && !(pos_off & 1) && !(exp & 1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n_w + 32 * i;
+      if (nb >= N) continue;
+      const int which = (nb >= inner ? 1 : 0) + (nb >= 2 * inner ? 1 : 0);
+      const int c0 = nb - which * inner, hh = c0 >> 6, d0 = c0 & 63;  // head, first channel of the tile inside the head (0 or 32)
+      float4 b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+      if (which < 2) {
+        const bool rope = pe_heads < 0 || hh < pe_heads;
+        f16* P = which == 0 ? q16 : k16;
+        f16* Pl = which == 0 ? q16_lo : k16_lo;
+        const BufRsrc R = make_rsrc(P, qk_bytes);
+        const BufRsrc Rl = make_rsrc(Pl ? Pl : P, Pl ? qk_bytes : 0u);
+        const float sc = which == 0 ? qscale : 1.0f;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const bool ok = m_w + 32 * j + r < M;
+          float4 cs[4];
+          if (rope) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              cs[q] = *reinterpret_cast<const float4*>(rope_cs + (pos[j] * 32 + ((d0 + 8 * q + 4 * h) >> 1)) * 2);  // pos < nseq for every m
+#ifndef F5_HIPEMU
+            if (exp & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+          }
+          uint32_t hi[4][2], lo[4][2];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+            if (rope) {
+              const float a0 = x[0] * cs[q].x - x[1] * cs[q].y, a1 = x[1] * cs[q].x + x[0] * cs[q].y;
+              const float a2 = x[2] * cs[q].z - x[3] * cs[q].w, a3 = x[3] * cs[q].z + x[2] * cs[q].w;
+              x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
+            }
+            if (which == 0) { x[0] *= sc; x[1] *= sc; x[2] *= sc; x[3] *= sc; }
+            pp::split4(x, hi[q], lo[q]);
+          }
+          const uint32_t rowb = ok ? (uint32_t)((((bp[j] * heads + hh) * sn + pos_off + pos[j]) << 6) + d0 + 8 * h) * 2u : OOB_ROW;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            pp::store_b128(R, rowb + 32u * p, pp::widen(hi[2 * p], hi[2 * p + 1]));
+            if (Pl) pp::store_b128(Rl, rowb + 32u * p, pp::widen(lo[2 * p], lo[2 * p + 1]));
+          }
+        }
+      } else {
+        const BufRsrc R = make_rsrc(vt16, vt_bytes);
+        const BufRsrc Rl = make_rsrc(vt16_lo ? vt16_lo : vt16, vt16_lo ? vt_bytes : 0u);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const bool ok = m_w + 32 * j + r < M;
+          const int tokp = pos_off + pos[j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+            uint32_t hv[2], lv[2];
+            pp::split4(x, hv, lv);
+            const int d = d0 + 8 * q + 4 * h;
+            const uint32_t base = (uint32_t)((bp[j] * heads + hh) * 64 + d) * (uint32_t)ldvt;  // element index of (channel d, token 0)
+            if (pair_ok) {
+              // lane pair (even, odd) = tokens (t, t + 1) of one sequence, t even: the even lane writes channels d, d+1 of both tokens, the
+              // odd lane channels d+2, d+3 — two 4-byte stores each instead of four 2-byte ones
+              const bool odd = lane & 1;
+              const uint32_t got = pp::xchg1(odd ? hv[0] : hv[1]);    // even receives the partner's (d, d+1); odd the partner's (d+2, d+3)
+              const uint32_t gotl = pp::xchg1(odd ? lv[0] : lv[1]);
+              const uint32_t mine = odd ? hv[1] : hv[0], minel = odd ? lv[1] : lv[0];
+              const uint32_t first = odd ? got : mine, second = odd ? mine : got;  // token t, token t + 1
+              const uint32_t firstl = odd ? gotl : minel, secondl = odd ? minel : gotl;
+              const uint32_t w0 = (first & 0xffffu) | (second << 16), w1 = (first >> 16) | (second & 0xffff0000u);
+              const uint32_t w0l = (firstl & 0xffffu) | (secondl << 16), w1l = (firstl >> 16) | (secondl & 0xffff0000u);
+              const uint32_t o = ok ? (base + (uint32_t)(odd ? 2 : 0) * (uint32_t)ldvt + (uint32_t)(tokp - (odd ? 1 : 0))) * 2u : OOB_ROW;
+              pp::store_b32(R, o, w0);
+              pp::store_b32(R, o + (uint32_t)ldvt * 2u, w1);
+              if (vt16_lo) { pp::store_b32(Rl, o, w0l); pp::store_b32(Rl, o + (uint32_t)ldvt * 2u, w1l); }
+            } else {
+              const uint32_t o = ok ? (base + (uint32_t)tokp) * 2u : OOB_ROW;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                pp::store_b16(R, o + (uint32_t)e * (uint32_t)ldvt * 2u, (uint16_t)(hv[e >> 1] >> (16 * (e & 1))));
+                if (vt16_lo) pp::store_b16(Rl, o + (uint32_t)e * (uint32_t)ldvt * 2u, (uint16_t)(lv[e >> 1] >> (16 * (e & 1))));
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+};
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------------
+template <int TM, int TN, int WGM, int WGN, int NS>
+constexpr int gemm_pp_lds_bytes() {
+  return NS * 32 * (WGM * TM + WGN * TN) * GEMM_KTB;
+}
+
+// TM x TN 32x32 tiles per wave, WGM x WGN waves, ring of NS stages, JG activation tiles per fragment slot (TM % JG == 0).
+// ABL (microbenchmark ablations): bit 0 = no epilogue, bit 2 = no LDS-DMA after the prologue, bit 3 = no MFMAs.
+template <typename T, int NSPLIT, int TM, int TN, int WGM, int WGN, int NS, int JG, typename Epi, int ABL = 0>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi epi) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
+  constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
+  constexpr int KS = NPL == 2 ? 2 : 4;             // 16-wide MFMA k-steps per 128-byte line
+  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
+  constexpr int LPT = PA + PW;
+  constexpr int TILE_A = BM * GEMM_KTB, STAGE = (BM + BN) * GEMM_KTB;
+  constexpr int NSLOT = TM / JG;                   // fragment slots per k-step
+  static_assert(PA * 8 * NW == BM && PW * 8 * NW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
+  static_assert(TM % JG == 0 && (NS == 2 || NS == 3), "slot / ring shape");
+  static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
+  F5_DYN_LDS(char, smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = pp::uniform(tid >> 6);
+  const int wm = wave % WGM, wn = wave / WGM;
+  int m0, n0;
+  {  // tile order as gemm_kernel: XCD-contiguous runs, channel tiles fastest, optional groups of row tiles
+    const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
+    const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    int mt, ntile;
+    if (g.group_m > 1) {
+      const int mtt = (g.M + BM - 1) / BM, per = g.group_m * nt;
+      const int grp = L / per, first = grp * g.group_m, gsz = min(g.group_m, mtt - first), within = L - grp * per;
+      ntile = within / gsz;
+      mt = first + (within - ntile * gsz);
+    } else {
+      mt = L / nt;
+      ntile = L - mt * nt;
+    }
+    m0 = mt * BM;
+    n0 = ntile * BN;
+  }
+  const int kbytes = g.K * 2 * NPL;  // bytes of one operand row; a multiple of 128 (launcher)
+  const int nkt = kbytes / GEMM_KTB;
+  const BufRsrc Ar = make_rsrc(g.A, (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * 2 + kbytes));
+  const BufRsrc Wr = make_rsrc(g.W, (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * 2 + kbytes));
+  // DMA piece P of an operand = rows 8P .. 8P+7 -> LDS bytes [1024 P, +1024); lane l brings row 8P + l/8, logical chunk (l%8) ^ swz(row)
+  uint32_t a_off[PA], w_off[PW];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = 8 * (wave * PA + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+    a_off[p] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * 2 + lc * 16) : OOB_ROW;
+  }
+#pragma unroll
+  for (int p = 0; p < PW; ++p) {
+    const int row = 8 * (wave * PW + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[p] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + lc * 16) : OOB_ROW;
+  }
+  auto issue = [&](int kt, int stage) {
+    char* base = smem + stage * STAGE;
+    const uint32_t kb = (uint32_t)kt * GEMM_KTB;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) pp::dma_b128(Ar, base + (wave * PA + p) * 1024, a_off[p], kb);
+#pragma unroll
+    for (int p = 0; p < PW; ++p) pp::dma_b128(Wr, base + TILE_A + (wave * PW + p) * 1024, w_off[p], kb);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+  // fragment addressing: lane (row = lane & 31, hi = lane >> 5) reads logical chunk 2 ks + hi (+4 for the lo plane) of its row
+  const uint32_t lds0 = pp::lds_base(smem);
+  const int frow = (lane & 31) * GEMM_KTB, fswz = ((lane & 31) >> 1) & 7, fhi = lane >> 5;
+  uint32_t fa_addr[NPL][KS], fw_addr[NPL][KS];  // + stage offset (updated per k-tile) + 4096 * tile index (immediate)
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t o = (uint32_t)(frow + (((p * 4 + 2 * ks + fhi) ^ fswz) << 4));
+      fa_addr[p][ks] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
+      fw_addr[p][ks] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
+    }
+  Frag fa[2][NPL][JG], fw[2][NPL][TN];
+
+  // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot
+  auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, slot>
+    constexpr int s = decltype(SC)::value, ks = s / NSLOT, jg = s % NSLOT, buf = s & 1, wbuf = ks & 1;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      if constexpr (jg == 0) {
+        const uint32_t wb = fw_addr[p][ks] + soff;
+        static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * 4096>(wb); });
+      }
+      const uint32_t ab = fa_addr[p][ks] + soff;
+      static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * 4096>(ab); });
+    }
+    // (no scheduling fence here: pinning the reads ahead of the slot's MFMAs measured -20 % on the 8-wave tiles and 0 on the 4-wave ones —
+    // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
+  };
+  auto mma_slot = [&](auto SC) {
+    constexpr int s = decltype(SC)::value, ks = s / NSLOT, jg = s % NSLOT, buf = s & 1, wbuf = ks & 1;
+#pragma unroll
+    for (int jj = 0; jj < JG; ++jj)
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        if constexpr (ABL & 8) {  // keep the fragments alive without the MFMAs
+#ifndef F5_HIPEMU
+          asm volatile("" ::"v"(fw[wbuf][0][i].u.x), "v"(fw[wbuf][NPL - 1][i].u.w), "v"(fa[buf][0][jj].u.x), "v"(fa[buf][NPL - 1][jj].u.w));
+#endif
+          continue;
+        }
+        Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][0][jj]);
+        if constexpr (NPL == 2) {
+          Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][1][jj]);  // W_hi . A_lo
+          Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][1][i], fa[buf][0][jj]);  // W_lo . A_hi
+        }
+      }
+  };
+  constexpr int SLOTS = KS * NSLOT;
+  static_assert(SLOTS % 2 == 0, "slot buffers alternate: an even number of slots per k-tile keeps slot 0 in buffer 0");
+
+  // One k-tile.  On entry: slot 0's reads are in flight (or landed); tiles t+1 .. t+NS-1 are issued.  MODE 0: steady state (refill tile
+  // t+NS when it exists), 1: next-to-last tile (nothing left to issue, everything outstanding is waited for), 2: last tile.
+  auto ktile = [&](auto MODE, int t, uint32_t soff, uint32_t soff_next, int stage) {
+    constexpr int mode = decltype(MODE)::value;
+    // slots 0 .. SLOTS-2: wait for this slot's fragments, read the next slot's, multiply
+    static_for<SLOTS - 1>([&](auto S) {
+      pp::lds_wait();
+      read_slot(std::integral_constant<int, decltype(S)::value + 1>{}, soff);
+      mma_slot(S);
+    });
+    pp::lds_wait();  // the last slot's fragments: every read of this tile by this wave has landed
+    if constexpr (mode != 2) {
+      if constexpr (mode == 0) pp::wait_vmcnt<(NS - 2) * LPT>();  // tile t+1 landed (this wave's pieces); NS-2 tiles stay in flight
+      else pp::wait_vmcnt<0>();
+      pp::wg_barrier();  // tile t+1 visible to all; nobody reads this tile's stage any more
+      if constexpr (mode == 0) {
+        if constexpr (!(ABL & 4)) {
+          if (t + NS < nkt) issue(t + NS, stage);
+        }
+      }
+      read_slot(std::integral_constant<int, 0>{}, soff_next);
+    }
+    mma_slot(std::integral_constant<int, SLOTS - 1>{});
+  };
+
+  // prologue: tiles 0 .. NS-1 in flight, tile 0 landed and visible, its first fragments requested
+#pragma unroll
+  for (int s = 0; s < NS; ++s) issue(s, s);
+  pp::wait_vmcnt<(NS - 1) * LPT>();
+  pp::wg_barrier();
+  read_slot(std::integral_constant<int, 0>{}, 0u);
+  int stage = 0;
+  uint32_t soff = 0;
+  auto next_soff = [&](uint32_t so) { return so + STAGE == (uint32_t)(NS * STAGE) ? 0u : so + STAGE; };
+  int t = 0;
+  for (; t < nkt - 2; ++t) {
+    const uint32_t sn = next_soff(soff);
+    ktile(std::integral_constant<int, 0>{}, t, soff, sn, stage);
+    soff = sn;
+    stage = stage == NS - 1 ? 0 : stage + 1;
+  }
+  {
+    const uint32_t sn = next_soff(soff);
+    ktile(std::integral_constant<int, 1>{}, t, soff, sn, stage);
+    soff = sn;
+    ++t;
+  }
+  ktile(std::integral_constant<int, 2>{}, t, soff, 0u, 0);
+
+  if (g.sk_exp & 2) pp::wg_barrier();
+  if constexpr (ABL & 1) {
+#ifndef F5_HIPEMU
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
+#endif
+  } else {
+    epi.template tile<TM, TN>(acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+  }
+}

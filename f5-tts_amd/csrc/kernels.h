@@ -10,6 +10,7 @@ enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2 };  // GEMM operand kind
 // batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
 hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s);
 hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s);
+hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g, const EpiQKV& e, int variant, hipStream_t s);  // microbenchmarks / tests: < 0 = heuristic
 // explicit tile variant (microbenchmarks): 0 = 64x128, 1 = 128x64, 2 = 128x128 (rows x channels), -1 = heuristic
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s);
 // one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "engine.h"
@@ -89,15 +90,6 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   g.A = op == OP_F32 ? (const void*)a32 : (const void*)ah;
   g.W = op == OP_F32 ? (const void*)w32 : (const void*)wh;
   g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
-  const size_t sk_slots_per_wg = (variant == 42 || variant == 43) ? 2 : 1;  // gemm_skrs.h: slot A + slot B, and two flags, per workgroup
-  if (variant >= 40 && variant <= 43) {  // stream-K: private workspace (slots of 128 KB + flags + error word), zeroed flags
-    const char* gv = getenv("KB_SKGRID");
-    g.sk_grid = gv ? atoi(gv) : 256;
-    const size_t slots = (size_t)g.sk_grid * sk_slots_per_wg * 131072, total = slots + ((size_t)g.sk_grid * sk_slots_per_wg + 2) * sizeof(int) + (size_t)g.sk_grid * 64;
-    char* ws = t.get<char>(total);
-    if (!ws || hipMemsetAsync(ws + slots, 0, total - slots, s) != hipSuccess) return F5HIP_ERR_HIP;
-    g.sk_ws = ws;
-  }
   EpiStore e{};
   e.alpha = 1.f; e.bias = bias; e.ldo = N; e.ldres = N;
   if (epilogue == 2) {  // out-proj / FF2: x += gate * (acc + bias), fp32 residual stream
@@ -108,25 +100,23 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
     if (op == OP_F32) e.out32 = o32;
     else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = 1; e.ldo16 = 2 * (int64_t)N; } }
   }
-  if (getenv("KB_CHECK") && epilogue != 2) {  // compare this variant's output with the plain 128x64 tiling (variant 1), bit for bit
-    const size_t nb = op == OP_F32 ? (size_t)M * N * 4 : (size_t)M * N * pl * 2;
-    void* outp = op == OP_F32 ? (void*)o32 : (void*)oh;
+  if (getenv("KB_CHECK")) {  // compare this variant's output with the generic 128x64 tiling (variant 1): bytes and numeric distance
+    const bool r32 = epilogue == 2 || op == OP_F32;
+    const size_t nb = r32 ? (size_t)M * N * 4 : (size_t)M * N * pl * 2;
+    void* outp = epilogue == 2 ? (void*)res : op == OP_F32 ? (void*)o32 : (void*)oh;
     std::vector<unsigned char> ref(nb), got(nb);
-    if (hipMemsetAsync(outp, 0, nb, s) != hipSuccess || launch_gemm_store_variant(op, g, e, 1, 1, s) != hipSuccess ||
-        hipMemcpyAsync(ref.data(), outp, nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-      return F5HIP_ERR_HIP;
     for (int rep = 0; rep < 3; ++rep) {
-      if (hipMemsetAsync(outp, 0, nb, s) != hipSuccess || launch_gemm_store_variant(op, g, e, 1, variant, s) != hipSuccess ||
-          hipMemcpyAsync(got.data(), outp, nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return F5HIP_ERR_HIP;
+      for (int pass = 0; pass < 2; ++pass) {  // the same inputs for both kernels (epilogue 2 updates its residual in place)
+        if (epilogue == 2 ? fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess : hipMemsetAsync(outp, 0, nb, s) != hipSuccess) return F5HIP_ERR_HIP;
+        if (launch_gemm_store_variant(op, g, e, 1, pass == 0 ? 1 : variant, s) != hipSuccess ||
+            hipMemcpyAsync(pass == 0 ? ref.data() : got.data(), outp, nb, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return F5HIP_ERR_HIP;
+      }
       size_t bad = 0, first = 0;
       for (size_t i = 0; i < nb; ++i)
         if (ref[i] != got[i]) { if (!bad) first = i; ++bad; }
-      int errw = 0;
-      if (g.sk_ws) (void)hipMemcpy(&errw, reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * sk_slots_per_wg * 131072 + (size_t)g.sk_grid * sk_slots_per_wg * sizeof(int), sizeof(int), hipMemcpyDeviceToHost);
-      // stream-K sums the k-tiles of a tile in a different (fixed) association than one workgroup does: report the numeric distance too
       double maxd = 0.0, maxv = 0.0;
-      if (op == OP_F32) {
+      if (r32) {
         const float* a = reinterpret_cast<const float*>(ref.data());
         const float* b = reinterpret_cast<const float*>(got.data());
         for (size_t i = 0; i < nb / 4; ++i) { maxd = std::max(maxd, (double)fabsf(a[i] - b[i])); maxv = std::max(maxv, (double)fabsf(a[i])); }
@@ -135,29 +125,100 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
         const f16* b = reinterpret_cast<const f16*>(got.data());
         for (size_t i = 0; i < nb / 2; ++i) { maxd = std::max(maxd, (double)fabsf((float)a[i] - (float)b[i])); maxv = std::max(maxv, (double)fabsf((float)a[i])); }
       }
-      int flags_set = 0;
-      if (g.sk_ws) {
-        std::vector<int> fl((size_t)g.sk_grid * sk_slots_per_wg);
-        (void)hipMemcpy(fl.data(), reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * sk_slots_per_wg * 131072, fl.size() * sizeof(int), hipMemcpyDeviceToHost);
-        for (int v : fl) flags_set += v != 0;
-      }
-      fprintf(stderr, "KB_CHECK variant %d rep %d: %zu of %zu bytes differ from variant 1 (first at %zu), max |diff| %.3g of max |value| %.3g, sk err word %d, flags left set %d\n",
-              variant, rep, bad, nb, first, maxd, maxv, errw, flags_set);
+      fprintf(stderr, "KB_CHECK variant %d epi %d rep %d: %zu of %zu bytes differ from variant 1 (first at %zu), max |diff| %.3g of max |value| %.3g\n",
+              variant, epilogue, rep, bad, nb, first, maxd, maxv);
     }
+    if (epilogue == 2 && fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess) return F5HIP_ERR_HIP;
   }
   const int rc = time_it([&] { return launch_gemm_store_variant(op, g, e, 1, variant, s); }, iters, s, avg_ms);
-  if (g.sk_ws && sk_slots_per_wg == 1 && getenv("F5HIP_SK_DEBUG")) {  // phase stamps of the last launch (10 ns ticks relative to the earliest start)
-    std::vector<long long> st((size_t)g.sk_grid * 8);
-    (void)hipMemcpy(st.data(), reinterpret_cast<char*>(g.sk_ws) + (size_t)g.sk_grid * 131072 + ((size_t)g.sk_grid + 2) * sizeof(int), st.size() * 8, hipMemcpyDeviceToHost);
-    long long t0 = st[0];
-    for (int b = 0; b < g.sk_grid; ++b) if (st[(size_t)b * 8] && st[(size_t)b * 8] < t0) t0 = st[(size_t)b * 8];
-    for (int b = 0; b < g.sk_grid && b < 48; b += (b < 8 ? 8 : 8)) {
-      fprintf(stderr, "sk wg %3d:", b);
-      for (int k = 0; k < 8; ++k) fprintf(stderr, " %7.2f", st[(size_t)b * 8 + k] ? (st[(size_t)b * 8 + k] - t0) * 0.01 : -1.0);
-      fprintf(stderr, " us\n");
+  return rc;
+}
+
+// The fused q|k|v projection of one block (bias, rope, head scatter into the flash layouts) for `seqs` sequences of nseq tokens, H = 16
+// heads of 64: time of `variant`, and with check != 0 every output plane (q, k hi/lo, V^T) compared byte for byte with the generic kernel
+// of gemm.h (variant 1).  Returns the number of differing bytes in *diff (negative status on errors).
+int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff) {
+  if (!ctx || !avg_ms || seqs <= 0 || nseq <= 1 || iters <= 0 || precision == F5HIP_PREC_FP32 || (K % 32)) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
+  if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
+  hipStream_t s = nullptr;
+  Tmp t;
+  const int op = precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3;
+  const int H = 16, dh = 64, inner = H * dh, N = 3 * inner, M = seqs * nseq, ldv = (nseq + 7) & ~7;
+  const bool x3 = op == OP_F16X3;
+  const size_t pl = x3 ? 2 : 1;
+  float* a32 = t.get<float>((size_t)M * K);
+  float* w32 = t.get<float>((size_t)N * K);
+  float* bias = t.get<float>(N);
+  float* rope = t.get<float>((size_t)nseq * dh);
+  float* invf = t.get<float>(dh / 2);
+  f16 *ah = t.get<f16>((size_t)M * K * pl), *wh = t.get<f16>((size_t)N * K * pl);
+  const size_t nq = (size_t)seqs * H * nseq * dh, nv = (size_t)seqs * H * dh * ldv;
+  f16* out[2][6];  // [reference / variant][q, q_lo, k, k_lo, vt, vt_lo]
+  for (auto& o : out)
+    for (int i = 0; i < 6; ++i) {
+      o[i] = t.get<f16>(i < 4 ? nq : nv);
+      if (!o[i]) return F5HIP_ERR_HIP;
+    }
+  if (!a32 || !w32 || !bias || !rope || !invf || !ah || !wh) return F5HIP_ERR_HIP;
+  std::vector<float> f(dh / 2);
+  for (int k = 0; k < dh / 2; ++k) f[k] = 1.0f / powf(10000.0f, (float)(2 * k) / (float)dh);
+  if (hipMemcpy(invf, f.data(), f.size() * 4, hipMemcpyHostToDevice) != hipSuccess || launch_rope_table(invf, nseq, dh / 2, rope, s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (fill(a32, (int64_t)M * K, 1u, 1.0f, s) != hipSuccess || fill(w32, (int64_t)N * K, 2u, 0.05f, s) != hipSuccess || fill(bias, N, 3u, 0.02f, s) != hipSuccess)
+    return F5HIP_ERR_HIP;
+  if (x3) {
+    if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
+  } else if (launch_split_f16(a32, (int64_t)M * K, 1.0f, ah, nullptr, s) != hipSuccess || launch_split_f16(w32, (int64_t)N * K, 1.0f, wh, nullptr, s) != hipSuccess) {
+    return F5HIP_ERR_HIP;
+  }
+  GemmCore g{};
+  g.A = ah; g.W = wh; g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
+  auto epi = [&](int which) {
+    EpiQKV e{};
+    e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = getenv("KB_QKV_PE") ? atoi(getenv("KB_QKV_PE")) : -1; e.qscale = 0.125f; e.ldvt = ldv;
+    e.q16 = out[which][0]; e.k16 = out[which][2]; e.vt16 = out[which][4];
+    if (x3) { e.q16_lo = out[which][1]; e.k16_lo = out[which][3]; e.vt16_lo = out[which][5]; }
+    return e;
+  };
+  int64_t bad = 0;
+  if (check) {
+    for (int w = 0; w < 2; ++w) {
+      for (int i = 0; i < 6; ++i)
+        if (hipMemsetAsync(out[w][i], 0, (i < 4 ? nq : nv) * sizeof(f16), s) != hipSuccess) return F5HIP_ERR_HIP;
+      if (launch_gemm_qkv_variant(op, g, epi(w), w == 0 ? 1 : variant, s) != hipSuccess) return F5HIP_ERR_HIP;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return F5HIP_ERR_HIP;
+    // the VALUE of every output (hi + lo in fp16x3) must agree to fp32 rounding: the two kernels contract the rope arithmetic differently
+    // (an fma here, a mul + add there), which flips a last bit of `hi` now and then and is absorbed by `lo`; anything above 4e-6 of the
+    // plane's largest value is a real difference.  V (no rope) is compared byte for byte as well.
+    for (int pl3 = 0; pl3 < 3; ++pl3) {
+      const size_t n = (pl3 < 2 ? nq : nv);
+      std::vector<f16> ah(n), bh(n), al(x3 ? n : 0), bl(x3 ? n : 0);
+      if (hipMemcpy(ah.data(), out[0][2 * pl3], n * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(bh.data(), out[1][2 * pl3], n * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        return F5HIP_ERR_HIP;
+      if (x3 && (hipMemcpy(al.data(), out[0][2 * pl3 + 1], n * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(bl.data(), out[1][2 * pl3 + 1], n * 2, hipMemcpyDeviceToHost) != hipSuccess))
+        return F5HIP_ERR_HIP;
+      double vmax = 0;
+      for (size_t j = 0; j < n; ++j) vmax = std::max(vmax, (double)fabsf((float)ah[j]));
+      const double tol = (x3 ? 4e-6 : 2e-3) * std::max(vmax, 1e-3);
+      int64_t nb = 0, first = -1, nbytes = 0;
+      double maxd = 0;
+      for (size_t j = 0; j < n; ++j) {
+        const double va = (double)(float)ah[j] + (x3 ? (double)(float)al[j] : 0.0), vb = (double)(float)bh[j] + (x3 ? (double)(float)bl[j] : 0.0);
+        const double d = fabs(va - vb);
+        if (d > tol) { if (first < 0) first = (int64_t)j; ++nb; }
+        maxd = std::max(maxd, d);
+        if (memcmp(&ah[j], &bh[j], 2) != 0) ++nbytes;
+      }
+      if (pl3 == 2 && nbytes) { nb += nbytes; }
+      if (nb) fprintf(stderr, "QKV_CHECK variant %d plane %s: %lld of %zu values differ by more than %.3g (first at %lld), max |diff| %.3g of max |value| %.3g\n", variant,
+                      pl3 == 0 ? "q" : pl3 == 1 ? "k" : "v^T", (long long)nb, n, tol, (long long)first, maxd, vmax);
+      bad += nb;
     }
   }
-  return rc;
+  if (diff) *diff = bad;
+  return time_it([&] { return launch_gemm_qkv_variant(op, g, epi(1), variant, s); }, iters, s, avg_ms);
 }
 
 // flash attention over [batch2 * heads, n, 64]; precision FP16 -> plain fp16 operands, FP16X3 -> hi/lo split

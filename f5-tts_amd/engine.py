@@ -231,6 +231,16 @@ class F5HipEngine:
         return out
 
 
+    def istft(self, logits: torch.Tensor) -> torch.Tensor:
+        """The Vocos head's inverse STFT alone: logits [batch, frames, ld >= 1026] = (log-magnitude | phase) -> wave [batch, 256 * (frames - 1)]."""
+        logits = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        b, frames, ld = logits.shape
+        out = torch.empty((b, 256 * (frames - 1)), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._chk(self.lib.f5hip_istft(self._ctx, _ptr(logits), ld, b, frames, _ptr(out), self._stream()))
+        return out
+
+
 def _as_tensor(ptr: int, numel: int, device: torch.device) -> torch.Tensor:
     """Wrap a raw device pointer as a float32 torch tensor (no copy) via __cuda_array_interface__."""
 
@@ -332,11 +342,14 @@ class F5HipCFM:
         cond_mask = torch.nn.functional.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)
         use_mask = batch > 1  # cfm.py:155-158
         # noise from torch's CPU generator, exactly as the reference draws it (cfm.py:196-201)
+        # (seeded: a private generator re-seeded per utterance — the same stream torch.manual_seed(seed) would give the global one, without
+        # touching state that other threads of infer_batch_process' pool draw from)
         y0 = []
+        gen = torch.Generator(device="cpu") if seed is not None else None
         for dur in duration:
-            if seed is not None:
-                torch.manual_seed(seed)
-            y0.append(torch.randn(int(dur), self.num_channels, dtype=torch.float32))
+            if gen is not None:
+                gen.manual_seed(seed)
+            y0.append(torch.randn(int(dur), self.num_channels, dtype=torch.float32, generator=gen))
         y0 = torch.nn.utils.rnn.pad_sequence(y0, padding_value=0, batch_first=True)
         t_start = 0
         if duplicate_test:  # cfm.py:205-209: start the solve at t_inter from a noised copy of the prompt

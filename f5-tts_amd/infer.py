@@ -156,20 +156,36 @@ def load_checkpoint(engine: F5HipEngine, ckpt_path: str, use_ema: bool = True, f
 
 def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos", vocab_file: str = "", ode_method: str = ode_method,
                use_ema: bool = True, device=0, precision: str = "fp16x3", vocos_cfg: Optional[VocosConfig] = VOCOS_MEL_24K,
-               state_dict: Optional[Dict[str, torch.Tensor]] = None) -> F5HipCFM:
-    """reference utils_infer.py:238-276.  ``model_cfg``: a preset name ("F5TTS_v1_Base", "F5TTS_Base", "E2TTS_Base"), a ``DiTConfig``
-    or the reference's ``model.arch`` dict.  The returned object quacks like the reference's ``CFM`` on the inference path; its
-    engine also hosts the vocoder (``load_vocoder(engine=model.engine, ...)``)."""
+               state_dict: Optional[Dict[str, torch.Tensor]] = None, model_cls=None) -> F5HipCFM:
+    """reference utils_infer.py:238-276 — ``load_model(model_cls, model_cfg, ckpt_path, ...)``.  The reference's leading ``model_cls``
+    argument (the backbone CLASS: DiT / UNetT / MMDiT) is the keyword ``model_cls`` here — a class or its name; it is REQUIRED when
+    ``model_cfg`` is the reference's ``model.arch`` dict, which does not say which backbone it describes (and UNetT / MMDiT have
+    constructor defaults — text_dim = mel_dim, no text conv layers — that a DiT default would silently get wrong).  ``model_cfg`` may
+    also be a preset name ("F5TTS_v1_Base", "F5TTS_Base", "E2TTS_Base") or a ``DiTConfig``.  The returned object quacks like the
+    reference's ``CFM`` on the inference path; with ``mel_spec_type="vocos"`` its engine also hosts the vocoder
+    (``load_vocoder(engine=model.engine, ...)``); with ``"bigvgan"`` the generator is its own context and this one is finalised here."""
     if mel_spec_type not in ("vocos", "bigvgan"):
         raise ValueError("mel_spec_type must be vocos or bigvgan (modules.py:127)")
+    if mel_spec_type == "bigvgan":
+        vocos_cfg = None  # no Vocos tensors to wait for: load_vocoder("bigvgan") builds a separate F5HipBigVGAN context
     vocab_char_map, vocab_size = (get_tokenizer(vocab_file, "custom") if vocab_file else (None, None))
     if isinstance(model_cfg, str):
         cfg = PRESETS[model_cfg]
     elif isinstance(model_cfg, DiTConfig):
         cfg = model_cfg
     else:
+        name = model_cls if isinstance(model_cls, str) or model_cls is None else getattr(model_cls, "__name__", str(model_cls))
+        if name not in ("DiT", "UNetT", "MMDiT"):
+            raise ValueError("load_model(model.arch dict): pass model_cls='DiT' | 'UNetT' | 'MMDiT' (the reference's first argument, "
+                             "utils_infer.py:238) — the arch dict alone does not name its backbone")
         fields = DiTConfig.__dataclass_fields__
-        cfg = DiTConfig(**{k: v for k, v in dict(model_cfg).items() if k in fields})
+        arch = {k: v for k, v in dict(model_cfg).items() if k in fields}
+        mel_dim = arch.get("mel_dim", 100)
+        if name == "UNetT":  # unett.py:108-128: text_dim defaults to mel_dim, there are no ConvNeXt text layers
+            arch = {"text_dim": mel_dim, "conv_layers": 0, **arch}
+        elif name == "MMDiT":  # mmdit.py:94-110: text embedded at model width, no ConvNeXt text layers
+            arch = {"text_dim": arch.get("dim", 1024), "conv_layers": 0, **arch}
+        cfg = DiTConfig(**{**arch, "backbone": name})
     if vocab_size is not None and vocab_size != cfg.text_num_embeds:
         from dataclasses import replace
 

@@ -16,8 +16,15 @@
  * All "device" pointers are HIP device pointers valid on the context's device; all launches go to
  * the `stream` argument (a hipStream_t passed as void*; NULL = the legacy default stream).  Calls
  * return after enqueueing unless stated otherwise; outputs are complete when the stream reaches the
- * end of the enqueued work.  A context is internally serialised (one mutex): concurrent
- * f5hip_sample() calls from a thread pool (reference utils_infer.py:540-543) are safe.
+ * end of the enqueued work.  Host arrays passed to a call (text ids, masks, time grids) are copied into
+ * pinned, context-owned staging before the call returns, so the caller may free or reuse them at once;
+ * no entry point on the sample / mel / vocoder paths waits for the stream (exceptions: the first call at
+ * a new shape grows the workspace with hipMalloc, which synchronises the device; "profile" mode reads
+ * its events back).  A context owns ONE workspace: its mutex covers the host-side enqueue only, so
+ * concurrent f5hip_sample() calls from a thread pool (reference utils_infer.py:540-543) overlap their
+ * host work with the GPU work already queued; on the GPU the calls of one context run in submission
+ * order — a call that arrives on a different stream than its predecessor first waits (hipStreamWaitEvent,
+ * GPU side) for the predecessor's work.
  */
 #ifndef F5HIP_H
 #define F5HIP_H
@@ -28,7 +35,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 5
+#define F5HIP_ABI_VERSION 6
 
 /* status codes */
 enum {
@@ -163,6 +170,13 @@ int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, voi
  * out: device fp32 [batch, 256 * (frames - 1)] (torch.istft(center=True) length). */
 int f5hip_vocos_decode(f5hip_ctx* ctx, const float* mel, int batch, int frames, int channel_major, float* out, void* stream);
 
+/* The head's inverse STFT alone — replaces: ISTFTHead's `self.istft(S)` with S = exp(log-magnitude, clipped at 1e2) * (cos + i sin)(phase),
+ * torch.istft(n_fft 1024, hop 256, hann, center=True) semantics (restated in-repo at export_vocoder_to_onnx.py:45-59; the reference's own
+ * runnable conv-iSTFT, runtime/triton_trtllm/scripts/conv_stft.py:193-234, is what tests/golden/istft_conv_reference.npz holds).
+ * logits: device fp32 [batch * frames, ld], columns [0, 513) log-magnitude, [513, 1026) phase (ld >= 1026, ld % 4 == 0).
+ * out: device fp32 [batch, 256 * (frames - 1)].  A component entry point for parity tests of the kernels f5hip_vocos_decode ends with. */
+int f5hip_istft(f5hip_ctx* ctx, const float* logits, int64_t ld, int batch, int frames, float* out, void* stream);
+
 /* ---- BigVGAN generator (mel_spec_type "bigvgan") -------------------------------------------------- */
 /* replaces: the object load_vocoder(vocoder_name="bigvgan") returns — bigvgan.BigVGAN.from_pretrained(...), .remove_weight_norm(),
  * .eval() (reference utils_infer.py:130-144) — and its call `vocoder(mel)` (utils_infer.py:512-513).  The generator's source is an
@@ -220,10 +234,7 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
  * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
  * "attn_kv_split" (1 off (default) / 2..8: flash attention with every query block cut into that many key ranges + a merge kernel —
- * shorter workgroups for small batches, csrc/attention_kernel.h),
- * "gemm_streamk" (0 off (default) / 42 / 43: the DiT block GEMMs of the packed schedule through the stream-K kernel with the
- * reduce-scattered epilogue, csrc/gemm_skrs.h, 256x128 / 128x256 tiles; implies one kernel chain unless "gemm_streamk_split" is 1: then the two chains
- * each get half the grid). */
+ * shorter workgroups for small batches, csrc/attention_kernel.h). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
 /* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
  * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */
@@ -239,6 +250,7 @@ int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
  *              128x128, 256x128, 128x256, 256x256 tiles (rows x output channels)
  *   attention: the flash kernel over [batch2*heads, n, 64] (precision FP16 or FP16X3) */
 int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms);
+int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff);
 int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms);
 
 #ifdef __cplusplus

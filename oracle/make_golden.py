@@ -104,6 +104,10 @@ FULL_CASES = {
     # BASELINE.json configs[4] backbone at full size: E2-TTS Base (UNetT, depth 24, ff_mult 4), same prompt/duration as config 1
     "e2_base_cfg5": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # BASELINE.json configs[2] / [3] shape at a size the CPU finishes in minutes: F5-TTS Base, a BATCH of 4 distinct fixed-length prompts
+    # (rows of the packed cond | uncond schedule: 8 x 1406), NFE 32, sway, CFG 2 — the batched path of the engine at the full model size
+    "base_v1_cfg3_b4": dict(preset="F5TTS_v1_Base", wseed=0, nw=120000, wavseed=10, batch=4, nt=220, tseed=3, duration=1406, lens=None,
+                            kw=dict(steps=32, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[0]/[1]: F5-TTS Base, 5 s ref + 10 s gen, NFE 16, sway, CFG 2
     "base_v1_cfg1": dict(preset="F5TTS_v1_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
@@ -122,11 +126,7 @@ def case_inputs(c):
 
 
 def build_reference(cfg, sd, method="euler"):
-    CFM, DiT, UNetT = ref_shims.reference_classes()
-    backbone = {"UNetT": UNetT, "MMDiT": ref_shims.reference_mmdit()}.get(cfg.backbone, DiT)
-    model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method=method))
-    model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
-    return model.eval()
+    return ref_shims.build_reference_cfm(cfg, sd, method)
 
 
 def run_case(name, c, pins):

@@ -240,6 +240,19 @@ def reference_classes():
     return CFM, DiT, UNetT
 
 
+MEL_KW = dict(n_fft=1024, hop_length=256, win_length=1024, n_mel_channels=100, target_sample_rate=24000, mel_spec_type="vocos")
+
+
+def build_reference_cfm(cfg, sd, method="euler"):
+    """The reference's own CFM around its own backbone class, loaded (strict) with a synth.py state dict — what oracle/make_golden.py runs
+    to mint the goldens and what bench.py's cpu_baseline leg times in the build container (kind "reference")."""
+    CFM, DiT, UNetT = reference_classes()
+    backbone = {"UNetT": UNetT, "MMDiT": reference_mmdit() if cfg.backbone == "MMDiT" else None}.get(cfg.backbone, DiT)
+    model = CFM(transformer=backbone(**cfg.arch_kwargs()), mel_spec_kwargs=MEL_KW, odeint_kwargs=dict(method=method))
+    model.load_state_dict(sd, strict=True)  # proves the key contract of synth.py == the reference's
+    return model.eval()
+
+
 def reference_mmdit():
     """The reference's own MMDiT class (src/f5_tts/model/backbones/mmdit.py)."""
     install()

@@ -1,4 +1,4 @@
-"""Run the repo's bench.py — unmodified main(), real rank protocol, real schedule-probing children — with libf5hip built for the host
+"""Run the repo's bench.py — unmodified main(), real self-launch and rank protocol — with libf5hip built for the host
 (tests/hipemu) instead of a GPU: `python tests/bench_shim_harness.py --tiny ...` (F5HIP_EMU_LIB = the emulated library).  Test infrastructure:
 what it prints is not a measurement of anything."""
 import contextlib
@@ -45,7 +45,7 @@ def install():
     import bench
 
     bench.DEVICE_TYPE = "cpu"
-    bench.PROBE_CMD = [sys.executable, os.path.abspath(__file__)]
+    bench.LAUNCH_CMD = [sys.executable, os.path.abspath(__file__)]  # --gpus N > 1 re-executes THIS harness per rank
     return bench
 
 

@@ -88,6 +88,8 @@ static inline hipError_t hipFree(void* p) {
   return hipSuccess;
 }
 // (a synchronous copy inside a thread-local capture is an error on the GPU as well: hipErrorStreamCaptureImplicit)
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { if (hipemu::capturing) return 906; memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (hipemu::capturing) return 906; memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
@@ -293,6 +295,34 @@ inline float shfl_xor(float v, int mask, int) {
   const float r = w.sh[lane ^ mask];
   barrier_wait(w.bar);
   return r;
+}
+
+inline unsigned shfl_xor_u32(unsigned v, int mask) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  memcpy(&w.sh[lane], &v, 4);
+  barrier_wait(w.bar);
+  unsigned r;
+  memcpy(&r, &w.sh[lane ^ mask], 4);
+  barrier_wait(w.bar);
+  return r;
+}
+// v_permlane32_swap_b32 a, b: lanes 32-63 of a exchange with lanes 0-31 of b
+inline void permlane32_swap(unsigned& a, unsigned& b) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  memcpy(&w.sh[lane], lane < 32 ? &b : &a, 4);
+  barrier_wait(w.bar);
+  unsigned r;
+  memcpy(&r, &w.sh[lane ^ 32], 4);
+  barrier_wait(w.bar);
+  if (lane < 32) b = r; else a = r;
+}
+inline void raw_buffer_store(Rsrc r, uint32_t off, const void* src, int bytes) {  // out-of-range dwords are dropped
+  for (int i = 0; i < bytes; i += (bytes < 4 ? bytes : 4)) {
+    const int n = bytes < 4 ? bytes : 4;
+    if ((uint64_t)off + i + n <= r.num_records) memcpy(const_cast<char*>(r.base) + off + i, static_cast<const char*>(src) + i, n);
+  }
 }
 
 constexpr size_t kFiberStack = 128 * 1024;

@@ -5,7 +5,6 @@
 #include "bigvgan_kernels.h"
 #include "attention_kernel.h"
 #include "conv_gemm.h"
-#include "gemm_skrs.h"
 
 #include <string>
 
@@ -157,69 +156,6 @@ int main(int argc, char** argv) {
     else go(I1{}, I1{});
     wr("out.bin", o);
     if (!o_packed) wr("out_lo.bin", olo);
-  } else if (mode == "skrs") {  // op M N K rows256 grid has_res act launches pk_out special(0 EpiStore, 1 EpiFF1, 2 EpiGateRes)
-    const int op = A(0), M = A(1), N = A(2), K = A(3), rows256 = A(4), grid = A(5), has_res = A(6), act = A(7), launches = A(8), pk_out = A(9);
-    const int special = argc > 13 ? A(10) : 0;
-    auto gate = rd<float>("gate.bin", true);
-    auto rowmask = rd<uint8_t>("rowmask.bin", true);
-    auto Ab = rd<char>("A.bin"), Wb = rd<char>("W.bin");
-    auto bias = rd<float>("bias.bin"), res = rd<float>("res.bin", true);
-    std::vector<float> out((size_t)M * N, -777.f);
-    const int mul = op == OP_F16X3 ? 2 : 1;
-    GemmCore g{};
-    g.A = Ab.data(); g.W = Wb.data();
-    g.lda = (int64_t)K * mul; g.ldw = (int64_t)K * mul; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N; g.group_m = 1;
-    EpiStore e{};
-    e.alpha = 1.f; e.act = act; e.bias = bias.data(); e.out32 = out.data(); e.ldo = N; e.ldres = N; e.res = has_res ? res.data() : nullptr;
-    std::vector<f16> out16(pk_out ? (size_t)M * N * 2 : 0);
-    if (pk_out) {  // FF1-style epilogue: the packed fp16 hi/lo operand rows of the next GEMM instead of fp32
-      e.out32 = nullptr; e.out16 = out16.data(); e.out16_lo = out16.data() + 32; e.pk16 = 1; e.ldo16 = 2 * (int64_t)N;
-    }
-    const int BM = rows256 ? 256 : 128, BN = rows256 ? 128 : 256;
-    const int SLOT = SKRS_UNITS * 512 * 4;
-    std::vector<float> ws((size_t)grid * 2 * SLOT, 0.f);
-    std::vector<int> flags((size_t)grid * 2 + 1, 0);
-    SkrsArgs sk{};
-    sk.ws = ws.data(); sk.flags = flags.data(); sk.err = flags.data() + (size_t)grid * 2;
-    sk.tiles_n = (N + BN - 1) / BN;
-    sk.tiles = ((M + BM - 1) / BM) * sk.tiles_n;
-    const int esz = op == OP_F32 ? 4 : 2;
-    sk.kt = (K * esz * mul + GEMM_KTB - 1) / GEMM_KTB;
-    std::vector<int> status;
-    for (int rep = 0; rep < launches; ++rep) {
-      std::fill(out.begin(), out.end(), -777.f);
-      std::fill(out16.begin(), out16.end(), (f16)-7.f);
-      if (special == 2 || (has_res && !gate.empty())) {  // gated residual, in place: out starts as the residual stream
-        std::copy(res.begin(), res.end(), out.begin());
-        e.res = out.data();
-        e.colscale = gate.data();
-        e.rowmask = rowmask.empty() ? nullptr : rowmask.data();
-        e.mask_mode = 1;
-      }
-      auto body = [&](auto tag_t, auto tag_ns) {
-        using T = decltype(tag_t);
-        constexpr int NS = decltype(tag_ns)::value;
-        const int lds = gemm_lds_bytes<T, NS, 2, 2, 2, 4>() / 2 * 3;  // 3 stages of (BM + BN) x 128 B
-        auto go = [&](auto epi) {
-          using E = decltype(epi);
-          if (rows256) hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, E, 4, 2>(g, epi, sk); });
-          else hipemu::launch_coop(dim3(grid), dim3(512), lds, [&] { gemm_skrs_kernel<T, NS, E, 2, 4>(g, epi, sk); });
-        };
-        if (special == 1) go(EpiFF1{bias.data(), out16.data(), 2 * (int64_t)N});
-        else if (special == 2) go(EpiGateRes{bias.data(), gate.data(), rowmask.empty() ? nullptr : rowmask.data(), out.data(), (int64_t)N});
-        else go(e);
-      };
-      if (op == OP_F32) body(float{}, std::integral_constant<int, 1>{});
-      else if (op == OP_F16) body(f16{}, std::integral_constant<int, 1>{});
-      else body(f16{}, std::integral_constant<int, 3>{});
-      int nz = 0;
-      for (int i = 0; i < grid * 2; ++i) nz += flags[i] != 0;
-      status.push_back(nz);
-      status.push_back(flags[(size_t)grid * 2]);
-      if (pk_out) wr(rep == 0 ? "out.bin" : "out2.bin", out16);
-      else wr(rep == 0 ? "out.bin" : "out2.bin", out);
-    }
-    wr("status.bin", status);
   } else {
     return 1;
   }

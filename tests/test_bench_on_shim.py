@@ -1,7 +1,7 @@
 """bench.py executed end to end without a GPU: its main() over libf5hip built for the host (tests/hipemu) on the --tiny workload — the
-single-rank flow with the schedule-probing children, and the two-rank flow under torch.distributed.run (gloo): weight broadcast from rank 0,
-the probe on rank 0 only and its result shared, max-over-ranks timing, one JSON line from rank 0.  Numbers printed here mean nothing; the
-contract fields and the rank protocol are what is checked."""
+single-rank flow, and the PLAIN `bench.py --gpus 2` command: the file launches its own two ranks under torch.distributed.run (gloo here,
+RCCL on the GPU box), rank 0 loads and broadcasts the weights, max-over-ranks timing, one JSON line from rank 0.  Numbers printed here
+mean nothing; the contract fields and the rank protocol are what is checked."""
 import json
 import os
 import subprocess
@@ -16,55 +16,52 @@ from test_hipemu import CLANG, engine_emu_lib  # noqa: E402,F401
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
 HARNESS = os.path.join(ROOT, "tests", "bench_shim_harness.py")
 CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE")
 
 
-def run(cmd, lib, timeout=900, **extra_env):
-    env = dict(os.environ, F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2", **extra_env)
+def run(cmd, lib, timeout=900, expect_fail=False, **extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
+    env.update(F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2", **extra_env)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if expect_fail:
+        assert r.returncode != 0, r.stdout[-1000:]
+        return r.stdout + r.stderr
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line
     return json.loads(lines[0])
 
 
-def check_probe_report(sched):
-    for group, n in (("sk", 2), ("kv", 1)):  # both children ran their candidates (--tiny: a packed and a two-chain stream-K one, one key split)
-        pr = sched["probe"][group]
-        assert "error" not in pr and pr["default_ms"] > 0 and len(pr["candidates"]) == n
-        for c in pr["candidates"]:
-            assert c["ok"] and c["deterministic"] and c["max_abs_vs_default"] < 5e-4 and c["ms"] > 0, c
-    for k in sched["selected"]:  # whatever was adopted went through the in-process check as well
-        assert any(t["ok"] and k in t["options"] and t["ms_max_over_ranks"] >= t["ms"] for t in sched["tried"])
-
-
-@pytest.mark.skipif(os.environ.get("F5HIP_SHIM_FULL") != "1", reason="2 min on the shim; the two-rank test below covers the same code plus the rank protocol")
-def test_single_rank_with_schedule_probe(engine_emu_lib):  # noqa: F811
-    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib)
-    assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
-    check_probe_report(d["config"]["schedule"])
-    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
-
-
-def test_default_schedule_flag_skips_the_probe(engine_emu_lib):  # noqa: F811
-    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0", "--schedule", "default"], engine_emu_lib)
+def test_single_rank(engine_emu_lib):  # noqa: F811
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib)
     assert all(k in d for k in CONTRACT) and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["vs_baseline"] is None and "NOT A BENCHMARK" in d["config"]["workload"]
-    assert d["config"]["schedule"] == {"selected": {}, "how": "default schedule"}
+    assert d["config"]["rccl_ranks"] == 0 and len(d["config"]["per_rank_ms_per_step"]) == 1 and not d["config"]["self_launched"]
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["roofline"]["traffic"] is None  # no PMC pass of the tiny workload is committed
+    assert d["roofline_whole_path"]["achieved"] > 0
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
-def test_two_ranks_under_torch_distributed_run(engine_emu_lib):  # noqa: F811
+def test_plain_gpus_2_command_launches_its_own_two_ranks(engine_emu_lib):  # noqa: F811
+    """`python bench.py --gpus 2 ...` with no launcher around it (what a user types; the driver wraps it in torch.distributed.run itself)."""
+    d = run([sys.executable, HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
+    assert d["config"]["rccl_ranks"] == 2 and len(d["config"]["per_rank_ms_per_step"]) == 2 and d["config"]["self_launched"]
+    assert d["ms_per_step"] >= max(d["config"]["per_rank_ms_per_step"]) * 0.999  # MAX over ranks (plus the closing barrier)
+    assert d["config"]["weight_broadcast_plus_finalize_s"] > 0
+    assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim)
+    assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
+
+
+def test_under_the_drivers_launcher(engine_emu_lib):  # noqa: F811
     port = 29911 + (os.getpid() % 80)
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-             HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200,
-            F5HIP_BENCH_ADOPT_RATIO="100")  # timing on the shim is noise: adopt whatever verifies, so that the adoption path runs too
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 and "rccl broadcast" in d["config"]["weights"]
-    assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim) while the probe flips schedules
-    assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
-    sched = d["config"]["schedule"]
-    check_probe_report(sched)  # rank 0's children; the decision is shared and re-checked on both ranks
-    assert sched["selected"] and sched["how"].startswith("measured at start-up") and len(sched["tried"]) == 3  # combination, stream-K alone, key-split alone
-    assert d["roofline"]["traffic"] is None  # the committed PMC pass describes the default schedule only
+             HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib, timeout=1200)
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and not d["config"]["self_launched"]
+
+
+def test_a_launch_of_the_wrong_size_is_refused(engine_emu_lib):  # noqa: F811
+    out = run([sys.executable, HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib, expect_fail=True,
+              WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert "refusing" in out

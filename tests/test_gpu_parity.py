@@ -378,11 +378,8 @@ def test_small_models_golden(name):
 
 
 # written without GPU minutes: executed on the CPU shim (tests/test_parity_on_shim.py) and under a real gloo broadcast (tests/test_dist_cpu.py);
-# on a GPU it runs in a child process first (tests/test_zz_gpu_first_light.py) so that it cannot turn the established suite red
-first_light = pytest.mark.skipif(os.environ.get("F5HIP_FIRST_LIGHT_GPU") != "1", reason="run by tests/test_zz_gpu_first_light.py in a child process")
 
 
-@first_light
 def test_weight_blob_receiver_equals_the_rank_that_loaded(engines):
     """The N>1 path of bench.py / dist.broadcast_engine_weights from the receiver's side, in one process: a context that never saw a
     state dict gets the packed blob and the sender's loaded mask, finalises, and must produce the sender's bits — with a checkpoint
@@ -649,3 +646,211 @@ def test_all_padding_text_and_single_frame_prompt(engines):
     ref, _ = O.cfm_sample(sd, cfg, wav, text, 50, **kw)
     assert out.shape == ref.shape == (1, 50, 100)
     assert maxerr(out, ref) < TIGHT
+
+
+# ---- round 2: the parity holes VERDICT r01 listed -------------------------------------------------------------------------------------
+def test_vocos_full_size_on_the_benchmarked_mel():
+    """F5HipVocos at VOCOS_MEL_24K (dim 512 x 8 layers, 1026-wide head: the vocoder bench.py times) on the 938 generated frames of the
+    reference-minted golden base_v1_cfg1, against the oracle.  The oracle's backbone is a restatement (the `vocos` package is absent:
+    parity unpinned for the backbone); its iSTFT is pinned by the reference's conv-iSTFT (tests/test_oracle.py) and the HIP iSTFT
+    directly by the next test."""
+    from f5_tts_amd.engine import F5HipEngine, F5HipVocos
+
+    vcfg = config.VOCOS_MEL_24K
+    vsd = synth.synth_vocos_state_dict(vcfg, seed=0)
+    eng = F5HipEngine(config.DIT_TINY, vcfg, device=0)
+    eng.load_state_dict({**synth.synth_dit_state_dict(config.DIT_TINY, seed=1), **vsd})
+    try:
+        mel = torch.from_numpy(gold("base_v1_cfg1")["out"][:, 468:, :]).permute(0, 2, 1).contiguous()  # [1, 100, 938] as utils_infer.py:507-511
+        assert mel.shape == (1, 100, 938)
+        w = F5HipVocos(eng).decode(mel.cuda())
+        ref = O.vocos_decode(vsd, mel, vcfg.num_layers)
+        assert w.shape == ref.shape == (1, 256 * 937)
+        e, scale = maxerr(w, ref), float(ref.abs().max())
+        print(f"full-size vocos: wave max-abs {e:.2e} of max |wave| {scale:.2e}")
+        assert e < 1e-4 * max(1.0, scale)
+        w2 = eng.vocos_decode(mel.permute(0, 2, 1).contiguous().cuda(), channel_major=False)  # the layout bench.py hands over
+        assert torch.equal(w, w2)
+    finally:
+        eng.close()
+
+
+def test_hip_istft_against_the_reference_conv_istft_fixture(engines):
+    """istft_frames_kernel + istft_ola_kernel (the head of f5hip_vocos_decode) against the wave the reference's own runnable conv-iSTFT
+    (runtime/triton_trtllm/scripts/conv_stft.py:193-234) produced for the complex spectrogram in tests/golden/istft_conv_reference.npz."""
+    g = gold("istft_conv_reference")
+    spec = torch.complex(torch.from_numpy(g["spec_re"]), torch.from_numpy(g["spec_im"]))  # [1, 513, T]
+    b, nbin, T = spec.shape
+    assert nbin == 513
+    logits = torch.zeros(b, T, 1028)
+    logits[:, :, :513] = spec.abs().clamp_min(1e-30).log().permute(0, 2, 1)
+    logits[:, :, 513:1026] = spec.angle().permute(0, 2, 1)
+    eng = engines("tiny", 1, vocos=True)
+    w = eng.istft(logits.cuda())
+    ref = g["wav"][:, :256 * (T - 1)]
+    assert w.shape == ref.shape
+    assert maxerr(w, ref) < 5e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_configs2_shaped_batch_golden():
+    """BASELINE.json configs[2] / [3] shape (a batch of fixed-length prompts through the packed cond | uncond schedule, NFE 32) at the full
+    model size: 4 distinct utterances against the golden minted by the reference's own CFM.sample (oracle/make_golden.py base_v1_cfg3_b4),
+    then the same 4 utterances inside a batch of 32 (rows 0..3 of the B = 32 packed schedule that bench.py --batch 32 --nfe 32 times;
+    fixed-length batches have no cross-row coupling, so those rows must reproduce the golden as well)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["base_v1_cfg3_b4"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    g = gold("base_v1_cfg3_b4")
+    try:
+        model = F5HipCFM(eng, precision="fp16x3")
+        out, traj = model.sample(wav.cuda(), text, duration, **c["kw"])
+        e = maxerr(out[:, 468:], g["out"][:, 468:])
+        print(f"configs[2]-shaped B=4 NFE=32 fp16x3: generated-mel max-abs {e:.2e}")
+        assert e < MEL_TOL and maxerr(traj[1], g["traj_1"]) < MEL_TOL
+        wav32, text32 = wav.repeat(8, 1), text.repeat(8, 1)
+        out32, _ = model.sample(wav32.cuda(), text32, duration, **c["kw"])
+        e32 = maxerr(out32[:4, 468:], g["out"][:, 468:])
+        print(f"the same utterances as rows 0..3 of B=32: {e32:.2e}")
+        assert e32 < MEL_TOL
+        assert maxerr(out32[28:, 468:], g["out"][:, 468:]) < MEL_TOL  # and as the last four rows (other tiles of the 256-row GEMM tiling)
+    finally:
+        eng.close()
+
+
+def test_weights_reloaded_into_a_live_context():
+    """the per-step time-embedding / AdaLN tables are cached on the time grid; reloading weights into a context that
+    has already sampled must not reuse them.  Seed-2 weights loaded over seed-1 weights == a fresh seed-2 engine, bit for bit."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    cfg = config.DIT_TINY
+    wav = synth.synth_wave(256 * 40, seed=3)
+    text = synth.synth_text_ids(1, 30, cfg.text_num_embeds, seed=2)
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)
+    live, fresh = F5HipEngine(cfg, None, device=0), F5HipEngine(cfg, None, device=0)
+    try:
+        for use_graph in (0, 1):
+            live.set_option("use_graph", use_graph)
+            live.load_state_dict(synth.synth_dit_state_dict(cfg, seed=1))
+            a1, _ = F5HipCFM(live).sample(wav.cuda(), text, 120, **kw)
+            live.load_state_dict(synth.synth_dit_state_dict(cfg, seed=2))  # same grid, same shapes: only the weights changed
+            a2, _ = F5HipCFM(live).sample(wav.cuda(), text, 120, **kw)
+            fresh.load_state_dict(synth.synth_dit_state_dict(cfg, seed=2))
+            b2, _ = F5HipCFM(fresh).sample(wav.cuda(), text, 120, **kw)
+            assert not torch.equal(a1, a2)
+            assert torch.equal(a2, b2), float((a2 - b2).abs().max())
+        ref, _ = O.cfm_sample(synth.synth_dit_state_dict(cfg, seed=2), cfg, wav, text, 120, **kw)
+        assert maxerr(a2, ref) < TIGHT
+    finally:
+        live.close()
+        fresh.close()
+
+
+def test_sample_enqueues_and_returns(engines):
+    """include/f5hip.h: the entry points enqueue and return.  With the NFE loop replayed as a graph the host is back long before the GPU
+    has finished, and the stream is still busy at that moment."""
+    import time
+
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1)
+    eng.set_option("use_graph", 1)
+    try:
+        B = 8
+        wav = synth.synth_wave(256 * 100, seed=4, batch=B).cuda()
+        text = synth.synth_text_ids(B, 60, cfg.text_num_embeds, seed=5)
+        kw = dict(steps=64, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+        model = F5HipCFM(eng, precision="fp16x3")
+        model.sample(wav, text, 600, **kw)  # workspace + graph capture
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream()
+        t0 = time.perf_counter()
+        out, _ = model.sample(wav, text, 600, **kw)
+        t_host = time.perf_counter() - t0
+        busy = not st.query()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        print(f"host returned after {1e3 * t_host:.2f} ms, GPU finished after {1e3 * t_all:.2f} ms")
+        assert busy and t_host < 0.5 * t_all
+        assert bool(torch.isfinite(out).all())
+    finally:
+        eng.set_option("use_graph", 0)
+
+
+def test_four_threads_share_one_context(engines):
+    """The reference calls sample() from a thread pool (utils_infer.py:540-543).  Four threads on one context: every result bit-identical
+    to the same call made alone (the calls of a context are ordered on the GPU, their host work overlaps)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1)
+    model = F5HipCFM(eng, precision="fp16x3")
+    jobs = []
+    for i in range(8):
+        wav = synth.synth_wave(256 * (30 + 3 * i), seed=20 + i)
+        text = synth.synth_text_ids(1, 20 + i, cfg.text_num_embeds, seed=30 + i)
+        jobs.append((wav, text, 100 + 7 * i, dict(steps=4 + (i % 3), cfg_strength=2.0, sway_sampling_coef=-1.0, seed=40 + i)))
+
+    def one(j):
+        wav, text, dur, kw = j
+        with torch.cuda.device(0):
+            out, _ = model.sample(wav.cuda(), text, dur, **kw)
+            return out.cpu()
+
+    alone = [one(j) for j in jobs]
+    for _ in range(3):
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            together = list(pool.map(one, jobs))
+        for a, b in zip(alone, together):
+            assert torch.equal(a, b)
+
+
+# ---- the pipelined block GEMM (csrc/gemm_pp.h) on the GPU ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [50, 51, 55, 56, 59])  # the tiles pick_pp_variant() can choose
+@pytest.mark.parametrize("seqs", [2, 8])
+def test_pp_qkv_epilogue_equals_generic_kernel_on_the_gpu(engines, variant, seqs):
+    """The fused q|k|v projection through every production tile of the pipelined kernel against the generic kernel of gemm.h (GPU-verified
+    against the reference goldens since round 1): every q / k value to fp32 rounding, V^T byte for byte, three launches each (a race would
+    show as run-to-run differences; round 2 found one in the 4-wave two-per-CU tiles this way — they are not used by the engine)."""
+    import ctypes as C
+
+    from f5_tts_amd import binding
+
+    eng = engines("tiny", 1)
+    ms, diff = C.c_double(), C.c_int64()
+    for _ in range(3):
+        st = eng.lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS["fp16x3"], variant, seqs, 1406, 1024, 2, 1, C.byref(ms), C.byref(diff))
+        assert st == 0 and diff.value == 0, (variant, seqs, st, diff.value)
+
+
+def test_full_size_runs_are_bit_reproducible():
+    """F5-TTS Base, B = 1 (two concurrent CFG chains, graph replay) and B = 4 (the 256x128 tiles): five calls, one result, bit for bit."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["base_v1_cfg1"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    try:
+        model = F5HipCFM(eng, precision="fp16x3")
+        for use_graph in (0, 1):
+            eng.set_option("use_graph", use_graph)
+            kw = dict(c["kw"], steps=4)
+            first, _ = model.sample(wav.cuda(), text, duration, **kw)
+            for _ in range(4):
+                again, _ = model.sample(wav.cuda(), text, duration, **kw)
+                assert torch.equal(first, again)
+        eng.set_option("use_graph", 0)
+        kw = dict(c["kw"], steps=2)
+        w4, t4 = wav.repeat(4, 1).cuda(), text.repeat(4, 1)
+        first, _ = model.sample(w4, t4, duration, **kw)
+        for _ in range(3):
+            again, _ = model.sample(w4, t4, duration, **kw)
+            assert torch.equal(first, again)
+    finally:
+        eng.close()

@@ -326,81 +326,6 @@ def test_emulated_library_rejects_what_the_real_one_rejects(emu_lib):
     emu_lib.f5hip_bigvgan_destroy(ctx)
 
 
-# ---- stream-K GEMM with the reduce-scattered epilogue (csrc/gemm_skrs.h): all workgroups alive at once, talking through flags ----------
-def _gelu_tanh(x):
-    return 0.5 * x * (1.0 + np.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
-
-
-@pytest.mark.parametrize("case", [
-    # op, rows256, M, N, K, grid, act       what the share layout exercises
-    (OP_F16X3, 1, 1280, 1024, 160, 24, 0),  # 5 tiles per class, KT 5, shares 8/8/9: TAIL + FULL + HEAD inside one share
-    (OP_F16, 0, 300, 520, 200, 16, 0),      # 128x256 tiles, ragged M / N / K, classes with 1-2 tiles, HEAD + TAIL
-    (OP_F32, 1, 256, 1024, 224, 32, 3),     # one tile per class, KT 7 over 4 workgroups: HEAD + MIDDLE + MIDDLE + TAIL, tanh-GELU epilogue
-], ids=["x3_multi_tile_shares", "f16_ragged", "f32_middles_gelu"])
-def test_streamk_reduce_scatter_kernel(exe, tmp_path, case):
-    op, rows256, Mr, N, K, grid, act = case
-    rng = np.random.default_rng(Mr + N)
-    A = rng.standard_normal((Mr, K)).astype(np.float32)
-    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    res = rng.standard_normal((Mr, N)).astype(np.float32)
-    run(exe, tmp_path, "skrs", op, Mr, N, K, rows256, grid, 1, act, 2, 0, A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias, res=res)
-    got = np.frombuffer(open(os.path.join(tmp_path, "out.bin"), "rb").read(), dtype="<f4").reshape(Mr, N)
-    again = np.frombuffer(open(os.path.join(tmp_path, "out2.bin"), "rb").read(), dtype="<f4").reshape(Mr, N)
-    status = np.frombuffer(open(os.path.join(tmp_path, "status.bin"), "rb").read(), dtype="<i4")
-    assert status.tolist() == [0, 0, 0, 0], "flags left set / spin time-out (per launch: non-zero flags, err word)"
-    pre = operand_values(A, op) @ operand_values(W, op).T + bias
-    want = (_gelu_tanh(pre) if act == 3 else pre) + res
-    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
-    assert np.array_equal(got, again), "a second launch over the same workspace must reproduce the first bit for bit"
-
-
-def test_streamk_reduce_scatter_kernel_writes_the_next_gemms_operand_planes(exe, tmp_path):
-    """The FF1 epilogue through the stream-K kernel: bias + tanh-GELU, then the packed fp16 hi/lo operand rows FF2 reads."""
-    op, Mr, N, K, grid = OP_F16X3, 300, 256, 192, 16
-    rng = np.random.default_rng(5)
-    A = rng.standard_normal((Mr, K)).astype(np.float32)
-    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    run(exe, tmp_path, "skrs", op, Mr, N, K, 1, grid, 0, 3, 2, 1, A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias)
-    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Mr, N, OP_F16X3)
-    status = np.frombuffer(open(os.path.join(tmp_path, "status.bin"), "rb").read(), dtype="<i4")
-    assert status.tolist() == [0, 0, 0, 0]
-    want = _gelu_tanh(operand_values(A, op) @ operand_values(W, op).T + bias)
-    assert np.abs(got - want).max() < 3e-5 * max(1.0, np.abs(want).max())
-    assert open(os.path.join(tmp_path, "out.bin"), "rb").read() == open(os.path.join(tmp_path, "out2.bin"), "rb").read()
-
-
-@pytest.mark.parametrize("special", [1, 2])
-def test_specialised_epilogues_equal_the_generic_one(exe, tmp_path, special):
-    """EpiFF1 / EpiGateRes (gemm.h: the two DiT shapes with every run-time decision of EpiStore fixed at compile time) through the
-    stream-K kernel against EpiStore configured the same way."""
-    op, Mr, N, K, grid = OP_F16X3, 300, 256, 192, 16
-    rng = np.random.default_rng(special)
-    A = rng.standard_normal((Mr, K)).astype(np.float32)
-    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    bias = rng.standard_normal(N).astype(np.float32)
-    files = dict(A=operand_bytes(A, op), W=operand_bytes(W, op), bias=bias)
-    if special == 1:
-        args = (op, Mr, N, K, 1, grid, 0, 3, 1, 1)  # GELU, packed operand output
-    else:
-        files.update(res=rng.standard_normal((Mr, N)).astype(np.float32), gate=rng.standard_normal(N).astype(np.float32),
-                     rowmask=(rng.random(Mr) > 0.3).astype(np.uint8))
-        args = (op, Mr, N, K, 1, grid, 1, 0, 1, 0)
-    run(exe, tmp_path, "skrs", *args, 0, **files)
-    generic = open(os.path.join(tmp_path, "out.bin"), "rb").read()
-    run(exe, tmp_path, "skrs", *args, special, **files)
-    fast = open(os.path.join(tmp_path, "out.bin"), "rb").read()
-    if special == 1:
-        assert generic == fast
-    else:
-        a, b = np.frombuffer(generic, dtype="<f4"), np.frombuffer(fast, dtype="<f4")
-        assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()  # an fma contraction may differ by one rounding
-        pre = (operand_values(A, op) @ operand_values(W, op).T + bias) * files["gate"]
-        want = np.where(files["rowmask"][:, None] != 0, pre, 0.0) + files["res"]
-        assert np.abs(b.reshape(Mr, N) - want).max() < 3e-5 * np.abs(want).max()
-
-
 # ---- flash attention (csrc/attention_kernel.h): the GPU-proven kernel through the shim, then its key-split variant ---------------------
 def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None):
     bh = Bp * heads
@@ -458,7 +383,7 @@ def engine_emu_lib():
     csrc, emu = os.path.join(ROOT, "f5-tts_amd", "csrc"), os.path.join(ROOT, "tests", "hipemu")
     deps = [os.path.join(emu, "hipemu.h"), os.path.join(ROOT, "include", "f5hip.h")] + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")]
     objs = []
-    for src in ("gemm.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp"):
+    for src in ("gemm.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp", "microbench.cpp"):
         obj = os.path.join(out_dir, src + ".o")
         objs.append(obj)
         sp = os.path.join(csrc, src)
@@ -510,15 +435,13 @@ def emu_engine(engine_emu_lib, monkeypatch):
         eng.close()
 
 
-def test_engine_on_the_shim_matches_the_oracle_and_the_experimental_switches_change_nothing(emu_engine, capfd, monkeypatch):
+def test_engine_on_the_shim_matches_the_oracle_and_the_schedule_switches_change_nothing(emu_engine):
     """The tiny DiT through api.cpp and every kernel translation unit on the CPU: fp32 against the oracle (what smoke() checks on the
-    GPU), then fp16x3 with each switch written without GPU minutes — stream-K block GEMMs through the real dispatch (both tile shapes,
-    the branch-free epilogues, one chain / two chains), key-split attention — against the default path."""
+    GPU), then fp16x3 with each schedule switch (one chain / two chains, key-split attention) against the default path."""
     from f5_tts_amd import config, synth
     from f5_tts_amd.engine import F5HipCFM
     from oracle import f5_oracle as O
 
-    monkeypatch.setenv("F5HIP_SK_TRACE", "1")
     cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
     sd, vsd = synth.synth_dit_state_dict(cfg, seed=1), synth.synth_vocos_state_dict(vcfg, seed=1)
     eng = emu_engine(cfg, vcfg)
@@ -536,24 +459,13 @@ def test_engine_on_the_shim_matches_the_oracle_and_the_experimental_switches_cha
     model = F5HipCFM(eng, precision="fp16x3")
     base, _ = model.sample(wav, text, dur, **kw)
     assert (base - ref).abs().max().item() < 5e-4
-    capfd.readouterr()
-    eng.set_option("gemm_streamk_grid", 16)
-    # (options, rows per launch, stream-K launches expected: 2 blocks x the block GEMMs whose tile count suits the 16-workgroup grid)
-    cases = [(dict(gemm_streamk=42, branch_streams=0), 800, 8), (dict(gemm_streamk=43, attn_kv_split=3, branch_streams=0), 800, 4),
-             (dict(gemm_streamk=42, gemm_streamk_split=1, gemm_streamk_grid=32, attn_kv_split=2, branch_streams=1), 400, 8)]
-    for i, (opts, rows, launches) in enumerate(cases):
+    for opts in (dict(branch_streams=0), dict(attn_kv_split=3, branch_streams=0), dict(attn_kv_split=2, branch_streams=1)):
         for k, v in opts.items():
             eng.set_option(k, v)
         got, _ = model.sample(wav, text, dur, **kw)
         assert (got - base).abs().max().item() < 2e-4, opts
-        trace = capfd.readouterr().err
-        assert trace.count(f"skrs M={rows} ") == launches, (opts, trace)  # the real dispatch took the stream-K path (incl. EpiFF1 / EpiGateRes)
-        if i == 0:
-            again, _ = model.sample(wav, text, dur, **kw)
-            assert torch.equal(got, again)
-            capfd.readouterr()
         for k in opts:
-            eng.set_option(k, {"branch_streams": -1, "attn_kv_split": 1, "gemm_streamk_grid": 16}.get(k, 0))
+            eng.set_option(k, {"branch_streams": -1, "attn_kv_split": 1}[k])
 
 
 def test_qkv_epilogue_fast_index_path_equals_the_general_path(tmp_path):

@@ -124,3 +124,36 @@ def test_build_edit_condition_matches_the_reference_script():
     assert cond.shape[1] == 300 - (round(1.0 * 93.75) - round(0.5 * 93.75)) - (round(2.6 * 93.75) - round(2.0 * 93.75)) + round(0.3 * 93.75) + round(0.9 * 93.75)
     cond2, mask2 = I.build_edit_condition(mel, parts)  # spans keep their own length
     assert cond2.shape[1] == 300 and int((~mask2).sum()) == (round(1.0 * 93.75) - round(0.5 * 93.75)) + (round(2.6 * 93.75) - round(2.0 * 93.75))
+
+
+def test_load_model_arch_dict_needs_its_backbone_class(monkeypatch):
+    """the reference's load_model(model_cls, model_cfg, ...) (utils_infer.py:238) names the backbone class; an arch dict
+    alone must not silently become a DiT.  Checked on the config that reaches the engine constructor (no GPU needed)."""
+    from f5_tts_amd import infer as I
+
+    seen = {}
+
+    class FakeEngine:
+        def __init__(self, cfg, vocos_cfg, device=0):
+            seen["cfg"], seen["vocos"] = cfg, vocos_cfg
+
+        def finalize(self):
+            seen["finalized"] = True
+
+    monkeypatch.setattr(I, "F5HipEngine", FakeEngine)
+    monkeypatch.setattr(I, "F5HipCFM", lambda engine, **kw: engine)
+    e2_arch = dict(dim=1024, depth=24, heads=16, ff_mult=4, text_mask_padding=False, pe_attn_head=1)  # configs/E2TTS_Base.yaml:25-31
+    with pytest.raises(ValueError, match="model_cls"):
+        I.load_model(e2_arch, None)
+    I.load_model(e2_arch, None, model_cls="UNetT")
+    assert seen["cfg"].backbone == "UNetT" and seen["cfg"].text_dim == 100 and seen["cfg"].conv_layers == 0 and seen["cfg"].depth == 24
+
+    class DiT:  # a class object works like the reference's first argument
+        pass
+
+    I.load_model(dict(dim=1024, depth=22, heads=16, ff_mult=2, text_dim=512, conv_layers=4), None, model_cls=DiT)
+    assert seen["cfg"].backbone == "DiT" and seen["cfg"].text_dim == 512 and seen["vocos"] is not None
+    # mel_spec_type="bigvgan": no Vocos slots to wait for — the context is finalised by load_model itself
+    seen.clear()
+    I.load_model("E2TTS_Base", None, mel_spec_type="bigvgan")
+    assert seen["vocos"] is None and seen.get("finalized")

@@ -13,7 +13,13 @@ from f5_tts_amd import config  # noqa: E402
 from f5_tts_amd.binding import PRECISIONS  # noqa: E402
 from f5_tts_amd.engine import F5HipEngine  # noqa: E402
 
-VARIANTS = {-1: "auto", 0: "64x128", 1: "128x64", 2: "128x128", 3: "256x128", 4: "128x256", 5: "256x256", 6: "glds128x64", 7: "glds128x128", 8: "64x64", 10: "128x192", 13: "glds256x128w4", 21: "glds256sq_w8a", 22: "glds256sq_w8b", 23: "glds256sq_prio", 26: "glds128x64w2", 27: "glds128x64w2s2", 28: "glds128x128s2", 29: "glds64x128w2", 30: "glds256x128w8", 31: "glds128x256w8", 40: "sk256x128", 41: "sk128x256", 42: "skrs256x128", 43: "skrs128x256", 24: "glds128x64_2of3", 25: "glds256sq_2of3", 14: "glds128x256w4", 9: "noLoad", 10: "noLdsSt", 11: "noLd+noSt", 12: "noMFMA", 15: "noAll", 17: "s:noEpi", 18: "s:noMFMA", 19: "s:noAll", 20: "s:noStage"}
+VARIANTS = {-1: "auto", 0: "64x128", 1: "128x64", 2: "128x128", 6: "glds128x64", 8: "64x64",
+            50: "pp256x256w8", 51: "pp256x128w8", 52: "pp128x256w8", 53: "pp192x64w4", 54: "pp192x128w4", 55: "pp192x128w8", 56: "pp192x192w4",
+            57: "pp128x128s3", 58: "pp128x128s2", 59: "pp96x128w4", 60: "pp256x128w4",
+            61: "pp128x192s2", 62: "pp192x128s2", 63: "pp96x128s2", 64: "pp192x64s2"}
+for _id in (50, 56, 59):
+    for _c, _n in ((1, "noEpi"), (2, "noStore"), (4, "noDMA"), (8, "noMFMA"), (12, "noDMA+MFMA"), (13, "reads+barriers")):
+        VARIANTS[1000 * _c + _id] = f"{VARIANTS[_id]}:{_n}"
 
 
 def main():
@@ -31,6 +37,16 @@ def main():
         print(f"gemm {prec} {VARIANTS[v]} M={M} N={N} K={K}: st={st} {ms.value * 1e3:.1f} us {2.0 * M * N * K / ms.value / 1e9:.1f} TF")
         eng.close()
         return
+    if what == "qkv":  # qkv <prec> <seqs> <nseq> <variants comma> [iters]: time + byte comparison with the generic kernel's planes
+        prec, seqs, nseq = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+        diff = C.c_int64()
+        for v in (int(x) for x in sys.argv[5].split(",")):
+            for rep in range(3):
+                st = lib.f5hip_bench_qkv(ctx, PRECISIONS[prec], v, seqs, nseq, 1024, iters, 1, C.byref(ms), C.byref(diff))
+                print(f"qkv {prec} {VARIANTS.get(v, v)} seqs={seqs} nseq={nseq}: st={st} {ms.value * 1e3:.1f} us differing halves {diff.value}", flush=True)
+        eng.close()
+        return
     if what == "oneattn":  # oneattn <prec> <batch2> <n> [iters]
         prec, b2, n = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
         iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
@@ -41,6 +57,8 @@ def main():
     if what in ("gemm", "all"):
         shapes = [(2812, 3072, 1024, "QKV  B=1"), (2812, 1024, 1024, "out  B=1"), (2812, 2048, 1024, "FF1  B=1"), (2812, 1024, 2048, "FF2  B=1"),
                   (22496, 3072, 1024, "QKV  B=8"), (22496, 1024, 2048, "FF2  B=8"), (89984, 2048, 1024, "FF1  B=32")]
+        if os.environ.get("KB_SHAPES"):  # "M,N,K;M,N,K;..."
+            shapes = [tuple(int(x) for x in sh.split(",")) + ("custom  ",) for sh in os.environ["KB_SHAPES"].split(";")]
         for prec in os.environ.get("KB_PRECS", "fp16x3,fp16").split(","):
             for M, N, K, tag in shapes:
                 if prec == "fp32" and M > 30000:

@@ -16,14 +16,23 @@
     if ((int)_s != 0) { printf("%s failed: %d (line %d)\n", #x, (int)_s, __LINE__); return 1; } \
   } while (0)
 
+__global__ void fill_kernel(__half* x, size_t n, unsigned seed, float scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    x[i] = __float2half(scale * ((float)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f));
+  }
+}
+
 static int run(hipblasLtHandle_t h, int M, int N, int K, const char* tag) {
   // row-major out[M,N] = A[M,K] W[N,K]^T  ==  column-major out^T[N,M] = W^T-as-stored(op T)[N,K] . A-as-stored[K,M]
   __half *A, *W, *C;
   CK(hipMalloc(&A, (size_t)M * K * 2));
   CK(hipMalloc(&W, (size_t)N * K * 2));
   CK(hipMalloc(&C, (size_t)M * N * 2));
-  CK(hipMemset(A, 0, (size_t)M * K * 2));
-  CK(hipMemset(W, 0, (size_t)N * K * 2));
+  fill_kernel<<<1024, 256>>>(A, (size_t)M * K, 1u, 1.0f);  // full-range random operands: zero fill runs at a higher clock (DVFS) and flatters the library
+  fill_kernel<<<1024, 256>>>(W, (size_t)N * K, 2u, 0.05f);
+  CK(hipDeviceSynchronize());
   hipblasLtMatmulDesc_t desc;
   hipblasLtMatrixLayout_t la, lb, lc;
   CK(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
