@@ -347,6 +347,12 @@ const void* wsel(int op, const float* w32, const f16* hi, const f16* pk) {
   return op == OP_F32 ? (const void*)w32 : op == OP_F16 ? (const void*)hi : (const void*)pk;
 }
 
+// fp16x3 mode: are the attention SCORES computed from hi/lo-split q and k (3 MFMAs per product)?  Only on request (attn_impl 2: every
+// attention operand split; 4: q, k split, P and V plain — the default of round 1).  The default since round 2 is plain fp16 q, k, P, V:
+// measured on every reference-minted golden (tools/attn_precision_check.py) the generated mel moves from <= 1.4e-4 to
+// <= 2.9e-4 max-abs against a 1e-3 tolerance, for a third of the attention's MFMA work.
+bool split_qk(const f5hip_ctx* ctx, int op) { return op == OP_F16X3 && (ctx->attn_impl == 2 || ctx->attn_impl == 4); }
+
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
 
 // ---- finalize: derived layouts -------------------------------------------------------------------
@@ -845,7 +851,7 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
       } else {
         // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
         // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
-        const bool x3 = op == OP_F16X3 && ctx->attn_impl != 3;
+        const bool x3 = split_qk(ctx, op);
         const int ldv = (n + 7) & ~7;
         const int64_t voff = (int64_t)s0 * inner * ldv;
         HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
@@ -880,7 +886,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     e.ldvt = (ns + 7) & ~7;
     const int64_t voff = (int64_t)s0 * inner * e.ldvt;
     e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-    if (op == OP_F16X3 && ctx->attn_impl != 3) {  // lo planes only for what the flash kernel will read
+    if (split_qk(ctx, op)) {  // lo planes only for what the flash kernel will read
       e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
       if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
     }
@@ -1271,7 +1277,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     } else {
       e.ldvt = (ns + 7) & ~7;
       e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>();
-      if (op == OP_F16X3 && ctx->attn_impl != 3) {
+      if (split_qk(ctx, op)) {
         e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
         if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
       }
@@ -1326,9 +1332,9 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
       Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
       HIPCHK(launch_qk_norm_rope(ctx->q32.as<float>(), ctx->k32.as<float>(), bw.qn, bw.kn, ctx->rope.as<float>(), (int64_t)S * H * ns, ns, H, dh, -1,
                                  1.0f / sqrtf((float)dh), 1e-6f, exact_attn ? nullptr : ctx->q16.as<f16>(),
-                                 (!exact_attn && op == OP_F16X3 && ctx->attn_impl != 3) ? ctx->q16_lo.as<f16>() : nullptr,
+                                 (!exact_attn && split_qk(ctx, op)) ? ctx->q16_lo.as<f16>() : nullptr,
                                  exact_attn ? nullptr : ctx->k16.as<f16>(),
-                                 (!exact_attn && op == OP_F16X3 && ctx->attn_impl != 3) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));
+                                 (!exact_attn && split_qk(ctx, op)) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));
     }
     CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, op == OP_F32 ? reinterpret_cast<float*>(o_base) : nullptr,
                       op != OP_F32 ? reinterpret_cast<f16*>(o_base) : nullptr, pk ? reinterpret_cast<f16*>(o_base) + 32 : nullptr, pk, ldO, st, kvlen2, n));
@@ -1627,7 +1633,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   CHK(call_begin(ctx, st));
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
-  // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 modes -> flash with the mode's operands), 1 force materialised,
+  // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 / fp16x3 -> flash attention with plain fp16 operands), 1 force materialised,
+  // 4 flash with split q, k and plain P, V (fp16x3),
   // 2 flash with every operand split in fp16x3 mode, 3 flash with plain fp16 operands even in fp16x3 mode
   const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");

@@ -217,8 +217,8 @@ struct f5hip_ctx {
   // options / measurement
   bool use_graph = false;
   bool profile = false;
-  int attn_impl = 0;  // 0 auto (fp32: materialised scores; fp16: flash; fp16x3: flash, split q/k + plain P/V), 1 materialised fp32,
-                      // 2 flash with all operands split (fp16x3), 3 flash with plain fp16 operands
+  int attn_impl = 0;  // 0 auto (fp32: materialised scores; fp16 / fp16x3: flash attention, plain fp16 operands), 1 materialised fp32,
+                      // 2 flash with all operands split (fp16x3), 3 = 0 for the fp16 modes, 4 flash with split q/k + plain P/V (fp16x3)
   KStat stats[KC_COUNT];
   std::vector<ProfRec> prof;
 

@@ -25,7 +25,6 @@ struct GemmCore {
   int M, N, K;
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
   int w_rows;         // rows of W that exist (<= N)
-  int sk_exp;         // experiment switches (tools only)
   int group_m;        // tile rasterisation: row-tiles per group (0/1 = channel tiles fastest over the whole grid), see gemm_kernel
 };
 

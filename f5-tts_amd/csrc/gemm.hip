@@ -176,18 +176,6 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
     attr_done = true;
   }
   dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, 1);
-  static const int exp_env = [] { const char* v = getenv("F5HIP_PP_EXP"); return v ? atoi(v) : 0; }();
-  static const int pad_env = [] { const char* v = getenv("F5HIP_PP_LDS_PAD"); return v ? atoi(v) : 0; }();
-  if (exp_env || pad_env) {
-    GemmCore g2 = g;
-    g2.sk_exp = exp_env;
-    Epi e2 = e;
-    if constexpr (std::is_same<Epi, PpEpiQKV>::value) e2.exp = exp_env;
-    const int lds2 = lds + pad_env <= 160 * 1024 ? lds + pad_env : lds;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN), lds2, s, g2, e2);
-    return hipGetLastError();
-  }
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;  // which kernel ran (tests, tuning)
   if (trace) fprintf(stderr, "gemm_pp variant %d (%dx%d) nsplit %d M=%d N=%d K=%d grid %u\n", ID, C::BM, C::BN, NSPLIT, g.M, g.N, g.K, grid.x);
   hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN), lds, s, g, e);
@@ -218,7 +206,7 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
 
 // Tile choice.  A launch costs rounds x (time of one workgroup), so prefer the tile whose workgroup count fills whole rounds of the CUs
 // with the largest wave tiles; measured tables: DESIGN.md section 4 (tools/kernel_bench.py, profiles/r02*).
-int pick_pp_variant(const GemmCore& g) {
+int pick_pp_variant(const GemmCore& g, bool qkv = false) {
   static const int forced = [] { const char* e = getenv("F5HIP_PP_VARIANT"); return e ? atoi(e) : -1; }();  // tuning knob; 0 = never use the pipelined kernel
   if (forced >= 0) return forced;
   static const int f3072 = [] { const char* e = getenv("F5HIP_PP_VARIANT_N3072"); return e ? atoi(e) : -1; }();  // per-shape tuning knobs (tools/)
@@ -238,7 +226,10 @@ int pick_pp_variant(const GemmCore& g) {
   // (NOT the 4-wave, 2-stage tiles that fit two workgroups per CU — 58 / 62 / 63 / 64, 3-8 % faster here: with two of them co-resident
   // the fused q|k|v epilogue's rope values came out wrong in a few hundred outputs per launch, run-to-run different, clean as soon as a
   // CU holds one workgroup; unexplained, so they stay microbenchmark-only.  DESIGN.md section 4, tools/r2_call7.sh)
-  if (g.M >= 4096) return 51;
+  if (g.M >= 4096) return qkv ? 55 : 51;
+  // the fused q|k|v projection (rope + scatter epilogue, tools/kernel_bench.py qkv): 192x192 in the one-round regime (63 us against 73
+  // for 192x128 / 8 waves), 192x128 / 8 waves for one CFG chain (39 against 43-56) and for a few rounds (230 us at M = 11k against 244)
+  if (qkv && (g.M < 2048 || g.M >= 4096)) return 55;
   if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : 59;
   return g.N >= 3072 ? 55 : 59;
 }
@@ -323,11 +314,11 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
   e.fast = 0;
   if (!generic) epi_qkv_prepare(e, g0.M);  // fast = 1 when its preconditions hold
   // the pipelined kernel: half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour
-  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3) && e.dh == 64 && !e.qk_raw && e.q16 && !e.q32 &&
+  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
       (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
     GemmCore g = g0;
     if (g.group_m == 0) g.group_m = g.M >= 8192 ? 4 : 1;
-    const int variant = want >= 50 ? want : pick_pp_variant(g);
+    const int variant = want >= 50 ? want : pick_pp_variant(g, true);
     const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = (g.M + e.nseq - 1) / e.nseq;
     const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
     if (variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000) {

@@ -18,6 +18,7 @@
 //     descriptor (no branches), outputs leave as 16-byte stores (v_permlane32_swap pairs the two half-waves' 4-channel groups).
 // Fragment and accumulator layouts are those of gemm.h (weights on the MFMA "A" side: a lane owns 4 consecutive channels of one row).
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "gemm.h"
@@ -226,7 +227,7 @@ struct PpEpiQKV {
   int nseq_shift, inner;
   int M, N;
   uint32_t qk_bytes, vt_bytes;  // sizes of the q / k planes and of the V^T planes in bytes (< 2^31)
-  int exp;                      // experiment switches (tools): bit 0 = scalar V^T stores
+
   template <int TM, int TN>
   __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
     const int h = lane >> 5, r = lane & 31;
@@ -238,7 +239,7 @@ struct PpEpiQKV {
       bp[j] = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift);
       pos[j] = m - bp[j] * nseq;
     }
-    const bool pair_ok = !(nseq & 1) && !(pos_off & 1) && !(exp & 1);
+    const bool pair_ok = !(nseq & 1) && !(pos_off & 1);
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int nb = n_w + 32 * i;
@@ -258,24 +259,22 @@ struct PpEpiQKV {
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           const bool ok = m_w + 32 * j + r < M;
+          // (cos, sin) of this lane's two channel pairs per quad; always fetched (pos < nseq for every m, so the address is valid even for
+          // rows >= M), replaced by the identity rotation for heads outside pe_attn_head: one code path, no value defined on one branch only
           float4 cs[4];
-          if (rope) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              cs[q] = *reinterpret_cast<const float4*>(rope_cs + (pos[j] * 32 + ((d0 + 8 * q + 4 * h) >> 1)) * 2);  // pos < nseq for every m
-#ifndef F5_HIPEMU
-            if (exp & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+          for (int q = 0; q < 4; ++q) cs[q] = *reinterpret_cast<const float4*>(rope_cs + (pos[j] * 32 + ((d0 + 8 * q + 4 * h) >> 1)) * 2);
+          if (!rope) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cs[q] = make_float4(1.f, 0.f, 1.f, 0.f);
           }
           uint32_t hi[4][2], lo[4][2];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
-            if (rope) {
-              const float a0 = x[0] * cs[q].x - x[1] * cs[q].y, a1 = x[1] * cs[q].x + x[0] * cs[q].y;
-              const float a2 = x[2] * cs[q].z - x[3] * cs[q].w, a3 = x[3] * cs[q].z + x[2] * cs[q].w;
-              x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
-            }
+            const float a0 = x[0] * cs[q].x - x[1] * cs[q].y, a1 = x[1] * cs[q].x + x[0] * cs[q].y;
+            const float a2 = x[2] * cs[q].z - x[3] * cs[q].w, a3 = x[3] * cs[q].z + x[2] * cs[q].w;
+            x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
             if (which == 0) { x[0] *= sc; x[1] *= sc; x[2] *= sc; x[3] *= sc; }
             pp::split4(x, hi[q], lo[q]);
           }
@@ -507,7 +506,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi
   }
   ktile(std::integral_constant<int, 2>{}, t, soff, 0u, 0);
 
-  if (g.sk_exp & 2) pp::wg_barrier();
   if constexpr (ABL & 1) {
 #ifndef F5_HIPEMU
 #pragma unroll

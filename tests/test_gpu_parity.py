@@ -263,12 +263,15 @@ def test_flash_attention_equals_materialised_attention(engines):
         exact, _ = model.sample(wav.cuda(), text, 333, **kw)
         eng.set_option("attn_impl", 2)  # every attention operand hi/lo split
         flash, _ = model.sample(wav.cuda(), text, 333, **kw)
-        eng.set_option("attn_impl", 0)  # default: split q/k, plain fp16 P/V
+        eng.set_option("attn_impl", 4)  # split q/k, plain fp16 P/V (the default of round 1)
         mixed, _ = model.sample(wav.cuda(), text, 333, **kw)
+        eng.set_option("attn_impl", 0)  # default: plain fp16 q, k, P, V
+        plain, _ = model.sample(wav.cuda(), text, 333, **kw)
     finally:
         eng.set_option("attn_impl", 0)
     assert maxerr(flash, exact.cpu()) < 5e-5
     assert maxerr(mixed, exact.cpu()) < 2e-4
+    assert maxerr(plain, exact.cpu()) < 3e-4
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL)])
