@@ -10,24 +10,39 @@ constexpr int WAVES_PER_BLOCK = 4;
 // ---------------------------------------------------------------------------------------------
 // LayerNorm (+ affine | AdaLN modulation).  One wave per row; the row lives in registers.
 // ---------------------------------------------------------------------------------------------
-template <int VPL>  // float4 vectors per lane: D <= 64*4*VPL
+template <int VPL, bool EARLY = true>  // float4 vectors per lane: D <= 64*4*VPL
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
                                                          const float* __restrict__ weight, const float* __restrict__ bias,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          float* out32, f16* out16, f16* out16_lo, int64_t ldo, int pk16,
-                                                         int64_t ldo16, int mode) {
+                                                         int64_t ldo16, int mode, int pair16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (int64_t)row * ldx;
   float4 v[VPL];
-  float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (i * 64 + lane) * 4;
     v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
+  // the per-channel parameters do not depend on the row statistics: requested here, they arrive while the row is being reduced (a second
+  // dependent round trip to L2 otherwise — with < 3 waves per SIMD at one utterance nothing else hides it)
+  float4 pa[VPL], pb[VPL];  // (weight, bias) or (scale, shift); both pairs only in the general path below
+  const bool two = !EARLY || (weight && scale);
+  if (!two) {
+    const float* A = weight ? weight : scale;
+    const float* Bp = weight ? bias : shift;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      pa[i] = (A && c < D) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[i] = (Bp && c < D) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mean = mode == 0 ? wave_sum(sum) / (float)D : 0.f;  // RMSNorm / copy: no centring
   float sq = 0.f;
 #pragma unroll
@@ -45,28 +60,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if (c >= D) continue;
+    const bool in = c < D;  // (no early exit: the lane exchange below is executed by whole waves)
     float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
     if (weight) {
-      const float4 w = *reinterpret_cast<const float4*>(weight + c);
-      const float4 b = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 w = two ? (in ? *reinterpret_cast<const float4*>(weight + c) : make_float4(0.f, 0.f, 0.f, 0.f)) : pa[i];
+      const float4 b = two ? (bias && in ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f)) : pb[i];
       y[0] = y[0] * w.x + b.x; y[1] = y[1] * w.y + b.y; y[2] = y[2] * w.z + b.z; y[3] = y[3] * w.w + b.w;
     }
     if (scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      const float4 sc = two ? (in ? *reinterpret_cast<const float4*>(scale + c) : make_float4(0.f, 0.f, 0.f, 0.f)) : pa[i];
+      const float4 sh = two ? (in ? *reinterpret_cast<const float4*>(shift + c) : make_float4(0.f, 0.f, 0.f, 0.f)) : pb[i];
       y[0] = y[0] * (1.0f + sc.x) + sh.x; y[1] = y[1] * (1.0f + sc.y) + sh.y;
       y[2] = y[2] * (1.0f + sc.z) + sh.z; y[3] = y[3] * (1.0f + sc.w) + sh.w;
     }
     const int64_t o = (int64_t)row * ldo + c;
-    if (out32) *reinterpret_cast<float4*>(out32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+    if (out32 && in) *reinterpret_cast<float4*>(out32 + o) = make_float4(y[0], y[1], y[2], y[3]);
     if (out16) {
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { f16 h, l; split_f16(y[e], h, l); hi[e] = h; lo[e] = l; }
       const int64_t o16 = (int64_t)row * ldo16 + pk_off(c, pk16);
-      *reinterpret_cast<f16x4*>(out16 + o16) = hi;
-      if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o16) = lo;
+      if (pair16) {
+        // neighbouring lanes hold channels c .. c+3 and c+4 .. c+7: the even lane collects the 8 hi halves, the odd lane the 8 lo halves —
+        // one 16-byte store per lane instead of two 8-byte ones (the kernel is store-issue bound once its loads overlap)
+        union { f16x4 h; uint32_t u[2]; } H, L;
+        H.h = hi; L.h = lo;
+        const bool odd = lane & 1;
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)(odd ? H.u[0] : L.u[0]), 1, 64), r1 = (uint32_t)__shfl_xor((int)(odd ? H.u[1] : L.u[1]), 1, 64);
+        if (!in) {
+        } else if (!odd) *reinterpret_cast<uint4*>(out16 + o16) = make_uint4(H.u[0], H.u[1], r0, r1);
+        else if (out16_lo) *reinterpret_cast<uint4*>(out16_lo + o16 - 4) = make_uint4(r0, r1, L.u[0], L.u[1]);
+      } else if (in) {
+        *reinterpret_cast<f16x4*>(out16 + o16) = hi;
+        if (out16_lo) *reinterpret_cast<f16x4*>(out16_lo + o16) = lo;
+      }
     }
   }
 }
@@ -372,11 +399,23 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps
                             hipStream_t s, int pk16, int64_t ldo16, int mode) {
   if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
   if (ldo16 == 0) ldo16 = ldo;
+  // paired 16-byte half stores: whole pairs of 4-channel groups per row, 16-byte aligned rows
+  const int pair16 = out16 && D % 8 == 0 && ldo16 % 8 == 0 && (reinterpret_cast<uintptr_t>(out16) & 15) == 0 &&
+                     (!out16_lo || (reinterpret_cast<uintptr_t>(out16_lo) & 15) == 0);
   dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-  if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
-  else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
-  else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode);
+  // Two shapes of the same arithmetic.  Few rows (one utterance: < 3 waves per SIMD, latency-bound): parameters requested before the
+  // reduction and paired 16-byte stores, 7.24 against 7.70 ms per B = 1 sample.  Many rows (bandwidth-bound, 8 waves per SIMD hide the
+  // second round trip): the lean kernel — the early parameters cost registers and the lane exchange LDS-pipe slots, 229 against 187 ms per
+  // B = 32 sample (same box, tools/r2_call18.sh).  F5HIP_LN_LATE / F5HIP_LN_EARLY force one (A/B runs).
+  static const int forced = getenv("F5HIP_LN_LATE") ? 1 : getenv("F5HIP_LN_EARLY") ? 0 : -1;
+  const bool late = forced >= 0 ? forced == 1 : M >= 8192;
+#define F5_LN(V, E, P) hipLaunchKernelGGL((layernorm_kernel<V, E>), grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode, P)
+  if (late) {
+    if (D <= 256) F5_LN(1, false, 0); else if (D <= 512) F5_LN(2, false, 0); else if (D <= 1024) F5_LN(4, false, 0); else F5_LN(8, false, 0);
+  } else {
+    if (D <= 256) F5_LN(1, true, pair16); else if (D <= 512) F5_LN(2, true, pair16); else if (D <= 1024) F5_LN(4, true, pair16); else F5_LN(8, true, pair16);
+  }
+#undef F5_LN
   return hipGetLastError();
 }
 

@@ -129,13 +129,16 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
 //   53  192x64   4 waves of  96x32   3 stages      54  192x128  4 waves of 96x64   3 stages      55  192x128  8 waves of 96x32  3 stages
 //   56  192x192  4 waves of  96x96   3 stages      57  128x128  4 waves of 64x64   3 stages      58  128x128  4 waves of 64x64  2 stages (2 / CU)
 //   59   96x128  4 waves of  96x32   3 stages      60  256x128  4 waves of 128x64  3 stages
+//   61-64  2-stage 4-wave tiles that fit two workgroups per CU (microbenchmark only, see pick_pp_variant)
+//   65  192x128  66  96x128  67  192x64: k-split, 2 groups x 4 waves on alternate k-tiles of one output tile
 template <int ID>
 struct PpV;
-#define F5_PPV(ID, TM_, TN_, WGM_, WGN_, NS_, JG_)                                        \
+#define F5_PPV(ID, TM_, TN_, WGM_, WGN_, NS_, JG_, ...)                                   \
   template <>                                                                             \
   struct PpV<ID> {                                                                        \
     static constexpr int TM = TM_, TN = TN_, WGM = WGM_, WGN = WGN_, NS = NS_, JG = JG_;  \
     static constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;                          \
+    static constexpr int KSP = 1 __VA_ARGS__;                                             \
   }
 F5_PPV(50, 4, 2, 2, 4, 2, 1);
 F5_PPV(51, 2, 2, 4, 2, 3, 2);
@@ -152,6 +155,10 @@ F5_PPV(61, 2, 3, 2, 2, 2, 2);  // 128x192, 4 waves of 64x96, 2 stages = 80 KB: t
 F5_PPV(62, 3, 2, 2, 2, 2, 3);  // 192x128, 4 waves of 96x64, 2 stages = 80 KB
 F5_PPV(63, 3, 1, 1, 4, 2, 3);  //  96x128, 4 waves of 96x32, 2 stages = 56 KB
 F5_PPV(64, 3, 1, 2, 2, 2, 3);  // 192x64,  4 waves of 96x32, 2 stages = 64 KB
+// k-split (gemm_pp.h): two groups of 4 waves on alternate k-tiles of one output tile, 2 stages of 2 k-tiles
+F5_PPV(65, 3, 2, 2, 2, 2, 3, +1);  // 192x128, 2 x 4 waves of 96x64 = 160 KB
+F5_PPV(66, 3, 1, 1, 4, 2, 3, +1);  //  96x128, 2 x 4 waves of 96x32 = 112 KB
+F5_PPV(67, 3, 1, 2, 2, 2, 3, +1);  // 192x64,  2 x 4 waves of 96x32 = 128 KB
 #undef F5_PPV
 
 // what the pipelined kernel needs from a launch: fp16 operands whose rows are whole 128-byte k-tiles (at least 3 of them), channel
@@ -166,9 +173,14 @@ bool pp_applies(const GemmCore& g, int batch) {
 template <int NSPLIT, int ID, typename Epi, int ABL = 0>
 hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   using C = PpV<ID>;
-  constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, C::NS>();
+  constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, C::NS, C::KSP>();
   static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
-  auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL>;
+  static_assert(C::KSP == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the k-split reuses the ring");
+  if constexpr (C::KSP > 1) {  // each group needs its own whole pipeline: k-tiles split evenly, at least NS + 1 per group
+    const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
+    if (kt % C::KSP != 0 || kt / C::KSP < C::NS + 1) return hipErrorInvalidValue;
+  }
+  auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL, C::KSP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -178,7 +190,7 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, 1);
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;  // which kernel ran (tests, tuning)
   if (trace) fprintf(stderr, "gemm_pp variant %d (%dx%d) nsplit %d M=%d N=%d K=%d grid %u\n", ID, C::BM, C::BN, NSPLIT, g.M, g.N, g.K, grid.x);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN), lds, s, g, e);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN * C::KSP), lds, s, g, e);
   return hipGetLastError();
 }
 
@@ -200,6 +212,9 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
     case 62: return launch_pp_one<NSPLIT, 62, Epi>(g, e, s);
     case 63: return launch_pp_one<NSPLIT, 63, Epi>(g, e, s);
     case 64: return launch_pp_one<NSPLIT, 64, Epi>(g, e, s);
+    case 65: return launch_pp_one<NSPLIT, 65, Epi>(g, e, s);
+    case 66: return launch_pp_one<NSPLIT, 66, Epi>(g, e, s);
+    case 67: return launch_pp_one<NSPLIT, 67, Epi>(g, e, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -230,8 +245,12 @@ int pick_pp_variant(const GemmCore& g, bool qkv = false) {
   // the fused q|k|v projection (rope + scatter epilogue, tools/kernel_bench.py qkv): 192x192 in the one-round regime (63 us against 73
   // for 192x128 / 8 waves), 192x128 / 8 waves for one CFG chain (39 against 43-56) and for a few rounds (230 us at M = 11k against 244)
   if (qkv && (g.M < 2048 || g.M >= 4096)) return 55;
-  if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : 59;
-  return g.N >= 3072 ? 55 : 59;
+  // narrow outputs (out-proj, FF2; FF1 of one chain): the k-split 96x128 — two waves per SIMD on one output tile, -10 % against the 4-wave
+  // 96x128 (M = 2812: 23.9 / 39.9 us against 26.4 / 44.5; M = 1406: 20.9 / 34.0 / 23.6 against 23.5 / 39.6 / 25.8; profiles/r02c_ksplit.log).
+  // For 192x128 it measures the same as the 8 waves of 96x32 (41.0 / 41.3), so that one stays.
+  const int narrow = (g.K % 128 == 0 && g.K >= 512) ? 66 : 59;  // k-split: an even number of k-tiles, a whole pipeline per group
+  if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : narrow;
+  return g.N >= 3072 ? 55 : narrow;
 }
 
 // EpiStore configurations the block GEMMs use -> wave-tile epilogues of gemm_pp.h; returns hipErrorInvalidValue when the launch is not

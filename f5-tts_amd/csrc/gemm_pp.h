@@ -35,7 +35,7 @@ namespace pp {
 template <int N>
 inline void wait_vmcnt() {}  // the shim's LDS-DMA is synchronous (what it CAN show: a refill racing the reads of the stage it overwrites)
 inline void wg_barrier() { __syncthreads(); }
-inline uint32_t lds_base(char*) { return 0; }
+inline uint32_t lds_base(char* smem) { return (uint32_t)(smem - hipemu::dyn_lds()); }
 template <int IMM>
 inline uint4 lds_read_b128(uint32_t addr) { uint4 v; memcpy(&v, hipemu::dyn_lds() + addr + IMM, 16); return v; }
 inline void lds_wait() {}
@@ -330,30 +330,36 @@ struct PpEpiQKV {
 };
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------
-template <int TM, int TN, int WGM, int WGN, int NS>
+template <int TM, int TN, int WGM, int WGN, int NS, int KSP = 1>
 constexpr int gemm_pp_lds_bytes() {
-  return NS * 32 * (WGM * TM + WGN * TN) * GEMM_KTB;
+  return NS * KSP * 32 * (WGM * TM + WGN * TN) * GEMM_KTB;
 }
 
 // TM x TN 32x32 tiles per wave, WGM x WGN waves, ring of NS stages, JG activation tiles per fragment slot (TM % JG == 0).
+// KSP = 2 ("k-split"): TWO groups of WGM x WGN waves work on the SAME output tile, group g on the k-tiles 2 s + g — two waves per SIMD with
+// the large wave tiles of a 4-wave workgroup: one group's LDS-DMA issue, fragment reads and waits hide behind the other's MFMAs, and the
+// epilogue is shared (the groups exchange the partial sums of the tiles they do not finish through the idle ring).  For the one-round
+// launches of a single utterance, where a CU holds one workgroup and nothing else covers those gaps.
 // ABL (microbenchmark ablations): bit 0 = no epilogue, bit 2 = no LDS-DMA after the prologue, bit 3 = no MFMAs.
-template <typename T, int NSPLIT, int TM, int TN, int WGM, int WGN, int NS, int JG, typename Epi, int ABL = 0>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi epi) {
-  constexpr int NW = WGM * WGN;
+template <typename T, int NSPLIT, int TM, int TN, int WGM, int WGN, int NS, int JG, typename Epi, int ABL = 0, int KSP = 1>
+__global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore g, Epi epi) {
+  constexpr int NW = WGM * WGN;  // waves of one group
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
   constexpr int KS = NPL == 2 ? 2 : 4;             // 16-wide MFMA k-steps per 128-byte line
   constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
   constexpr int LPT = PA + PW;
-  constexpr int TILE_A = BM * GEMM_KTB, STAGE = (BM + BN) * GEMM_KTB;
+  constexpr int TILE_A = BM * GEMM_KTB, SUB = (BM + BN) * GEMM_KTB, STAGE = KSP * SUB;  // a stage holds the k-tiles of all groups
   constexpr int NSLOT = TM / JG;                   // fragment slots per k-step
   static_assert(PA * 8 * NW == BM && PW * 8 * NW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
-  static_assert(TM % JG == 0 && (NS == 2 || NS == 3), "slot / ring shape");
+  static_assert(TM % JG == 0 && (NS == 2 || NS == 3) && (KSP == 1 || KSP == 2), "slot / ring shape");
   static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
-  F5_DYN_LDS(char, smem);
+  F5_DYN_LDS(char, smem_all);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = pp::uniform(tid >> 6);
+  const int wave_all = pp::uniform(tid >> 6);
+  const int grp = KSP == 1 ? 0 : wave_all / NW, wave = KSP == 1 ? wave_all : wave_all % NW;  // group, wave inside the group
+  char* smem = smem_all + grp * SUB;               // this group's half of every stage
   const int wm = wave % WGM, wn = wave / WGM;
   int m0, n0;
   {  // tile order as gemm_kernel: XCD-contiguous runs, channel tiles fastest, optional groups of row tiles
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi
     n0 = ntile * BN;
   }
   const int kbytes = g.K * 2 * NPL;  // bytes of one operand row; a multiple of 128 (launcher)
-  const int nkt = kbytes / GEMM_KTB;
+  const int nkt = kbytes / GEMM_KTB / KSP;  // k-tiles of this group (a multiple of KSP in total: launcher)
   const BufRsrc Ar = make_rsrc(g.A, (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * 2 + kbytes));
   const BufRsrc Wr = make_rsrc(g.W, (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * 2 + kbytes));
   // DMA piece P of an operand = rows 8P .. 8P+7 -> LDS bytes [1024 P, +1024); lane l brings row 8P + l/8, logical chunk (l%8) ^ swz(row)
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi
   }
   auto issue = [&](int kt, int stage) {
     char* base = smem + stage * STAGE;
-    const uint32_t kb = (uint32_t)kt * GEMM_KTB;
+    const uint32_t kb = (uint32_t)(KSP * kt + grp) * GEMM_KTB;
 #pragma unroll
     for (int p = 0; p < PA; ++p) pp::dma_b128(Ar, base + (wave * PA + p) * 1024, a_off[p], kb);
 #pragma unroll
@@ -515,7 +521,41 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_pp_kernel(GemmCore g, Epi
 #pragma unroll
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
-  } else {
+  } else if constexpr (KSP == 1) {
     epi.template tile<TM, TN>(acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+  } else {
+    // The two groups hold partial sums of the same tiles.  Tile t = j * TN + i is FINISHED by group (t < NT0 ? 0 : 1): every wave parks the
+    // tiles it does not finish in the (now idle) ring — [wave][tile][quad][lane] float4, one conflict-free 1 KB run per store — and adds its
+    // partner's copy of the tiles it does finish, always partner + own in group order 0 + 1 (one summation order whoever finishes).
+    constexpr int NT = TM * TN, NT0 = (NT + 1) / 2;
+    pp::wg_barrier();  // every wave has read its last fragments: the ring is free
+    float4* xch = reinterpret_cast<float4*>(smem_all);
+    static_for<NT>([&](auto TI) {
+      constexpr int ti = decltype(TI)::value, j = ti / TN, i = ti % TN;
+      if (grp != (ti < NT0 ? 0 : 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          xch[((wave * NT + ti) * 4 + q) * 64 + lane] = make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]);
+      }
+    });
+    __syncthreads();
+    static_for<NT>([&](auto TI) {
+      constexpr int ti = decltype(TI)::value, j = ti / TN, i = ti % TN;
+      if (grp == (ti < NT0 ? 0 : 1)) {
+        f32x16 one[1][1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 o = xch[((wave * NT + ti) * 4 + q) * 64 + lane];
+          if (grp == 0) {  // own (group 0) + partner (group 1)
+            one[0][0][4 * q] = acc[j][i][4 * q] + o.x; one[0][0][4 * q + 1] = acc[j][i][4 * q + 1] + o.y;
+            one[0][0][4 * q + 2] = acc[j][i][4 * q + 2] + o.z; one[0][0][4 * q + 3] = acc[j][i][4 * q + 3] + o.w;
+          } else {         // partner (group 0) + own
+            one[0][0][4 * q] = o.x + acc[j][i][4 * q]; one[0][0][4 * q + 1] = o.y + acc[j][i][4 * q + 1];
+            one[0][0][4 * q + 2] = o.z + acc[j][i][4 * q + 2]; one[0][0][4 * q + 3] = o.w + acc[j][i][4 * q + 3];
+          }
+        }
+        epi.template tile<1, 1>(one, m0 + wm * 32 * TM + 32 * j, n0 + wn * 32 * TN + 32 * i, lane);
+      }
+    });
   }
 }

@@ -307,6 +307,7 @@ inline unsigned shfl_xor_u32(unsigned v, int mask) {
   barrier_wait(w.bar);
   return r;
 }
+inline int shfl_xor(int v, int mask, int) { return (int)shfl_xor_u32((unsigned)v, mask); }  // bits, not a value conversion to float
 // v_permlane32_swap_b32 a, b: lanes 32-63 of a exchange with lanes 0-31 of b
 inline void permlane32_swap(unsigned& a, unsigned& b) {
   WaveCtx& w = wv();

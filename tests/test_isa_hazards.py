@@ -49,7 +49,7 @@ def pp_kernels(dis):
     for ln in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
         if m:
-            name = m.group(1) if "gemm_pp_kernel" in m.group(1) and "Li0EEv8GemmCore" in m.group(1) else None  # ABL = 0: not a microbenchmark ablation
+            name = m.group(1) if "gemm_pp_kernel" in m.group(1) and re.search(r"Li0ELi[12]EEv8GemmCore", m.group(1)) else None  # ABL = 0: not a microbenchmark ablation
             if name:
                 out[name] = []
             continue
