@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="F5TTS_v1_Base")
     ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
+    ap.add_argument("--bigvgan-conv-impl", type=int, default=-1, help="BigVGAN conv implementation 0 / 1 / 2 (-1 = the library default)")
+    ap.add_argument("--attn-kv-split", type=int, default=1, help="key ranges per query block in the flash kernel (1 = off, the default)")
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
                     help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
     ap.add_argument("--schedule", default="default", choices=["default"], help="kept for command-line compatibility: there is one schedule")
@@ -211,6 +213,8 @@ def main():
     if not a.no_graph:
         eng.set_option("use_graph", 1)
     eng.set_option("branch_streams", a.branch_streams)
+    if a.attn_kv_split > 1:
+        eng.set_option("attn_kv_split", a.attn_kv_split)
     if big:  # the generator is a context of its own (as in the reference); every rank builds the same seeded weights
         from f5_tts_amd.bigvgan import F5HipBigVGAN
 
@@ -218,6 +222,8 @@ def main():
         model = F5HipCFM(eng, precision=a.precision, mel_spec_type="bigvgan")
         bsd = synth.synth_bigvgan_state_dict(bcfg, seed=0)
         voc = F5HipBigVGAN(bcfg, device=dev, precision=a.precision).load_state_dict(bsd)
+        if a.bigvgan_conv_impl >= 0:
+            voc.set_option("conv_impl", a.bigvgan_conv_impl)
     else:
         model, voc = F5HipCFM(eng, precision=a.precision), F5HipVocos(eng)
 

@@ -849,8 +849,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         }
         HIPCHK(launch_gemm_store(OP_F32, g, e2, S * H, st));
       } else {
-        // fp16x3 default: hi/lo split q,k (the scores feed an exponential) and plain fp16 P,V — 1.1e-4 max-abs on the full-size
-        // generated mel vs 3.4e-5 with everything split and 2.6e-4 with nothing split (tools/precision_study.py)
+        // fp16x3 default: plain fp16 q, k, P, V (fp32 softmax statistics and accumulators) — every reference-minted golden stays within
+        // 2.8e-4 of the reference (tolerance 1e-3; profiles/r02d_attn_precision.log); attn_impl 4 splits q, k, attn_impl 2 everything
         const bool x3 = split_qk(ctx, op);
         const int ldv = (n + 7) & ~7;
         const int64_t voff = (int64_t)s0 * inner * ldv;

@@ -74,8 +74,9 @@ struct f5hip_bigvgan {
   bool profile = false;
   KStat stats[4];             // BV_* classes
   std::vector<ProfRec> prof;
-  int conv_impl = 0;          // 0 = tap-gathered operand + plain GEMM, 1 = implicit GEMM with tap-shifted rows (conv_gemm.h),
-                              // 2 = 1 + Activation1d writes the conv's operand copy itself
+  int conv_impl = 2;          // 0 = tap-gathered operand + plain GEMM, 1 = implicit GEMM with tap-shifted rows (conv_gemm.h),
+                              // 2 = 1 + Activation1d writes the conv's operand copy itself (the default since it was timed: 945 against
+                              // 977 / 1010 ms per configs[4] step, the generator's share 99 against 164 ms; tools/r2_call20.sh)
   int stop_after_stage = -1;  // parity tap (tests): >= 0 makes forward() return the channels-last stage tensor instead of the waveform
 };
 

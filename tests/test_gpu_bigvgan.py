@@ -93,13 +93,21 @@ def test_raw_weight_norm_checkpoint_and_frame_major_input():
         F5HipBigVGAN(cfg, device=0).load_state_dict({k: v for k, v in raw.items() if not k.startswith("conv_post")})
 
 def test_full_size_generator_short_clip():
-    """nvidia/bigvgan_v2_24khz_100band_256x shape (112 M parameters), 24 frames -> 6144 samples, fp16x3 against the CPU restatement."""
+    """nvidia/bigvgan_v2_24khz_100band_256x shape (112 M parameters), 24 frames -> 6144 samples, fp16x3 against the CPU restatement:
+    every stage tensor (the waveform of a random-init generator sits near the tanh's rails and says little) and the waveform, with the
+    default conv implementation (2: implicit GEMM, operand written by the activation kernel) and the two others."""
     from oracle import bigvgan_oracle as BO
 
     cfg = config.BIGVGAN_V2_24K_100B_256X
     voc, sd = make(cfg, "fp16x3", seed=0)
     mel = torch.randn(1, 100, 24, generator=torch.Generator().manual_seed(0))
-    want = BO.bigvgan_forward(sd, cfg, mel)
-    got = voc(mel.cuda()).cpu()
-    assert got.shape == (1, 1, 24 * 256)
-    assert (got - want).abs().max().item() < 2e-3
+    want, stages = BO.bigvgan_forward(sd, cfg, mel, return_stages=True)
+    for impl in (2, 1, 0):
+        voc.set_option("conv_impl", impl)
+        for k, ref in enumerate(stages):
+            got = voc.stage_tensor(mel.cuda(), k).cpu().transpose(1, 2)
+            err = (got - ref).abs().max().item()
+            assert err < TOL["fp16x3"] * max(1.0, ref.abs().max().item()), (impl, k, err)
+        got = voc(mel.cuda()).cpu()
+        assert got.shape == (1, 1, 24 * 256)
+        assert (got - want).abs().max().item() < 2e-3, impl

@@ -1,5 +1,5 @@
 """Generated-mel error of the fp16x3 mode against the reference-minted goldens with the attention scores computed from hi/lo-split q, k
-(attn_impl 0, 3 MFMAs per product) and from plain fp16 q, k (attn_impl 3, 1 MFMA): python tools/attn_precision_check.py  (GPU box)."""
+(attn_impl 4, 3 MFMAs per product) and from plain fp16 q, k (attn_impl 0, the default: 1 MFMA): python tools/attn_precision_check.py  (GPU box)."""
 import os
 import sys
 
@@ -25,7 +25,7 @@ for name in names:
     eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
     g = np.load(os.path.join(GOLD, name + ".npz"))["out"]
     res = []
-    for impl in (0, 3):
+    for impl in (4, 0):
         eng.set_option("attn_impl", impl)
         model = F5HipCFM(eng, precision="fp16x3", ode_method=c.get("method", "euler"))
         out, _ = model.sample(wav.cuda(), text, duration, lens=lens, **c["kw"])

@@ -12,13 +12,13 @@ import sys
 
 
 def klass(name):
-    if "gemm_kernel" in name:
-        if "EpiQKV" in name or "EpiStore" in name:
-            if "DF16_Li3" in name or "_Float16, 3" in name:
-                return "gemm_fp16x3"
-            if "DF16_Li1" in name or "_Float16, 1" in name:
-                return "gemm_fp16"
-            return "gemm_fp32"
+    # the block GEMMs: the pipelined kernel (gemm_pp.h) and the generic one (gemm.h), by operand mode
+    if "gemm_pp_kernel" in name or ("gemm_kernel" in name and ("EpiQKV" in name or "EpiStore" in name)):
+        if "DF16_Li3" in name or "_Float16, 3" in name:
+            return "gemm_fp16x3"
+        if "DF16_Li1" in name or "_Float16, 1" in name:
+            return "gemm_fp16"
+        return "gemm_fp32"
     if "flash_attn" in name:
         return "flash_attn"
     if "layernorm" in name:
@@ -50,7 +50,11 @@ def main():
     ap.add_argument("--model", default="F5TTS_v1_Base")
     a, _ = ap.parse_known_args(sys.argv[2:])
     fetch, write = load(os.path.join(out, "fetch"), "FETCH_SIZE"), load(os.path.join(out, "write"), "WRITE_SIZE")
-    res = {"precision": a.precision, "batch": a.batch, "nfe": a.nfe, "model": a.model, "classes": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench  # kernel_source_hash(): bench.py quotes this summary only while the kernel sources are the ones it was taken from
+
+    res = {"precision": a.precision, "batch": a.batch, "nfe": a.nfe, "model": a.model, "kernel_source_hash": bench.kernel_source_hash(),
+           "classes": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, [0, 0]), write.get(k, [0, 0])
         res["classes"][k] = {"launches": f[1] or w[1], "fetch_bytes_per_launch_x2": 2 * 1024 * f[0] / max(f[1], 1),
