@@ -1373,7 +1373,14 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Small batches are latency-bound per kernel (20-90 us launches, 1-2 waves of workgroups): the cond and uncond branches of the CFG
   // batch are independent until the combine, so they run as two concurrent kernel chains (fork / join per evaluation; inside a
   // graph capture the side stream becomes a parallel branch of the graph).
-  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && (int64_t)B * n <= 6144));  // measured: +7 % at B=1, +9 % at B=3, +3 % at B=4, 0 at B=8 (N=1406)
+  // Two chains against one, measured with the round-2 tiles at N = 1406 (same box, tools/r2_call23.sh / r2_call24.sh; ms per step):
+  //   B = 1: 85.1 / 84.4 (the one-round tiles of a 2812-row launch win)   B = 2: 138 / 156   B = 3: 206 / 251   B = 4: 258 / 284
+  //   B = 6: 376 / 432   B = 8: 254 / 269 (NFE 8)   B = 12: 390 / 406   B = 16: 522 / 497   B = 24: 779 / 752   B = 32: 960 / 978
+  // i.e. two chains wherever the second chain fills the partial rounds of the 192- and 256-row tilings (4k .. 40k rows), and again once
+  // each chain alone is in the 256x256 regime.
+  const int64_t rows1 = (int64_t)B * n;  // rows of one chain
+  const bool auto_split = (rows1 >= 2048 && rows1 <= 17500) || rows1 >= 40000;
+  const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && auto_split));
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));

@@ -131,6 +131,7 @@ hipError_t launch_tiled(const GemmCore& g, const Epi& e, int batch, int variant,
 //   59   96x128  4 waves of  96x32   3 stages      60  256x128  4 waves of 128x64  3 stages
 //   61-64  2-stage 4-wave tiles that fit two workgroups per CU (microbenchmark only, see pick_pp_variant)
 //   65  192x128  66  96x128  67  192x64: k-split, 2 groups x 4 waves on alternate k-tiles of one output tile
+//   68  192x192  69  192x128  70  192x64: k-step split, 2 groups x 4 waves on alternate k-steps of the same k-tiles
 template <int ID>
 struct PpV;
 #define F5_PPV(ID, TM_, TN_, WGM_, WGN_, NS_, JG_, ...)                                   \
@@ -138,7 +139,7 @@ struct PpV;
   struct PpV<ID> {                                                                        \
     static constexpr int TM = TM_, TN = TN_, WGM = WGM_, WGN = WGN_, NS = NS_, JG = JG_;  \
     static constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;                          \
-    static constexpr int KSP = 1 __VA_ARGS__;                                             \
+    static constexpr int KSP = (1 __VA_ARGS__) == 2 ? 2 : 1, KSS = (1 __VA_ARGS__) == 3 ? 2 : 1; /* +1: k-split, +2: k-step split */ \
   }
 F5_PPV(50, 4, 2, 2, 4, 2, 1);
 F5_PPV(51, 2, 2, 4, 2, 3, 2);
@@ -159,6 +160,10 @@ F5_PPV(64, 3, 1, 2, 2, 2, 3);  // 192x64,  4 waves of 96x32, 2 stages = 64 KB
 F5_PPV(65, 3, 2, 2, 2, 2, 3, +1);  // 192x128, 2 x 4 waves of 96x64 = 160 KB
 F5_PPV(66, 3, 1, 1, 4, 2, 3, +1);  //  96x128, 2 x 4 waves of 96x32 = 112 KB
 F5_PPV(67, 3, 1, 2, 2, 2, 3, +1);  // 192x64,  2 x 4 waves of 96x32 = 128 KB
+// k-step split (gemm_pp.h): two groups of 4 waves on alternate 16-wide k-steps of the same k-tiles, one ring filled by all 8 waves
+F5_PPV(68, 3, 3, 2, 2, 3, 1, +2);  // 192x192, 2 x 4 waves of 96x96, 3 stages = 144 KB
+F5_PPV(69, 3, 2, 2, 2, 3, 3, +2);  // 192x128, 2 x 4 waves of 96x64, 3 stages = 120 KB
+F5_PPV(70, 3, 1, 2, 2, 3, 3, +2);  // 192x64,  2 x 4 waves of 96x32, 3 stages =  96 KB
 #undef F5_PPV
 
 // what the pipelined kernel needs from a launch: fp16 operands whose rows are whole 128-byte k-tiles (at least 3 of them), channel
@@ -175,12 +180,16 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   using C = PpV<ID>;
   constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, C::NS, C::KSP>();
   static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
-  static_assert(C::KSP == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the k-split reuses the ring");
+  static_assert(C::KSP * C::KSS == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the split tiles reuses the ring");
+  if constexpr (C::KSS > 1) {  // even / odd tiles alternate the fragment buffers: an even number of k-tiles, a whole pipeline
+    const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
+    if (kt % 2 != 0 || kt < C::NS + 1) return hipErrorInvalidValue;
+  }
   if constexpr (C::KSP > 1) {  // each group needs its own whole pipeline: k-tiles split evenly, at least NS + 1 per group
     const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
     if (kt % C::KSP != 0 || kt / C::KSP < C::NS + 1) return hipErrorInvalidValue;
   }
-  auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL, C::KSP>;
+  auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL, C::KSP, C::KSS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -190,7 +199,7 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, 1);
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;  // which kernel ran (tests, tuning)
   if (trace) fprintf(stderr, "gemm_pp variant %d (%dx%d) nsplit %d M=%d N=%d K=%d grid %u\n", ID, C::BM, C::BN, NSPLIT, g.M, g.N, g.K, grid.x);
-  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN * C::KSP), lds, s, g, e);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * C::WGM * C::WGN * C::KSP * C::KSS), lds, s, g, e);
   return hipGetLastError();
 }
 
@@ -215,6 +224,9 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
     case 65: return launch_pp_one<NSPLIT, 65, Epi>(g, e, s);
     case 66: return launch_pp_one<NSPLIT, 66, Epi>(g, e, s);
     case 67: return launch_pp_one<NSPLIT, 67, Epi>(g, e, s);
+    case 68: return launch_pp_one<NSPLIT, 68, Epi>(g, e, s);
+    case 69: return launch_pp_one<NSPLIT, 69, Epi>(g, e, s);
+    case 70: return launch_pp_one<NSPLIT, 70, Epi>(g, e, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -249,7 +261,10 @@ int pick_pp_variant(const GemmCore& g, bool qkv = false) {
   // 96x128 (M = 2812: 23.9 / 39.9 us against 26.4 / 44.5; M = 1406: 20.9 / 34.0 / 23.6 against 23.5 / 39.6 / 25.8; profiles/r02c_ksplit.log).
   // For 192x128 it measures the same as the 8 waves of 96x32 (41.0 / 41.3), so that one stays.
   const int narrow = (g.K % 128 == 0 && g.K >= 512) ? 66 : 59;  // k-split: an even number of k-tiles, a whole pipeline per group
-  if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : narrow;
+  // one round of 240 workgroups (2048 <= M < 4096): the k-step-split 192x192 / 192x128 — 8 waves on the 4-wave tiles' ring, 57.0 against
+  // 62.2 us (q|k|v, 192x192 / 4 waves) and 40.0 against 41.2 (FF1, 192x128 / 8 waves of 96x32); profiles/r02e_kss.log
+  const bool even_kt = g.K % 64 == 0 && g.K >= 256;  // k-step split: an even number of k-tiles (fp16: K / 64, fp16x3: K / 32)
+  if (g.M >= 2048) return g.N >= 3072 ? (even_kt ? 68 : 56) : g.N >= 2048 ? (even_kt ? 69 : 55) : narrow;
   return g.N >= 3072 ? 55 : narrow;
 }
 

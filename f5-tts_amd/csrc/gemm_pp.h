@@ -340,26 +340,32 @@ constexpr int gemm_pp_lds_bytes() {
 // the large wave tiles of a 4-wave workgroup: one group's LDS-DMA issue, fragment reads and waits hide behind the other's MFMAs, and the
 // epilogue is shared (the groups exchange the partial sums of the tiles they do not finish through the idle ring).  For the one-round
 // launches of a single utterance, where a CU holds one workgroup and nothing else covers those gaps.
+// KSS = 2 ("k-step split"): two groups as above, but on the SAME k-tiles — group g multiplies the 16-wide k-steps g, g + 2, .. of every
+// k-tile (fp16x3 lines hold two k-steps, plain fp16 lines four).  No extra LDS: one ring, filled by all the waves together, read by both
+// groups; for the tiles whose ring already fills the LDS (192x192).  The partial sums meet in the epilogue exactly as with KSP.
 // ABL (microbenchmark ablations): bit 0 = no epilogue, bit 2 = no LDS-DMA after the prologue, bit 3 = no MFMAs.
-template <typename T, int NSPLIT, int TM, int TN, int WGM, int WGN, int NS, int JG, typename Epi, int ABL = 0, int KSP = 1>
-__global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore g, Epi epi) {
+template <typename T, int NSPLIT, int TM, int TN, int WGM, int WGN, int NS, int JG, typename Epi, int ABL = 0, int KSP = 1, int KSS = 1>
+__global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(GemmCore g, Epi epi) {
   constexpr int NW = WGM * WGN;  // waves of one group
+  constexpr int DW = NW * KSS;   // waves that fill one (sub-)stage
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
   constexpr int KS = NPL == 2 ? 2 : 4;             // 16-wide MFMA k-steps per 128-byte line
-  constexpr int PA = BM / 8 / NW, PW = BN / 8 / NW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
+  constexpr int KSL = KS / KSS;                    // k-steps one group multiplies per k-tile
+  constexpr int PA = BM / 8 / DW, PW = BN / 8 / DW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
   constexpr int LPT = PA + PW;
   constexpr int TILE_A = BM * GEMM_KTB, SUB = (BM + BN) * GEMM_KTB, STAGE = KSP * SUB;  // a stage holds the k-tiles of all groups
   constexpr int NSLOT = TM / JG;                   // fragment slots per k-step
-  static_assert(PA * 8 * NW == BM && PW * 8 * NW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
-  static_assert(TM % JG == 0 && (NS == 2 || NS == 3) && (KSP == 1 || KSP == 2), "slot / ring shape");
+  static_assert(PA * 8 * DW == BM && PW * 8 * DW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
+  static_assert(TM % JG == 0 && (NS == 2 || NS == 3) && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2, "slot / ring shape");
   static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
   F5_DYN_LDS(char, smem_all);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_all = pp::uniform(tid >> 6);
-  const int grp = KSP == 1 ? 0 : wave_all / NW, wave = KSP == 1 ? wave_all : wave_all % NW;  // group, wave inside the group
-  char* smem = smem_all + grp * SUB;               // this group's half of every stage
+  const int grp = KSP * KSS == 1 ? 0 : wave_all / NW, wave = KSP * KSS == 1 ? wave_all : wave_all % NW;  // group, wave inside the group
+  const int dwave = KSS == 1 ? wave : wave_all;    // this wave's place among those that fill a (sub-)stage
+  char* smem = smem_all + (KSP == 1 ? 0 : grp * SUB);  // k-split: this group's half of every stage
   const int wm = wave % WGM, wn = wave / WGM;
   int m0, n0;
   {  // tile order as gemm_kernel: XCD-contiguous runs, channel tiles fastest, optional groups of row tiles
@@ -387,21 +393,21 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
   uint32_t a_off[PA], w_off[PW];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int row = 8 * (wave * PA + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = 8 * (dwave * PA + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
     a_off[p] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * 2 + lc * 16) : OOB_ROW;
   }
 #pragma unroll
   for (int p = 0; p < PW; ++p) {
-    const int row = 8 * (wave * PW + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = 8 * (dwave * PW + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
     w_off[p] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + lc * 16) : OOB_ROW;
   }
   auto issue = [&](int kt, int stage) {
     char* base = smem + stage * STAGE;
-    const uint32_t kb = (uint32_t)(KSP * kt + grp) * GEMM_KTB;
+    const uint32_t kb = (uint32_t)(KSP * kt + (KSP == 1 ? 0 : grp)) * GEMM_KTB;
 #pragma unroll
-    for (int p = 0; p < PA; ++p) pp::dma_b128(Ar, base + (wave * PA + p) * 1024, a_off[p], kb);
+    for (int p = 0; p < PA; ++p) pp::dma_b128(Ar, base + (dwave * PA + p) * 1024, a_off[p], kb);
 #pragma unroll
-    for (int p = 0; p < PW; ++p) pp::dma_b128(Wr, base + TILE_A + (wave * PW + p) * 1024, w_off[p], kb);
+    for (int p = 0; p < PW; ++p) pp::dma_b128(Wr, base + TILE_A + (dwave * PW + p) * 1024, w_off[p], kb);
   };
 
   f32x16 acc[TM][TN];
@@ -415,20 +421,25 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
   // fragment addressing: lane (row = lane & 31, hi = lane >> 5) reads logical chunk 2 ks + hi (+4 for the lo plane) of its row
   const uint32_t lds0 = pp::lds_base(smem);
   const int frow = (lane & 31) * GEMM_KTB, fswz = ((lane & 31) >> 1) & 7, fhi = lane >> 5;
-  uint32_t fa_addr[NPL][KS], fw_addr[NPL][KS];  // + stage offset (updated per k-tile) + 4096 * tile index (immediate)
+  uint32_t fa_addr[NPL][KSL], fw_addr[NPL][KSL];  // + stage offset (updated per k-tile) + 4096 * tile index (immediate)
 #pragma unroll
   for (int p = 0; p < NPL; ++p)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ksl = 0; ksl < KSL; ++ksl) {
+      const int ks = KSS == 1 ? ksl : ksl * KSS + grp;  // k-step split: this group's k-steps of the line
       const uint32_t o = (uint32_t)(frow + (((p * 4 + 2 * ks + fhi) ^ fswz) << 4));
-      fa_addr[p][ks] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
-      fw_addr[p][ks] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
+      fa_addr[p][ksl] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
+      fw_addr[p][ksl] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
     }
   Frag fa[2][NPL][JG], fw[2][NPL][TN];
 
-  // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot
-  auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, slot>
-    constexpr int s = decltype(SC)::value, ks = s / NSLOT, jg = s % NSLOT, buf = s & 1, wbuf = ks & 1;
+  // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot.
+  // Slots are numbered v = parity * SLOTS + s over a PAIR of k-tiles: the fragment buffers alternate with v, so tiles with an odd number
+  // of slots or k-steps (the k-step split) run as even / odd tiles; with even counts the parity is always 0.
+  constexpr int SLOTS = KSL * NSLOT;
+  constexpr bool PAIRED = (SLOTS % 2 != 0) || (KSL % 2 != 0);
+  auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, v>
+    constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
 #pragma unroll
     for (int p = 0; p < NPL; ++p) {
       if constexpr (jg == 0) {
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
     // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
   };
   auto mma_slot = [&](auto SC) {
-    constexpr int s = decltype(SC)::value, ks = s / NSLOT, jg = s % NSLOT, buf = s & 1, wbuf = ks & 1;
+    constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
 #pragma unroll
     for (int jj = 0; jj < JG; ++jj)
 #pragma unroll
@@ -460,18 +471,16 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
         }
       }
   };
-  constexpr int SLOTS = KS * NSLOT;
-  static_assert(SLOTS % 2 == 0, "slot buffers alternate: an even number of slots per k-tile keeps slot 0 in buffer 0");
 
   // One k-tile.  On entry: slot 0's reads are in flight (or landed); tiles t+1 .. t+NS-1 are issued.  MODE 0: steady state (refill tile
   // t+NS when it exists), 1: next-to-last tile (nothing left to issue, everything outstanding is waited for), 2: last tile.
-  auto ktile = [&](auto MODE, int t, uint32_t soff, uint32_t soff_next, int stage) {
-    constexpr int mode = decltype(MODE)::value;
+  auto ktile = [&](auto MODE, auto PAR, int t, uint32_t soff, uint32_t soff_next, int stage) {
+    constexpr int mode = decltype(MODE)::value, v0 = decltype(PAR)::value * SLOTS, v0_next = PAIRED ? (1 - decltype(PAR)::value) * SLOTS : 0;
     // slots 0 .. SLOTS-2: wait for this slot's fragments, read the next slot's, multiply
     static_for<SLOTS - 1>([&](auto S) {
       pp::lds_wait();
-      read_slot(std::integral_constant<int, decltype(S)::value + 1>{}, soff);
-      mma_slot(S);
+      read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff);
+      mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
     });
     pp::lds_wait();  // the last slot's fragments: every read of this tile by this wave has landed
     if constexpr (mode != 2) {
@@ -483,9 +492,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
           if (t + NS < nkt) issue(t + NS, stage);
         }
       }
-      read_slot(std::integral_constant<int, 0>{}, soff_next);
+      read_slot(std::integral_constant<int, v0_next>{}, soff_next);
     }
-    mma_slot(std::integral_constant<int, SLOTS - 1>{});
+    mma_slot(std::integral_constant<int, v0 + SLOTS - 1>{});
   };
 
   // prologue: tiles 0 .. NS-1 in flight, tile 0 landed and visible, its first fragments requested
@@ -497,20 +506,28 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
   int stage = 0;
   uint32_t soff = 0;
   auto next_soff = [&](uint32_t so) { return so + STAGE == (uint32_t)(NS * STAGE) ? 0u : so + STAGE; };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, PAIRED ? 1 : 0>;  // parity of the odd tiles (an even number of k-tiles: launcher)
   int t = 0;
-  for (; t < nkt - 2; ++t) {
+  auto steady = [&](auto PAR) {
     const uint32_t sn = next_soff(soff);
-    ktile(std::integral_constant<int, 0>{}, t, soff, sn, stage);
+    ktile(std::integral_constant<int, 0>{}, PAR, t, soff, sn, stage);
     soff = sn;
     stage = stage == NS - 1 ? 0 : stage + 1;
+    ++t;
+  };
+  if constexpr (PAIRED) {
+    while (t < nkt - 2) { steady(P0{}); steady(P1{}); }
+  } else {
+    while (t < nkt - 2) steady(P0{});
   }
   {
     const uint32_t sn = next_soff(soff);
-    ktile(std::integral_constant<int, 1>{}, t, soff, sn, stage);
+    ktile(std::integral_constant<int, 1>{}, P0{}, t, soff, sn, stage);
     soff = sn;
     ++t;
   }
-  ktile(std::integral_constant<int, 2>{}, t, soff, 0u, 0);
+  ktile(std::integral_constant<int, 2>{}, P1{}, t, soff, 0u, 0);
 
   if constexpr (ABL & 1) {
 #ifndef F5_HIPEMU
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP) void gemm_pp_kernel(GemmCore 
 #pragma unroll
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
-  } else if constexpr (KSP == 1) {
+  } else if constexpr (KSP * KSS == 1) {
     epi.template tile<TM, TN>(acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   } else {
     // The two groups hold partial sums of the same tiles.  Tile t = j * TN + i is FINISHED by group (t < NT0 ? 0 : 1): every wave parks the

@@ -598,8 +598,8 @@ def test_f5tts_api_class(tmp_path):
 
 def test_full_size_batch_rows_equal_single_utterance():
     """F5-TTS Base at full size: a fixed-length batch of identical utterances (packed cond+uncond launches, M = 2*B*N rows) must give
-    every row the result of the B=1 call (cond / uncond branches on two streams, M = N rows per launch) — same arithmetic, different
-    schedules and tile heuristics."""
+    every row the result of the B=1 call — same arithmetic, different schedules (since round 2: B = 1 is one packed chain of 2 N rows,
+    B = 4 two concurrent CFG chains of 4 N rows each) and tile heuristics."""
     from f5_tts_amd.engine import F5HipCFM, F5HipEngine
 
     c = MG.FULL_CASES["base_v1_cfg1"]
@@ -819,7 +819,7 @@ def test_four_threads_share_one_context(engines):
 
 
 # ---- the pipelined block GEMM (csrc/gemm_pp.h) on the GPU ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [50, 51, 55, 56, 59])  # the tiles pick_pp_variant() can choose
+@pytest.mark.parametrize("variant", [50, 51, 55, 56, 59, 68])  # the tiles pick_pp_variant() can choose
 @pytest.mark.parametrize("seqs", [2, 8])
 def test_pp_qkv_epilogue_equals_generic_kernel_on_the_gpu(engines, variant, seqs):
     """The fused q|k|v projection through every production tile of the pipelined kernel against the generic kernel of gemm.h (GPU-verified
@@ -836,7 +836,7 @@ def test_pp_qkv_epilogue_equals_generic_kernel_on_the_gpu(engines, variant, seqs
         assert st == 0 and diff.value == 0, (variant, seqs, st, diff.value)
 
 
-@pytest.mark.parametrize("variant", [55, 59, 65, 66, 67])
+@pytest.mark.parametrize("variant", [55, 59, 65, 66, 67, 69, 70])
 @pytest.mark.parametrize("epi,M,N,K", [(1, 2812, 2048, 1024), (2, 2812, 1024, 2048), (2, 1406, 1024, 1024)])
 def test_pp_store_epilogues_equal_generic_kernel_on_the_gpu(engines, capfd, variant, epi, M, N, K):
     """FF1 (GELU -> packed operand rows) and out-proj / FF2 (gated residual update) of the DiT Base shapes through the production tiles,
@@ -863,7 +863,8 @@ def test_pp_store_epilogues_equal_generic_kernel_on_the_gpu(engines, capfd, vari
 
 
 def test_full_size_runs_are_bit_reproducible():
-    """F5-TTS Base, B = 1 (two concurrent CFG chains, graph replay) and B = 4 (the 256x128 tiles): five calls, one result, bit for bit."""
+    """F5-TTS Base, B = 1 (one packed chain, the one-round k-split tiles, graph replay) and B = 4 (two concurrent CFG chains, the 256x128
+    tiles): five calls, one result, bit for bit."""
     from f5_tts_amd.engine import F5HipCFM, F5HipEngine
 
     c = MG.FULL_CASES["base_v1_cfg1"]

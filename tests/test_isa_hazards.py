@@ -49,7 +49,7 @@ def pp_kernels(dis):
     for ln in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
         if m:
-            name = m.group(1) if "gemm_pp_kernel" in m.group(1) and re.search(r"Li0ELi[12]EEv8GemmCore", m.group(1)) else None  # ABL = 0: not a microbenchmark ablation
+            name = m.group(1) if "gemm_pp_kernel" in m.group(1) and re.search(r"Li0ELi[12]ELi[12]EEv8GemmCore", m.group(1)) else None  # ABL = 0: not a microbenchmark ablation
             if name:
                 out[name] = []
             continue
@@ -87,10 +87,14 @@ def test_pipelined_gemm_keeps_its_dma_ring_in_flight(code_objects):
             nbar = sum(1 for i in loop if i.startswith("s_barrier"))
             ndma = sum(1 for i in loop if i.startswith("buffer_load_dwordx4") and i.rstrip().endswith("lds"))
             vm = [int(re.search(r"vmcnt\((\d+)\)", i).group(1)) for i in loop if i.startswith("s_waitcnt") and "vmcnt" in i]
-            assert nbar == 1, (name, nbar)
-            assert ndma >= 2, (name, ndma)
             targs = re.search(r"gemm_pp_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)  # NSPLIT TM TN WGM WGN NS JG
             assert targs, name
+            kss = int(re.search(r"Li0ELi[12]ELi([12])EEv8GemmCore", name).group(1))
+            ksl = (2 if int(targs.group(1)) == 3 else 4) // kss  # k-steps per group per k-tile
+            slots = ksl * (int(targs.group(2)) // int(targs.group(7)))
+            paired = slots % 2 == 1 or ksl % 2 == 1  # gemm_pp.h PAIRED: an even and an odd k-tile per loop iteration
+            assert nbar == (2 if paired else 1), (name, nbar)  # one barrier per k-tile
+            assert ndma >= 2, (name, ndma)
             if int(targs.group(6)) == 3:
                 assert vm and min(vm) > 0, (name, vm)  # a vmcnt(0) here would drain the ring every k-tile
             checked += 1

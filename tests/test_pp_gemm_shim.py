@@ -35,10 +35,10 @@ def run(make_engine, capfd, prec, variant, epi, M, N, K):
 # (variant, M, N): ragged rows everywhere; N a multiple of 32 that is NOT a multiple of the tile width where the tile allows it
 CASES = [(50, 300, 288), (51, 300, 160), (52, 200, 288), (53, 250, 96), (54, 250, 160), (55, 250, 160), (56, 250, 224), (57, 200, 160),
          (58, 200, 160), (59, 130, 160), (60, 300, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (64, 250, 96),
-         (65, 250, 160), (66, 130, 160), (67, 250, 96)]
+         (65, 250, 160), (66, 130, 160), (67, 250, 96), (68, 250, 224), (69, 250, 160), (70, 250, 96)]
 
 
-KSPLIT = (65, 66, 67)  # the k-split tiles
+KSPLIT = (65, 66, 67, 68, 69, 70)  # the k-split and k-step-split tiles
 
 
 @pytest.mark.parametrize("variant,M,N", CASES)
@@ -72,7 +72,7 @@ def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
 
 # the fused q|k|v epilogue (rope, head scatter, V^T) of every tile variant against the generic kernel's, byte for byte: sequences that
 # straddle row tiles, even (paired V^T stores) and odd (scalar stores) sequence lengths, several sequences per launch
-@pytest.mark.parametrize("variant", [50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67])
+@pytest.mark.parametrize("variant", [50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70])
 @pytest.mark.parametrize("seqs,nseq", [(3, 150), (2, 141)])
 def test_pp_qkv_epilogue_equals_generic_kernel(emu_engine, capfd, variant, seqs, nseq):  # noqa: F811
     diff, err = run_qkv(emu_engine, capfd, "fp16x3", variant, seqs, nseq, K=256 if variant in KSPLIT else 128)
