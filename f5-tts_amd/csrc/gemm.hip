@@ -164,6 +164,8 @@ F5_PPV(67, 3, 1, 2, 2, 2, 3, +1);  // 192x64,  2 x 4 waves of 96x32 = 128 KB
 F5_PPV(68, 3, 3, 2, 2, 3, 1, +2);  // 192x192, 2 x 4 waves of 96x96, 3 stages = 144 KB
 F5_PPV(69, 3, 2, 2, 2, 3, 3, +2);  // 192x128, 2 x 4 waves of 96x64, 3 stages = 120 KB
 F5_PPV(70, 3, 1, 2, 2, 3, 3, +2);  // 192x64,  2 x 4 waves of 96x32, 3 stages =  96 KB
+// (deeper rings — 192x64 k-step split x 5 stages, 192x128 x 4, 96x128 / 4 waves x 5, 192x128 / 8 waves x 4 — measured the same or 1-3 % slower
+// than the 3-stage tiles: the one-round k-loops are not waiting for their DMA; profiles/r02e_deep_rings.log)
 #undef F5_PPV
 
 // what the pipelined kernel needs from a launch: fp16 operands whose rows are whole 128-byte k-tiles (at least 3 of them), channel
@@ -285,11 +287,13 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
                          // 4 no LDS-DMA in the loop, 8 no MFMAs, 12 neither (fragment reads + barriers + epilogue)
       if (variant >= 1000 && e.act == ACT_GELU_TANH) {
         const PpEpiAct16<true, ACT_GELU_TANH> ep{e.bias, e.out16, ld, g.M, g.N};
-        const PpEpiAct16<true, ACT_GELU_TANH, true> ens{e.bias, e.out16, ld, g.M, g.N};
+        const PpEpiAct16<true, ACT_GELU_TANH, 1> ens{e.bias, e.out16, ld, g.M, g.N};
+        const PpEpiAct16<true, ACT_GELU_TANH, 2> eds{e.bias, e.out16, ld, g.M, g.N};
         switch (variant) {
 #define F5_ABL(ID)                                                          \
   case 1000 + ID: return launch_pp_one<3, ID, decltype(ep), 1>(g, ep, s);   \
   case 2000 + ID: return launch_pp_one<3, ID, decltype(ens), 0>(g, ens, s); \
+  case 3000 + ID: return launch_pp_one<3, ID, decltype(eds), 0>(g, eds, s); \
   case 4000 + ID: return launch_pp_one<3, ID, decltype(ep), 4>(g, ep, s);   \
   case 8000 + ID: return launch_pp_one<3, ID, decltype(ep), 8>(g, ep, s);   \
   case 12000 + ID: return launch_pp_one<3, ID, decltype(ep), 12>(g, ep, s); \

@@ -117,7 +117,8 @@ __device__ __forceinline__ uint4 widen(uint32_t (&a)[2], uint32_t (&b)[2]) {
 // + 0..3 (acc[j][i][4 q + e]).  Rows >= M and channels >= N fall outside the buffer descriptors / are skipped per 32-channel tile.
 
 // FeedForward first linear (modules.py:353-364): tanh-GELU(acc + bias) -> the operand rows of the second linear, packed hi/lo (PK) or plain fp16
-template <bool PK, int ACT, bool NOSTORE = false>  // NOSTORE: microbenchmark ablation (the arithmetic without the stores)
+template <bool PK, int ACT, int NOSTORE = 0>  // NOSTORE: microbenchmark ablations — 1: the arithmetic without the stores, 2: the same bytes
+                                             // stored lane-linearly (1 KB runs per instruction; WRONG layout: what does the row-strided pattern cost?)
 struct PpEpiAct16 {
   const float* bias;
   f16* out;          // [M, ld] halves: PK: [N/32][32 hi | 32 lo], ld = 2N;  plain: [N], ld = N
@@ -148,7 +149,13 @@ struct PpEpiAct16 {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           const uint32_t o = row + col + (uint32_t)(16 * p + 8 * h) * 2u;
-          if constexpr (NOSTORE) {
+          if constexpr (NOSTORE == 2) {
+            const uint32_t d = (uint32_t)(((m_w >> 5) + j) * (N >> 5) + (nb >> 5)) * 4096u + (uint32_t)p * 2048u + (uint32_t)lane * 16u;
+            pp::store_b128(R, d, pp::widen(hi[2 * p], hi[2 * p + 1]));
+            if constexpr (PK) pp::store_b128(R, d + 1024u, pp::widen(lo[2 * p], lo[2 * p + 1]));
+            continue;
+          }
+          if constexpr (NOSTORE == 1) {
             const uint4 a = pp::widen(hi[2 * p], hi[2 * p + 1]), b2 = pp::widen(lo[2 * p], lo[2 * p + 1]);
             asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b2.x), "v"(b2.y), "v"(b2.z), "v"(b2.w), "v"(o));
             continue;
@@ -357,7 +364,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   constexpr int TILE_A = BM * GEMM_KTB, SUB = (BM + BN) * GEMM_KTB, STAGE = KSP * SUB;  // a stage holds the k-tiles of all groups
   constexpr int NSLOT = TM / JG;                   // fragment slots per k-step
   static_assert(PA * 8 * DW == BM && PW * 8 * DW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
-  static_assert(TM % JG == 0 && (NS == 2 || NS == 3) && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2, "slot / ring shape");
+  static_assert(TM % JG == 0 && NS >= 2 && NS <= 5 && (NS - 1) * LPT <= 63 && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2,
+                "slot / ring shape (the counted waits are 6-bit immediates)");
   static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
   F5_DYN_LDS(char, smem_all);
 
