@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--model", default="F5TTS_v1_Base"); ap.add_argument("--ckpt"); ap.add_argument("--vocab"); ap.add_argument("--vocos")
     ap.add_argument("--synthetic", type=int, default=0); ap.add_argument("--nfe", type=int, default=16)
     ap.add_argument("--precision", default="fp16x3"); ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--frames-per-batch", type=int, default=0,
+                    help="> 0: form length-bucketed batches with this frame budget (the reference's infer_batch_size, eval/utils_eval.py:72-205; "
+                         "f5-tts_amd/eval_batching.py) instead of running the utterances one by one")
     a = ap.parse_args()
     rank, local, world = fdist.init_distributed()
     dev = torch.device("cuda", local)
@@ -76,18 +79,42 @@ def main():
         for line in open(a.list, encoding="utf-8"):
             uid, ref_wav, ref_text, gen_text = line.rstrip("\n").split("|")[:4]
             utts.append((uid, ref_wav, ref_text, gen_text))
-    costs = [len(u[3].encode()) + len(u[2].encode()) for u in utts]  # text bytes ~ frames to generate
-    mine = fdist.shard_balanced(costs, world)[rank]
     os.makedirs(a.out, exist_ok=True)
-    if world > 1:
-        torch.distributed.barrier()  # eval_infer_batch.py:178
-    t0 = time.perf_counter()
     audio_s = 0.0
-    for i in mine:
-        uid, ref, ref_text, gen_text = utts[i]
-        wav, sr, _ = I.infer_process(ref, ref_text, gen_text, model, voc, show_info=lambda *_: None, nfe_step=a.nfe, seed=a.seed)
-        write_wav(os.path.join(a.out, uid + ".wav"), wav, sr)
-        audio_s += len(wav) / sr
+    if a.frames_per_batch > 0:  # the reference's evaluation batching: one ragged sample() per length-class batch
+        from f5_tts_amd import eval_batching as EB
+
+        def load_audio(x):  # a path, or the (wave, sr) pair of the synthetic utterances
+            w, sr = x if isinstance(x, tuple) else I.load_wav(x)
+            return (w if w.ndim == 2 else w[None]).float().cpu(), sr
+
+        meta = [(uid, ref_text, ref, gen_text, "") for uid, ref, ref_text, gen_text in utts]
+        batches = EB.get_inference_prompt(meta, lambda w: model.mel_spec(w.to(dev)).cpu(), tokenizer="char", infer_batch_size=a.frames_per_batch,
+                                          min_secs=1, max_secs=60, load_audio=load_audio)
+        mine = EB.deal_batches(batches, world)[rank]
+        if rank == 0:
+            print(f"{len(batches)} batches of <= {max(len(b[0]) for b in batches)} utterances, padding {100 * EB.padding_fraction(batches):.1f} % of the rows")
+        if world > 1:
+            torch.distributed.barrier()  # eval_infer_batch.py:178
+        t0 = time.perf_counter()
+
+        def save(uid, wave_):
+            nonlocal audio_s
+            write_wav(os.path.join(a.out, uid + ".wav"), wave_[0].numpy())
+            audio_s += wave_.shape[-1] / 24000
+
+        EB.run_prompt_batches(model, voc, [batches[i] for i in mine], nfe_step=a.nfe, seed=a.seed, on_wave=save)
+    else:
+        costs = [len(u[3].encode()) + len(u[2].encode()) for u in utts]  # text bytes ~ frames to generate
+        mine = fdist.shard_balanced(costs, world)[rank]
+        if world > 1:
+            torch.distributed.barrier()  # eval_infer_batch.py:178
+        t0 = time.perf_counter()
+        for i in mine:
+            uid, ref, ref_text, gen_text = utts[i]
+            wav, sr, _ = I.infer_process(ref, ref_text, gen_text, model, voc, show_info=lambda *_: None, nfe_step=a.nfe, seed=a.seed)
+            write_wav(os.path.join(a.out, uid + ".wav"), wav, sr)
+            audio_s += len(wav) / sr
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()  # eval_infer_batch.py:214
