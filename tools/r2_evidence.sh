@@ -3,7 +3,7 @@
 #   gpu tests -> bench lines (B=1 default with cpu_baseline, B=4, B=32 NFE 32, E2-TTS + BigVGAN B=8) -> rocprofv3 kernel-trace summaries
 #   -> PMC traffic / MFMA-busy passes (separate runs) -> microbenchmark tables.   Outputs: gpurun_out/r2ev/ (copied to profiles/r02*).
 set -u
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r2ev; rm -rf $out; mkdir -p $out
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/${EVDIR:-r2ev}; rm -rf $out; mkdir -p $out
 cd $R
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $out/gpu_tests.log; cat $out/gpu_tests.log
 timeout 900 python bench.py --steps 10 --warmup 3 > $out/bench_b1.json 2> $out/bench_b1.err; tail -c 300 $out/bench_b1.err
@@ -36,9 +36,9 @@ rm -rf gpurun_out/pmc_fp16x3_b1
 B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048;1406,3072,1024;1406,1024,1024;1406,2048,1024;1406,1024,2048"
 BIG="11248,3072,1024;11248,1024,2048;22496,3072,1024;22496,1024,2048;89984,2048,1024;89984,3072,1024;89984,1024,1024;89984,1024,2048"
 {
-for epi in 1 2; do KB_SHAPES=$B1 KB_PRECS=fp16x3 KB_EPI=$epi KB_VARIANTS=-1,1,55,56,59,65,66,67 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /"; done
+for epi in 1 2; do KB_SHAPES=$B1 KB_PRECS=fp16x3 KB_EPI=$epi KB_VARIANTS=-1,1,55,56,59,66,68,69,70 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /"; done
 for epi in 1 2; do KB_SHAPES=$BIG KB_PRECS=fp16x3,fp16 KB_EPI=$epi KB_VARIANTS=-1,2,50,51,52 timeout 400 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /"; done
-for sq in "1 1406" "2 1406" "8 1406" "64 1406"; do timeout 200 python tools/kernel_bench.py qkv fp16x3 $sq -1,1,50,51,55,56 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done
+for sq in "1 1406" "2 1406" "8 1406" "64 1406"; do timeout 200 python tools/kernel_bench.py qkv fp16x3 $sq -1,1,50,51,55,56,68 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done
 timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn
 } > $out/kernel_bench.log 2>&1
 tail -30 $out/kernel_bench.log
