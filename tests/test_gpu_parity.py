@@ -889,3 +889,45 @@ def test_full_size_runs_are_bit_reproducible():
             assert torch.equal(first, again)
     finally:
         eng.close()
+
+
+def test_bucketed_eval_batches_on_the_gpu(engines, tmp_path):
+    """eval/utils_eval.py:72-205 + eval_infer_batch.py:178-214 through the HIP engine: length-bucketed ragged batches formed with the
+    engine's own mel front-end, one ragged sample() per batch, every utterance vocoded once; the loop equals the manual per-batch
+    computation bit for bit, and the oracle's sampler agrees on a batch (ragged lens / durations, list-of-str text)."""
+    import wave as wave_mod
+
+    from f5_tts_amd import eval_batching as EB
+    from f5_tts_amd.engine import F5HipCFM, F5HipVocos
+
+    cfg = config.DIT_TINY
+    eng = engines("tiny", 1, vocos=True)
+    sd = synth.synth_dit_state_dict(cfg, seed=1)
+    vocab = {chr(c): 1 + (c % (cfg.text_num_embeds - 2)) for c in range(32, 127)}
+    model, voc = F5HipCFM(eng, precision="fp16x3", vocab_char_map=vocab), F5HipVocos(eng)
+    meta = []
+    for i, (secs, words) in enumerate([(0.45, 3), (0.5, 4), (0.47, 3), (0.9, 6), (0.52, 4), (0.95, 7)]):
+        x = (0.02 if i == 1 else 0.2) * np.random.default_rng(i).standard_normal(int(secs * 24000))
+        p = tmp_path / f"p{i}.wav"
+        with wave_mod.open(str(p), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes((x.clip(-1, 1) * 32767).astype("<i2").tobytes())
+        meta.append((f"u{i}", "ab cd.", str(p), " ".join(["w"] * words), ""))
+    batches = EB.get_inference_prompt(meta, lambda wv: model.mel_spec(wv.cuda()).cpu(), tokenizer="char", infer_batch_size=150, min_secs=0,
+                                      max_secs=3, num_buckets=3)
+    assert sorted(u for b in batches for u in b[0]) == sorted(m[0] for m in meta) and any(len(b[0]) > 1 for b in batches)
+    run = dict(nfe_step=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+    got = dict(EB.run_prompt_batches(model, voc, batches, **run))
+    assert set(got) == {m[0] for m in meta}
+    for utts, rms, mels, lens, totals, texts in batches:
+        out, _ = model.sample(cond=mels, text=texts, duration=torch.tensor(totals), lens=torch.tensor(lens), steps=4, cfg_strength=2.0,
+                              sway_sampling_coef=-1.0, seed=3)
+        from f5_tts_amd.engine import list_str_to_idx
+
+        ref, _ = O.cfm_sample(sd, cfg, mels, list_str_to_idx(texts, vocab), torch.tensor(totals), lens=torch.tensor(lens), steps=4,
+                              cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+        assert maxerr(out, ref) < X3TOL
+        for i, u in enumerate(utts):
+            w = voc.decode(out[i, lens[i]:totals[i]].unsqueeze(0).permute(0, 2, 1)).cpu()
+            if rms[i] < 0.1:
+                w = w * rms[i] / 0.1
+            assert torch.equal(w, got[u]) and w.shape[-1] == 256 * (totals[i] - lens[i] - 1)

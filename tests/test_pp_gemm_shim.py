@@ -32,10 +32,14 @@ def run(make_engine, capfd, prec, variant, epi, M, N, K):
     return [(int(bad), int(nb), float(d), float(v)) for _, _, _, bad, nb, d, v in lines]
 
 
-# (variant, M, N): ragged rows everywhere; N a multiple of 32 that is NOT a multiple of the tile width where the tile allows it
-CASES = [(50, 300, 288), (51, 300, 160), (52, 200, 288), (53, 250, 96), (54, 250, 160), (55, 250, 160), (56, 250, 224), (57, 200, 160),
-         (58, 200, 160), (59, 130, 160), (60, 300, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (64, 250, 96),
-         (65, 250, 160), (66, 130, 160), (67, 250, 96), (68, 250, 224), (69, 250, 160), (70, 250, 96)]
+# (variant, M, N): ragged rows everywhere; N a multiple of 32 that is NOT a multiple of the tile width where the tile allows it.
+# The default run covers the tiles pick_pp_variant() can choose plus one of every other family; F5HIP_SHIM_ALL_VARIANTS=1 runs them all
+# (the microbenchmark-only tiles too: 21 variants, +2 minutes).
+ALL_CASES = [(50, 300, 288), (51, 300, 160), (52, 200, 288), (53, 250, 96), (54, 250, 160), (55, 250, 160), (56, 250, 224), (57, 200, 160),
+             (58, 200, 160), (59, 130, 160), (60, 300, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (64, 250, 96),
+             (65, 250, 160), (66, 130, 160), (67, 250, 96), (68, 250, 224), (69, 250, 160), (70, 250, 96)]
+PRODUCTION = (50, 51, 55, 56, 59, 66, 68, 69)  # + 52 (128x256), 62 (two per CU), 65 (k-split of a wide tile) as family representatives
+CASES = ALL_CASES if os.environ.get("F5HIP_SHIM_ALL_VARIANTS") else [c for c in ALL_CASES if c[0] in PRODUCTION + (52, 62, 65)]
 
 
 KSPLIT = (65, 66, 67, 68, 69, 70)  # the k-split and k-step-split tiles
@@ -72,7 +76,7 @@ def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
 
 # the fused q|k|v epilogue (rope, head scatter, V^T) of every tile variant against the generic kernel's, byte for byte: sequences that
 # straddle row tiles, even (paired V^T stores) and odd (scalar stores) sequence lengths, several sequences per launch
-@pytest.mark.parametrize("variant", [50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70])
+@pytest.mark.parametrize("variant", [c[0] for c in CASES])
 @pytest.mark.parametrize("seqs,nseq", [(3, 150), (2, 141)])
 def test_pp_qkv_epilogue_equals_generic_kernel(emu_engine, capfd, variant, seqs, nseq):  # noqa: F811
     diff, err = run_qkv(emu_engine, capfd, "fp16x3", variant, seqs, nseq, K=256 if variant in KSPLIT else 128)
