@@ -292,7 +292,8 @@ def main():
                    "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via,
                    "rccl_ranks": world if world > 1 else 0, "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                    "weight_broadcast_plus_finalize_s": round(bcast_s, 4),
-                   "self_launched": bool(os.environ.get("F5HIP_BENCH_SELF_LAUNCHED")), "notes": notes},
+                   "self_launched": bool(os.environ.get("F5HIP_BENCH_SELF_LAUNCHED")), "kernel_source_hash": kernel_source_hash(),
+                   "notes": notes},
     }
     # ---- roofline of the dominant kernel: DiT block GEMMs, HIP events on the launch stream, untimed eager single-chain pass ----------
     eng.set_option("profile", 1)
