@@ -703,7 +703,7 @@ int ensure_workspace(f5hip_ctx* ctx, int B, int n, int nt, int op, bool exact_at
   if (mmdit) {
     ENS(ctext0, 2 * (int64_t)B * nt * D * 4); ENS(cmask, 2 * (int64_t)B * nt); ENS(kvlen2, 2 * B * 4);
   } else {
-    ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, 2 * B * 2 * T * 4);
+    ENS(tx, M * T * 4); ENS(ta, M * T * 4); ENS(th, M * 2 * T * 4); ENS(tg, M * 2 * T * 4); ENS(sumsq, (size_t)2 * B * 2 * T * 4 * (1 + grn_sumsq_slices(n)));  // sums, then the per-slice partial sums
   }
   ENS(step_cond, BN * mel * 4); ENS(cconst, M * D * 4); ENS(y, BN * mel * 4);
   ENS(h, M * D * 4); ENS(c1, M * D * 4); ENS(x, M * D * 4);
@@ -803,7 +803,7 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
     HIPCHK(launch_dwconv7_ln(tx, 2 * B, n, T, tb.dw7, tb.dw_b, tb.ln_w, tb.ln_b, 1e-6f, ctx->ta.as<float>(), st));
     GemmCore g = core(ctx->ta.p, T, tb.pw1_w, T, (int)M, 2 * T, T);
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->th.as<float>(), 2 * T, tb.pw1_b, ACT_GELU_ERF), 1, st));
-    HIPCHK(launch_grn_sumsq(ctx->th.as<float>(), 2 * B, n, 2 * T, ctx->sumsq.as<float>(), st));
+    HIPCHK(launch_grn_sumsq(ctx->th.as<float>(), 2 * B, n, 2 * T, ctx->sumsq.as<float>(), ctx->sumsq.as<float>() + (int64_t)2 * B * 2 * T, st));
     HIPCHK(launch_grn_apply(ctx->th.as<float>(), ctx->sumsq.as<float>(), tb.gamma, tb.beta, 2 * B, n, 2 * T, ctx->tg.as<float>(), st));
     g = core(ctx->tg.p, 2 * T, tb.pw2_w, 2 * T, (int)M, T, 2 * T);
     EpiStore e = epi_store(tx, T, tb.pw2_b);

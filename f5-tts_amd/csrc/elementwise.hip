@@ -190,22 +190,33 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
 // GRN
 // ---------------------------------------------------------------------------------------------
 // grid (C/64, S): block of 256 = 4 row-phases x 64 channels
-__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ h, int n, int C, float* sumsq) {
+// Two passes: blockIdx.z cuts the sequence into gridDim.z slices whose partial sums land in part[(s * RS + z) * C + c]; the finish kernel adds
+// them in slice order (deterministic).  One pass over a whole sequence per 64 channels (round 1) kept 32 workgroups busy for 100 us.
+__global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ h, int n, int C, float* part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int ph = threadIdx.x >> 6;
-  const int s = blockIdx.y;
+  const int s = blockIdx.y, RS = gridDim.z, z = blockIdx.z;
+  const int r0 = (int)((int64_t)n * z / RS), r1 = (int)((int64_t)n * (z + 1) / RS);
   float acc = 0.f;
   if (c < C) {
     const float* p = h + (int64_t)s * n * C + c;
-    for (int r = ph; r < n; r += 4) {
+    for (int r = r0 + ph; r < r1; r += 4) {
       const float v = p[(int64_t)r * C];
       acc += v * v;
     }
   }
   red[ph][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (ph == 0 && c < C) sumsq[(int64_t)s * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ph == 0 && c < C) part[((int64_t)s * RS + z) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void grn_sumsq_finish_kernel(const float* __restrict__ part, int RS, int64_t SC, int C, float* sumsq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // s * C + c
+  if (i >= SC) return;
+  const int64_t s = i / C, c = i - s * C;
+  float acc = 0.f;
+  for (int z = 0; z < RS; ++z) acc += part[(s * RS + z) * C + c];
+  sumsq[i] = acc;
 }
 
 // one wave per row; every wave first reduces mean_c(sqrt(sumsq[s,:])) (C floats, L2-resident)
@@ -440,8 +451,16 @@ hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w
   return hipGetLastError();
 }
 
-hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, hipStream_t s) {
-  hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S), dim3(256), 0, s, h, n, C, sumsq);
+int grn_sumsq_slices(int n) { return n >= 256 ? 32 : 1; }
+hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, float* part, hipStream_t s) {
+  const int RS = grn_sumsq_slices(n);  // part: S * RS * C floats (may alias sumsq when RS == 1)
+  if (RS == 1) {
+    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S, 1), dim3(256), 0, s, h, n, C, sumsq);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S, RS), dim3(256), 0, s, h, n, C, part);
+  const int64_t SC = (int64_t)S * C;
+  hipLaunchKernelGGL(grn_sumsq_finish_kernel, dim3((unsigned)((SC + 255) / 256)), dim3(256), 0, s, part, RS, SC, C, sumsq);
   return hipGetLastError();
 }
 hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,

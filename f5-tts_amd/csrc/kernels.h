@@ -37,7 +37,8 @@ hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w
                              const float* ln_b, float eps, float* out, hipStream_t s);
 // GRN (reference model/modules.py:242-245): sumsq[s, c] = sum_n h[s,n,c]^2 ; then
 //   out = gamma * (h * Gx / (mean_c(Gx) + 1e-6)) + beta + h
-hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, hipStream_t s);
+int grn_sumsq_slices(int n);  // sequence slices of the two-pass reduction; `part` holds S * slices * C floats
+hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, float* part, hipStream_t s);
 hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,
                             float* out, hipStream_t s);
 // zero rows where mask[row] != 0 (masked_fill), x [rows, C]
