@@ -38,12 +38,19 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
     hipLaunchKernelGGL(flash_combine_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, a, rows);
     return hipGetLastError();
   }
+  // Row sums of P: on the matrix pipe (a V^T fragment of ones, attention_kernel.h) where the kernel is VALU-bound — many workgroups per
+  // CU: -9 % at B' = 16, -4 % at B' = 64, -6 % at n = 3000 — and on the VALU for the one-round 192-row launch of a single utterance, which is
+  // latency-bound and pays +3 % for the extra dependent MFMAs at the end of a tile (tools/r2_call30.sh).  F5HIP_ATTN_VALU_SUM=1 / 0 forces.
+  static const int vsum_env = [] { const char* v = getenv("F5HIP_ATTN_VALU_SUM"); return v ? atoi(v) : -1; }();
+  const bool vsum = vsum_env >= 0 ? vsum_env == 1 : six;
   if (six) {
     a.nqb = nqb6; a.nwg = bh * nqb6;
-    hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6>), dim3(a.nwg), dim3(384), lds, s, a);
+    if (vsum && PVSPLIT == 1) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6, false, true>), dim3(a.nwg), dim3(384), lds, s, a);
+    else hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6>), dim3(a.nwg), dim3(384), lds, s, a);
   } else {
     a.nqb = nqb4; a.nwg = bh * nqb4;
-    hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4>), dim3(a.nwg), dim3(256), lds, s, a);
+    if (vsum && PVSPLIT == 1) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4, false, true>), dim3(a.nwg), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4>), dim3(a.nwg), dim3(256), lds, s, a);
   }
   return hipGetLastError();
 }
@@ -55,6 +62,14 @@ hipError_t set_attr() {
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           flash_lds_bytes<NSPLIT, PVSPLIT>());
   if (e != hipSuccess) return e;
+  if constexpr (PVSPLIT == 1) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            flash_lds_bytes<NSPLIT, PVSPLIT>());
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            flash_lds_bytes<NSPLIT, PVSPLIT>());
+    if (e != hipSuccess) return e;
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              flash_lds_bytes<NSPLIT, PVSPLIT>());
 }

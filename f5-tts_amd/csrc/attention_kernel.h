@@ -42,7 +42,7 @@ constexpr int flash_lds_bytes() {
 // NW: waves per workgroup = 32-row query groups per block.  4 (128 query rows, two workgroups per CU) everywhere except where 6
 // (192 rows, one workgroup per CU) makes the grid fit the chip in ONE round: B = 1, N = 1406 gives 11 x 32 = 352 blocks of 128 rows
 // (CUs with 2 and CUs with 1 workgroup: 69 % balance) but 8 x 32 = 256 blocks of 192 rows.  Only the first 4 waves stage K / V tiles.
-template <int NSPLIT, int PVSPLIT, int NW = 4, bool SPLIT = false>
+template <int NSPLIT, int PVSPLIT, int NW = 4, bool SPLIT = false, bool VSUM = false>  // VSUM: A/B switch — row sums on the VALU (round 1)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(FlashArgs a) {
   constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
@@ -140,6 +140,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
+  // Row sums on the matrix pipe (plain-fp16 P): the kernel is VALU-bound (33 exp + ~130 other VALU against 16 MFMAs per 64-key tile and
+  // wave), and 32 of those VALU are the adds of the row sum.  A V^T fragment of ones turns them into 4 MFMAs per tile on the pipe that
+  // has the slack: every accumulator row then holds sum_k P[q][k] over the 16 keys of a group — of BOTH half-waves, so the final
+  // lane ^ 32 exchange goes too.  The sum is that of the fp16 P the O product uses (numerator and denominator see the same weights).
+  constexpr bool MSUM = NPV == 1 && !VSUM;
+  Frag ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
 
   // one 64-key tile held in LDS stage `stage`: scores, online softmax, O update
   auto process = [&](int t, int stage) {
@@ -192,14 +200,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mb));
         s[kb][r] = p;
-        rs += p;
+        if constexpr (!MSUM) rs += p;
       }
-    l_run = l_run * alpha + rs;
+    if constexpr (!MSUM) l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+    f32x16 rsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rsum[r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // 16-key groups of the tile; P registers 8*(g&1) .. +7 of s[g>>1]
       Frag fp[NPV];
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
         fp[0].h[e] = ph;
         if constexpr (NPV == 2) fp[1].h[e] = (f16)(p - (float)ph);
       }
+      if constexpr (MSUM) Mma32<f16>::mma(rsum, ones, fp[0]);
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         Frag fv[NPV];
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
         }
       }
     }
+    if constexpr (MSUM) l_run = l_run * alpha + rsum[0];  // the whole row: both half-waves' keys
   };
 
   // Two register sets, as in gemm.h: the loads of tile t+2 are issued at the top of iteration t and written to LDS at the end
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   if (t < ntile) process(t0 + t, 0);
 
   // ---- normalise and store: lane (q, hi) owns O[q][32 db + 8 c + 4 hi + 0..3] --------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = MSUM ? l_run : l_run + __shfl_xor(l_run, 32, 64);
   if constexpr (SPLIT) {  // unnormalised partial result of this key range; flash_combine_kernel finishes the row
     if (qrow < n) {
       const int64_t prow = ((int64_t)bh * n + qrow) * a.kv_split + ks;
