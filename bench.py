@@ -339,7 +339,7 @@ def main():
             **({"gbps": round(v["bytes"] / (1e-3 * v["ms"]) / 1e9, 1)} if v["bytes"] and k not in ("gemm_block",) else {})}
         for k, v in stats.items() if v["calls"] and v["ms"] > 0}
     res["kernel_classes_ms"] = {k: round(v["ms"], 3) for k, v in stats.items() if v["calls"]}
-    res["kernel_classes_note"] = "profiled pass: eager, single chain, one event pair per launch; sum > ms_per_step (timed region: graph replay, two chains at small batch)"
+    res["kernel_classes_note"] = "profiled pass: eager, one chain, one event pair per launch (its dispatch gaps included); the timed region replays a graph and runs the cond / uncond halves as two concurrent chains where the engine's rule picks that (2048..17500 or >= 40000 rows per chain; DESIGN.md 3) — the classes rank the kernels, they do not partition ms_per_step"
     if not a.no_cpu_baseline and world == 1:
         try:
             res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen, (bcfg, bsd) if big else None)
