@@ -1,5 +1,7 @@
 #!/bin/bash
 # HBM-traffic PMC passes over one bench.py invocation (run on the GPU box; separate passes, counters only — no tracing).
+# NOTE: counter collection serialises every dispatch — the B = 1 NFE 16 line takes ~40 s per pass, but configs[2] (B = 32, NFE 32: 45 k large
+# dispatches) did not finish ONE pass in 14 minutes (round 2 lost its last GPU minutes that way): use --nfe 2 there.
 # usage: tools/pmc_bench.sh <tag> <bench.py args...>      -> gpurun_out/pmc_<tag>/{fetch,write}/..., gpurun_out/pmc_<tag>.json
 set -u
 tag=$1; shift
