@@ -8,7 +8,7 @@ for G in 0 22; do
   for shape in "6 2816 1024 2048" "1 2816 3072 1024"; do
     set -- $shape
     d=$out/g${G}_n$3
-    F5HIP_GEMM_GROUPM=$G rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $d -o p -- env KB_EPI=1 python $GRAFT_REPO_ROOT/tools/kernel_bench.py --schedule default one fp16x3 $1 $2 $3 $4 10 > $d.log 2>&1
+    F5HIP_GEMM_GROUPM=$G rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $d -o p -- env KB_EPI=1 python $GRAFT_REPO_ROOT/tools/kernel_bench.py one fp16x3 $1 $2 $3 $4 10 > $d.log 2>&1
   done
 done
 python - <<PY
