@@ -102,6 +102,17 @@ def test_deal_batches(corpus):
         assert max(bal) <= max(con)  # the greedy deal is never worse than the contiguous split of the shuffled list
 
 
+@needs_ref
+def test_metainfo_parsers_match_the_reference(tmp_path):
+    path = os.path.join(REF, "eval", "utils_eval.py")
+    lst = tmp_path / "meta.lst"
+    lst.write_text("u1|hello there.|wavs/p1.wav|generate this\nu2|second|/abs/p2.wav|and this|/abs/g2.wav\nu3|third one|p3.wav|more text\n")
+    assert EB.get_seedtts_testset_metainfo(str(lst)) == lift(path, "get_seedtts_testset_metainfo", {"os": os})(str(lst))
+    ls = tmp_path / "ls.lst"
+    ls.write_text("1-2-3\t4.0\tRef text.\t5-6-7\t3.0\tGen text.\n8-9-10\t2.5\tAnother ref\t8-9-11\t6.1\tAnother gen\n")
+    assert EB.get_librispeech_test_clean_metainfo(str(ls), "/ls") == lift(path, "get_librispeech_test_clean_metainfo", {"os": os})(str(ls), "/ls")
+
+
 def test_metainfo_parsers(tmp_path):
     lst = tmp_path / "meta.lst"
     lst.write_text("u1|hello there.|wavs/p1.wav|generate this\nu2|second|/abs/p2.wav|and this|/abs/g2.wav\n")
