@@ -138,3 +138,81 @@ def test_world2_gloo_engine_weight_broadcast(engine_emu_lib):  # noqa: F811
     assert res[0][1] == res[1][1] > 0
     assert np.isfinite(res[0][2]).all() and np.abs(res[0][2]).max() > 0
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def _bucket_worker(rank, world, port, lib_path, wav_dir, q):
+    import contextlib
+    import ctypes as C
+    import types
+    import wave as wave_mod
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import f5_tts_amd  # noqa: F401
+    from f5_tts_amd import binding, config, synth
+    from f5_tts_amd import dist as fd
+    from f5_tts_amd import engine as E
+    from f5_tts_amd import eval_batching as EB
+    from test_hipemu import host_alias
+
+    lib = C.CDLL(lib_path, mode=C.RTLD_LOCAL)
+    for name, (res, args) in binding.SYMBOLS.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+    E.load_library = lambda *a, **k: lib
+    E._as_tensor = host_alias
+    torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+    torch.cuda.current_stream = lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    fd.init_distributed(backend="gloo")
+    cfg, vcfg = config.DIT_TINY, config.VOCOS_TINY
+    eng = E.F5HipEngine(cfg, vcfg, device="cuda:0")
+    eng.device = torch.device("cpu")
+    if rank == 0:
+        eng.load_state_dict({**synth.synth_dit_state_dict(cfg, seed=5), **synth.synth_vocos_state_dict(vcfg, seed=5)}, finalize=False)
+    fd.broadcast_engine_weights(eng, src=0)
+    vocab = {chr(c): 1 + (c % (cfg.text_num_embeds - 2)) for c in range(32, 127)}
+    model, voc = E.F5HipCFM(eng, precision="fp32", vocab_char_map=vocab), E.F5HipVocos(eng)
+    meta = []
+    for i, (secs, words) in enumerate([(0.45, 3), (0.5, 4), (0.47, 3), (0.9, 6), (0.52, 4), (0.95, 7), (0.6, 2)]):
+        p = os.path.join(wav_dir, f"p{i}.wav")
+        if rank == 0:
+            x = 0.2 * np.random.default_rng(i).standard_normal(int(secs * 24000))
+            with wave_mod.open(p, "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000); w.writeframes((x.clip(-1, 1) * 32767).astype("<i2").tobytes())
+        meta.append((f"u{i}", "ab cd.", p, " ".join(["w"] * words), ""))
+    dist.barrier()  # the files exist
+    # every rank forms the SAME batch list (deterministic, seeded shuffle) and runs only its share
+    batches = EB.get_inference_prompt(meta, lambda wv: model.mel_spec(wv), tokenizer="char", infer_batch_size=150, min_secs=0, max_secs=3,
+                                      num_buckets=3)
+    mine = EB.deal_batches(batches, world)[rank]
+    got = EB.run_prompt_batches(model, voc, [batches[i] for i in mine], nfe_step=1, seed=1)
+    box = [None] * world
+    dist.all_gather_object(box, [(u, tuple(w.shape), float(w.abs().sum())) for u, w in got])
+    q.put((rank, len(batches), mine, box))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="needs the ROCm host clang++")
+def test_world2_gloo_bucketed_eval_batches(engine_emu_lib, tmp_path):  # noqa: F811
+    """eval_infer_batch.py:178-214 on two ranks: the same length-bucketed batch list on every rank, dealt by padded cost, every utterance
+    synthesised exactly once across the ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611 + (os.getpid() % 150)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, engine_emu_lib._name, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and sorted(res[0][2] + res[1][2]) == list(range(res[0][1]))  # same list, disjoint shares
+    assert res[0][3] == res[1][3]  # the gathered report is the same on both ranks
+    utts = [u for part in res[0][3] for u, _, _ in part]
+    assert sorted(utts) == [f"u{i}" for i in range(7)]
+    assert all(shape[0] == 1 and shape[1] > 0 and s > 0 for part in res[0][3] for _, shape, s in part)
