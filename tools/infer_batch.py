@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--model", default="F5TTS_v1_Base"); ap.add_argument("--ckpt"); ap.add_argument("--vocab"); ap.add_argument("--vocos")
     ap.add_argument("--synthetic", type=int, default=0); ap.add_argument("--nfe", type=int, default=16)
     ap.add_argument("--precision", default="fp16x3"); ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--testset", choices=["seedtts", "ls_pc_test_clean"], default=None,
+                    help="read --list with the reference's test-list parsers (eval/utils_eval.py:19-52) instead of the utt|wav|ref|gen layout")
+    ap.add_argument("--librispeech-path", default="", help="root of LibriSpeech test-clean for --testset ls_pc_test_clean")
     ap.add_argument("--frames-per-batch", type=int, default=0,
                     help="> 0: form length-bucketed batches with this frame budget (the reference's infer_batch_size, eval/utils_eval.py:72-205; "
                          "f5-tts_amd/eval_batching.py) instead of running the utterances one by one")
@@ -74,6 +77,12 @@ def main():
     if a.synthetic:
         utts = [(f"syn{i:04d}", (synth.synth_wave(24000 * (3 + i % 4), seed=i), 24000), "some call me nature, others call me mother nature.",
                  "i have been here for over four and a half billion years. " * (1 + i % 3)) for i in range(a.synthetic)]
+    elif a.testset:  # the reference's evaluation lists: (utt, prompt_text, prompt_wav, gt_text, gt_wav) -> (utt, wav, ref text, gen text)
+        from f5_tts_amd import eval_batching as EB
+
+        meta = (EB.get_seedtts_testset_metainfo(a.list) if a.testset == "seedtts"
+                else EB.get_librispeech_test_clean_metainfo(a.list, a.librispeech_path))
+        utts = [(utt, prompt_wav, prompt_text, gt_text) for utt, prompt_text, prompt_wav, gt_text, _gt_wav in meta]
     else:
         utts = []
         for line in open(a.list, encoding="utf-8"):
