@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
 
-ABI_VERSION = 6  # F5HIP_ABI_VERSION in include/f5hip.h
+ABI_VERSION = 7  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
 
@@ -58,6 +58,7 @@ SYMBOLS = {
     "f5hip_debug_tensor": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P]),
     "f5hip_vocos_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "f5hip_istft": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P]),
+    "f5hip_vocos_head": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P]),
     "f5hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "f5hip_num_kernel_stats": (C.c_int, [_P]),
     "f5hip_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -79,6 +80,7 @@ SYMBOLS = {
     "f5hip_bigvgan_reset_kernel_stats": (C.c_int, [_P]),
     "f5hip_bench_qkv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "f5hip_bench_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "f5hip_bench_qkv_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_char_p]),
 }
 
 _lib: Optional[C.CDLL] = None

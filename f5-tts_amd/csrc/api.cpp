@@ -1804,6 +1804,27 @@ int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, voi
 }
 
 // ---- vocoder -------------------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+// head.out Linear -> exp / clip(1e2) / cos / sin -> inverse STFT (frames + overlap-add); workspace vlogits / vframes sized by the caller
+int vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* out, hipStream_t st) {
+  const auto& v = ctx->vcfg;
+  const int C = v.dim, nout = v.n_fft + 2, npad = (nout + 3) & ~3;
+  const int64_t R = (int64_t)B * T;
+  {
+    Prof pr(ctx, st, KC_VOCOS_GEMM, gemm_flops(R, nout, C), 0);
+    GemmCore g = core(hidden, C, ctx->vhead_w.p, C, (int)R, npad, C);
+    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->vlogits.as<float>(), npad, ctx->vhead_b.as<float>()), 1, st));
+  }
+  {
+    Prof pr(ctx, st, KC_ISTFT, 0, (double)R * npad * 4 + 2.0 * R * v.n_fft * 4 + (double)B * 256.0 * (T - 1) * 4);
+    HIPCHK(launch_istft_frames(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
+    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
+  }
+  return F5HIP_OK;
+}
+}  // namespace
+extern "C" {
 int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int channel_major, float* out, void* stream) {
   if (!ctx || !melp || !out) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1857,16 +1878,26 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
     HIPCHK(launch_layernorm(vx, C, (int)R, C, 1e-6f, W(ctx, "backbone.final_layer_norm.weight"), W(ctx, "backbone.final_layer_norm.bias"), nullptr,
                             nullptr, ctx->va.as<float>(), nullptr, nullptr, C, st));
   }
-  {
-    Prof pr(ctx, st, KC_VOCOS_GEMM, gemm_flops(R, nout, C), 0);
-    GemmCore g = core(ctx->va.p, C, ctx->vhead_w.p, C, (int)R, npad, C);
-    HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->vlogits.as<float>(), npad, ctx->vhead_b.as<float>()), 1, st));
-  }
-  {
-    Prof pr(ctx, st, KC_ISTFT, 0, (double)R * npad * 4 + 2.0 * R * v.n_fft * 4 + (double)B * 256.0 * (T - 1) * 4);
-    HIPCHK(launch_istft_frames(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
-    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
-  }
+  CHK(vocos_head(ctx, ctx->va.as<float>(), B, T, out, st));
+  CHK(call_end(ctx, st));
+  collect_prof(ctx, st);
+  return F5HIP_OK;
+}
+
+// The ISTFTHead alone (vocos heads.py; the reference's runnable copy: runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:43-59):
+// hidden [B*T, dim] fp32 on the device -> waveform [B, 256 (T - 1)].
+int f5hip_vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* out, void* stream) {
+  if (!ctx || !hidden || !out) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->has_vocos) FAIL(F5HIP_ERR_STATE, "context was created without a vocoder config");
+  if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
+  if (B <= 0 || T < 2) FAIL(F5HIP_ERR_INVALID, "vocos head needs batch > 0 and frames >= 2");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(call_begin(ctx, st));
+  const int npad = (ctx->vcfg.n_fft + 2 + 3) & ~3;
+  HIPCHK(ctx->vlogits.ensure((size_t)B * T * npad * 4));
+  HIPCHK(ctx->vframes.ensure((size_t)B * T * ctx->vcfg.n_fft * 4));
+  CHK(vocos_head(ctx, hidden, B, T, out, st));
   CHK(call_end(ctx, st));
   collect_prof(ctx, st);
   return F5HIP_OK;

@@ -15,6 +15,9 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g, const EpiQKV& e, i
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s);
 // one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
 hipError_t init_gemm_kernels();
+// race_probe.hip: the reproducer of round 2's co-residency fault in the fused q|k|v epilogue (microbenchmarks / tests only)
+hipError_t launch_pp_qkv_probe(const GemmCore& g, const EpiQKV& e, int variant, int expt, int abl, int lds_pad, uint32_t* dbg, hipStream_t s);
+hipError_t launch_noise(const void* src, uint32_t bytes, int wgs, int rounds, int kind, int lds_bytes, uint32_t* sink, hipStream_t s);
 hipError_t init_convpos_kernels();
 
 // ---- elementwise.hip --------------------------------------------------------------------------

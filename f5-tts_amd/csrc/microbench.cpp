@@ -230,6 +230,102 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
   return time_it([&] { return launch_gemm_qkv_variant(op, g, epi(1), variant, s); }, iters, s, avg_ms);
 }
 
+// Reproducer of round 2's co-residency fault in the fused q|k|v epilogue (race_probe.hip): `reps` launches of tile `variant` with the
+// epilogue form `expt` (ablation `abl`, `lds_pad` extra LDS per workgroup, an optional co-tenant kernel on a second stream: noise 1 =
+// plain streaming loads, 2 = LDS-DMA), each compared with the generic kernel's q / k values and V^T bytes.  bad[r] = wrong outputs of
+// launch r.  With dump_path the wrong outputs of all launches are appended as records {int32 rep, plane, int64 index, float ref, got, partner ref, partner got}.
+int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int lds_pad, int noise, int seqs, int nseq, int reps, int64_t* bad,
+                          const char* dump_path) {
+  if (!ctx || !bad || seqs <= 0 || nseq <= 1 || reps <= 0) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
+  if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
+  hipStream_t s = nullptr, s2 = nullptr;
+  if (noise && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return F5HIP_ERR_HIP;
+  Tmp t;
+  const int K = 1024, H = 16, dh = 64, inner = H * dh, N = 3 * inner, M = seqs * nseq, ldv = (nseq + 7) & ~7;
+  float* a32 = t.get<float>((size_t)M * K);
+  float* w32 = t.get<float>((size_t)N * K);
+  float* bias = t.get<float>(N);
+  float* rope = t.get<float>((size_t)nseq * dh);
+  float* invf = t.get<float>(dh / 2);
+  f16 *ah = t.get<f16>((size_t)M * K * 2), *wh = t.get<f16>((size_t)N * K * 2);
+  const size_t nq = (size_t)seqs * H * nseq * dh, nv = (size_t)seqs * H * dh * ldv;
+  f16* out[2][3];
+  for (auto& o : out)
+    for (int i = 0; i < 3; ++i) {
+      o[i] = t.get<f16>(i < 2 ? nq : nv);
+      if (!o[i]) return F5HIP_ERR_HIP;
+    }
+  const uint32_t noise_bytes = 64u << 20;
+  void* nbuf = noise ? (void*)t.get<char>(noise_bytes) : nullptr;
+  uint32_t* sink = t.get<uint32_t>(4);
+  if (!a32 || !w32 || !bias || !rope || !invf || !ah || !wh || !sink || (noise && !nbuf)) return F5HIP_ERR_HIP;
+  std::vector<float> f(dh / 2);
+  for (int k = 0; k < dh / 2; ++k) f[k] = 1.0f / powf(10000.0f, (float)(2 * k) / (float)dh);
+  if (hipMemcpy(invf, f.data(), f.size() * 4, hipMemcpyHostToDevice) != hipSuccess || launch_rope_table(invf, nseq, dh / 2, rope, s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (fill(a32, (int64_t)M * K, 1u, 1.0f, s) != hipSuccess || fill(w32, (int64_t)N * K, 2u, 0.05f, s) != hipSuccess || fill(bias, N, 3u, 0.02f, s) != hipSuccess)
+    return F5HIP_ERR_HIP;
+  if (noise && hipMemsetAsync(nbuf, 1, noise_bytes, s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
+  GemmCore g{};
+  g.A = ah; g.W = wh; g.lda = (int64_t)K * 2; g.ldw = (int64_t)K * 2; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N; g.group_m = 1;
+  auto epi = [&](int which) {
+    EpiQKV e{};
+    e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = -1; e.qscale = 0.125f; e.ldvt = ldv;
+    e.q16 = out[which][0]; e.k16 = out[which][1]; e.vt16 = out[which][2];
+    return e;
+  };
+  for (int i = 0; i < 3; ++i)
+    if (hipMemsetAsync(out[0][i], 0, (i < 2 ? nq : nv) * sizeof(f16), s) != hipSuccess) return F5HIP_ERR_HIP;
+  if (launch_gemm_qkv_variant(OP_F16X3, g, epi(0), 1, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return F5HIP_ERR_HIP;
+  std::vector<f16> ref[3], got[3];
+  for (int i = 0; i < 3; ++i) {
+    ref[i].resize(i < 2 ? nq : nv);
+    got[i].resize(ref[i].size());
+    if (hipMemcpy(ref[i].data(), out[0][i], ref[i].size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return F5HIP_ERR_HIP;
+  }
+  double vmax[2] = {0, 0};
+  for (int i = 0; i < 2; ++i)
+    for (f16 v : ref[i]) vmax[i] = std::max(vmax[i], (double)fabsf((float)v));
+  FILE* dump = dump_path && *dump_path ? fopen(dump_path, "ab") : nullptr;
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int i = 0; i < 3; ++i)
+      if (hipMemsetAsync(out[1][i], 0, (i < 2 ? nq : nv) * sizeof(f16), s) != hipSuccess) return F5HIP_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return F5HIP_ERR_HIP;
+    if (noise && launch_noise(nbuf, noise_bytes, 512, 3, noise, 4096, sink, s2) != hipSuccess) return F5HIP_ERR_HIP;
+    if (hipMemsetAsync(sink, 0, 16, s) != hipSuccess) return F5HIP_ERR_HIP;
+    if (launch_pp_qkv_probe(g, epi(1), variant, expt, abl, lds_pad, sink + 1, s) != hipSuccess) return F5HIP_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess || (noise && hipStreamSynchronize(s2) != hipSuccess)) return F5HIP_ERR_HIP;
+    int64_t nb = 0;
+    for (int i = 0; i < 3; ++i) {
+      if (hipMemcpy(got[i].data(), out[1][i], got[i].size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return F5HIP_ERR_HIP;
+      // q, k: the generic kernel contracts the rope arithmetic differently, so a last bit of an fp16 value may differ (2^-11 relative);
+      // V^T carries no rope: byte for byte
+      for (size_t j = 0; j < got[i].size(); ++j) {
+        const float a = (float)ref[i][j], b = (float)got[i][j];
+        const bool wrong = i < 2 ? fabsf(a - b) > 1.5e-3f * std::max(fabsf(a), 2e-3f * (float)vmax[i]) : memcmp(&ref[i][j], &got[i][j], 2) != 0;
+        if (!wrong) continue;
+        ++nb;
+        if (dump && nb <= 20000) {
+          const int32_t hd[2] = {rep, i};
+          const int64_t idx = (int64_t)j;
+          // + the reference and the launch's value of the rope partner (channel d ^ 1 of the same token; for V^T: the neighbouring token)
+          const float vals[4] = {a, b, (float)ref[i][j ^ 1], (float)got[i][j ^ 1]};
+          fwrite(hd, 4, 2, dump); fwrite(&idx, 8, 1, dump); fwrite(vals, 4, 4, dump);
+        }
+      }
+    }
+    bad[rep] = nb;
+    uint32_t dbgv[4] = {0, 0, 0, 0};
+    if (hipMemcpy(dbgv, sink, 16, hipMemcpyDeviceToHost) != hipSuccess) return F5HIP_ERR_HIP;
+    if (dbgv[1]) fprintf(stderr, "QKV_PROBE launch %d: %u sine registers read differently right after the wait and 32 cycles later\n", rep, dbgv[1]);
+  }
+  if (dump) fclose(dump);
+  if (s2) (void)hipStreamDestroy(s2);
+  return F5HIP_OK;
+}
+
 // flash attention over [batch2 * heads, n, 64]; precision FP16 -> plain fp16 operands, FP16X3 -> hi/lo split
 int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms) {
   if (!ctx || !avg_ms || batch2 <= 0 || heads <= 0 || n <= 0 || iters <= 0 || precision == F5HIP_PREC_FP32) return F5HIP_ERR_INVALID;

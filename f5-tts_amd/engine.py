@@ -230,7 +230,6 @@ class F5HipEngine:
             self._chk(self.lib.f5hip_vocos_decode(self._ctx, _ptr(mel), b, frames, int(channel_major), _ptr(out), self._stream()))
         return out
 
-
     def istft(self, logits: torch.Tensor) -> torch.Tensor:
         """The Vocos head's inverse STFT alone: logits [batch, frames, ld >= 1026] = (log-magnitude | phase) -> wave [batch, 256 * (frames - 1)]."""
         logits = logits.to(device=self.device, dtype=torch.float32).contiguous()
@@ -238,6 +237,16 @@ class F5HipEngine:
         out = torch.empty((b, 256 * (frames - 1)), device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             self._chk(self.lib.f5hip_istft(self._ctx, _ptr(logits), ld, b, frames, _ptr(out), self._stream()))
+        return out
+
+
+    def vocos_head(self, hidden: torch.Tensor) -> torch.Tensor:
+        """The Vocos ISTFTHead alone: hidden [batch, frames, dim] (after final_layer_norm) -> wave [batch, 256 * (frames - 1)]."""
+        hidden = hidden.to(device=self.device, dtype=torch.float32).contiguous()
+        b, frames, _ = hidden.shape
+        out = torch.empty((b, 256 * (frames - 1)), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._chk(self.lib.f5hip_vocos_head(self._ctx, _ptr(hidden), b, frames, _ptr(out), self._stream()))
         return out
 
 

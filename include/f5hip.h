@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 6
+#define F5HIP_ABI_VERSION 7
 
 /* status codes */
 enum {
@@ -176,6 +176,11 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* mel, int batch, int frames, 
  * logits: device fp32 [batch * frames, ld], columns [0, 513) log-magnitude, [513, 1026) phase (ld >= 1026, ld % 4 == 0).
  * out: device fp32 [batch, 256 * (frames - 1)].  A component entry point for parity tests of the kernels f5hip_vocos_decode ends with. */
 int f5hip_istft(f5hip_ctx* ctx, const float* logits, int64_t ld, int batch, int frames, float* out, void* stream);
+/* The Vocos ISTFTHead alone: hidden [B*T, dim] (the backbone's output after final_layer_norm, fp32, device memory) -> head.out Linear ->
+ * exp -> clip(1e2) -> (cos, sin) -> inverse STFT, waveform [B, 256 (T - 1)].  Replaces vocos `ISTFTHead.forward`; the reference's own
+ * runnable copy is runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:43-59 (+ scripts/conv_stft.py:193-234), which is what
+ * tests/golden/vocos_head_ref.npz was minted from. */
+int f5hip_vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* out, void* stream);
 
 /* ---- BigVGAN generator (mel_spec_type "bigvgan") -------------------------------------------------- */
 /* replaces: the object load_vocoder(vocoder_name="bigvgan") returns — bigvgan.BigVGAN.from_pretrained(...), .remove_weight_norm(),
@@ -252,6 +257,11 @@ int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
 int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms);
 int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff);
 int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms);
+/* Reproducer of a co-residency fault found in round 2 (csrc/race_probe.hip; no reference counterpart): `reps`
+ * launches of the fused q|k|v GEMM on tile `variant` with epilogue form `expt`, each checked against the generic kernel; bad[r] = wrong
+ * outputs of launch r; dump_path (or NULL) receives the wrong outputs as binary records. */
+int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int lds_pad, int noise, int seqs, int nseq, int reps, int64_t* bad,
+                          const char* dump_path);
 
 #ifdef __cplusplus
 }

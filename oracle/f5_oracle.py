@@ -662,6 +662,12 @@ def vocos_decode(sd: SD, mel: Tensor, num_layers: int = 8, n_fft: int = 1024, ho
     return torch.istft(spec, n_fft, hop_length=hop, win_length=n_fft, window=sd["head.istft.window"], center=True)
 
 
+def vocos_head(sd: SD, hidden: Tensor, n_fft: int = 1024, hop: int = 256) -> Tensor:
+    """``ISTFTHead.forward`` alone (the reference's runnable copy: runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:43-59):
+    hidden [b, T, dim] -> wav [b, hop*(T-1)].  Pinned by tests/golden/vocos_head_ref*.npz, which the reference class itself produced."""
+    return torch.istft(vocos_head_spectrum(sd, hidden), n_fft, hop_length=hop, win_length=n_fft, window=sd["head.istft.window"], center=True)
+
+
 def istft_manual(spec: Tensor, n_fft: int = 1024, hop: int = 256) -> Tensor:
     """torch.istft(center=True) spelled out: irfft -> x window -> overlap-add -> / sum(window^2) ->
     trim n_fft/2 each side.  Used to pin the semantics the HIP kernel implements."""

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -213,6 +214,128 @@ def golden_vocos(pins):
                               nw=256 * 80, absmax=wav.abs().max().item())
 
 
+def golden_vocos_head(pins):
+    """The ISTFT head of Vocos as the REFERENCE restates it for its ONNX export (``runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:43-59``:
+    ``out`` Linear -> exp -> clip(1e2) -> cos / sin -> ``conv_stft.STFT.inverse``): the class is lifted out of the script with ``ast`` (the
+    script itself imports ``vocos`` / ``huggingface_hub``, absent here), given the seeded ``head.out`` layer of ``synth_vocos_state_dict`` and run on a
+    seeded hidden state.  Pins the head as a unit at the full Vocos width; the backbone stays unpinned."""
+    import ast
+    import torch.nn as nn
+
+    path = os.path.join(ref_shims.REFERENCE_SRC, "f5_tts", "runtime", "triton_trtllm", "scripts", "export_vocoder_to_onnx.py")
+    cls = next(n for n in ast.parse(open(path, encoding="utf-8").read()).body if isinstance(n, ast.ClassDef) and n.name == "ISTFTHead")
+    env = {"torch": torch, "nn": nn, "STFT": ref_shims.reference_conv_stft().STFT}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), path, "exec"), env)
+    for name, vcfg, vseed, T, hseed in (("vocos_head_ref", config.VOCOS_MEL_24K, 2, 96, 31), ("vocos_head_ref_tiny", config.VOCOS_TINY, 1, 40, 32)):
+        vsd = synth.synth_vocos_state_dict(vcfg, seed=vseed)
+        head = env["ISTFTHead"](vcfg.n_fft, vcfg.hop_length)
+        head.out = nn.Linear(vcfg.dim, vcfg.n_fft + 2)
+        with torch.no_grad():
+            head.out.weight.copy_(vsd["head.out.weight"])
+            head.out.bias.copy_(vsd["head.out.bias"])
+        g = torch.Generator().manual_seed(hseed)
+        hidden = torch.randn(2, T, vcfg.dim, generator=g)
+        hidden[1] *= 6.0  # second row: log-magnitudes large enough for the 1e2 clip to act on many bins
+        with torch.no_grad():
+            # one row per call: conv_stft.STFT.inverse divides by the window envelope through `th.where(coff > 1e-8)` on a [1, 1, L]
+            # tensor (conv_stft.py:221-233), which normalises batch row 0 ONLY — a batch of 2 comes back with row 1 un-normalised (0.08
+            # off torch.istft).  vocos itself calls torch.istft, so the single-row behaviour is the head's meaning.
+            # conv-iSTFT emits 256 T samples; the first 256 (T - 1) are torch.istft(center=True)'s
+            wav = torch.cat([head(hidden[r : r + 1])[:, : 256 * (T - 1)] for r in range(hidden.shape[0])])
+            logits = head.out(hidden)
+        clipped = (logits[..., : vcfg.n_fft // 2 + 1] > math.log(1e2)).float().mean().item()
+        d = (O.vocos_head(vsd, hidden) - wav).abs().max().item() if hasattr(O, "vocos_head") else float("nan")
+        print(f"{name}: reference ISTFTHead wav {tuple(wav.shape)} absmax {wav.abs().max().item():.3f}, clipped bins {clipped:.3f}, oracle-vs-reference {d:.2e}")
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), wav=wav.numpy())
+        pins[name] = dict(source="reference ISTFTHead (export_vocoder_to_onnx.py:43-59) + conv_stft.STFT.inverse, lifted with ast", vocos_seed=vseed,
+                          frames=T, hidden_seed=hseed, batch=2, row1_scale=6.0, clipped_bin_fraction=clipped, oracle_vs_reference=d,
+                          absmax=wav.abs().max().item())
+
+
+REAL_EXAMPLE = dict(wav="infer/examples/basic/basic_ref_en.wav", toml="infer/examples/basic/basic.toml", vocab="../../data/Emilia_ZH_EN_pinyin/vocab.txt",
+                    preset="F5TTS_v1_Base", wseed=0, kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0))
+
+
+def real_example_inputs():
+    """The reference's own example (``infer/examples/basic/basic.toml:4-6`` + ``basic_ref_en.wav``) taken through the reference's own glue up to
+    the sampler call: ``infer_process`` chunking (``utils_infer.py:400-402`` with ``chunk_text`` lifted out of the module), the RMS rule and the
+    duration heuristic of ``infer_batch_process`` / ``_infer_basic`` (``utils_infer.py:455-493``), ``convert_char_to_pinyin`` (``model/utils.py:148-185``,
+    the reference's function with ``rjieba.cut`` stubbed to return the whole string — exact for ASCII text).  The transcript gets
+    the ". " ending that ``preprocess_ref_audio_text`` gives it (``utils_infer.py:367-372``).  Returns (audio [1, nw] float32 after the RMS rule, the
+    int16 PCM it came from, token lists per chunk, durations per chunk, vocab map, chunks)."""
+    import ast
+    import re
+    import wave
+
+    ref_shims.install()
+    from f5_tts.model.utils import convert_char_to_pinyin
+
+    base = os.path.join(ref_shims.REFERENCE_SRC, "f5_tts")
+    toml = open(os.path.join(base, REAL_EXAMPLE["toml"]), encoding="utf-8").read()
+    ref_text = re.search(r'^ref_text = "(.*)"$', toml, re.M).group(1)
+    gen_text = re.search(r'^gen_text = "(.*)"$', toml, re.M).group(1)
+    if not ref_text.endswith(". "):
+        ref_text = ref_text + " " if ref_text.endswith(".") else ref_text + ". "
+    with wave.open(os.path.join(base, REAL_EXAMPLE["wav"])) as w:
+        assert w.getframerate() == 24000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").copy()
+    audio = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]  # torchaudio.load's normalisation of 16-bit PCM
+    sr = 24000
+    src = open(os.path.join(base, "infer", "utils_infer.py"), encoding="utf-8").read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "chunk_text")
+    env = {"re": re}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "utils_infer.py", "exec"), env)
+    max_chars = int(len(ref_text.encode("utf-8")) / (audio.shape[-1] / sr) * (22 - audio.shape[-1] / sr) * 1.0)
+    chunks = env["chunk_text"](gen_text, max_chars=max_chars)
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < 0.1:
+        audio = audio * 0.1 / rms
+    ref_audio_len = audio.shape[-1] // 256
+    texts, durations = [], []
+    for g in chunks:
+        speed = 0.3 if len(g.encode("utf-8")) < 10 else 1.0
+        texts.append(convert_char_to_pinyin([ref_text + g])[0])
+        durations.append(ref_audio_len + int(ref_audio_len / len(ref_text.encode("utf-8")) * len(g.encode("utf-8")) / speed))
+    with open(os.path.join(base, REAL_EXAMPLE["vocab"]), encoding="utf-8") as f:
+        vocab = {line[:-1]: i for i, line in enumerate(f)}
+    return audio, pcm, float(rms), texts, durations, vocab, chunks, ref_text
+
+
+def golden_real_example(pins):
+    """north_star's "identical (ref_audio, ref_text, gen_text, seed)": the reference's CFM.sample at the full F5-TTS v1 Base size on ITS OWN
+    example prompt and text (weights seeded: no checkpoint is reachable), one sample call per text chunk exactly as `infer_batch_process`
+    issues them.  The fixture carries the inputs too (PCM, token ids, durations): the wav lives in /root/reference, absent on the GPU box."""
+    audio, pcm, rms, texts, durations, vocab, chunks, ref_text = real_example_inputs()
+    cfg = config.PRESETS[REAL_EXAMPLE["preset"]]
+    assert len(vocab) == cfg.text_num_embeds
+    sd = synth.synth_dit_state_dict(cfg, seed=REAL_EXAMPLE["wseed"])
+    CFM, DiT, _ = ref_shims.reference_classes()
+    model = CFM(transformer=DiT(**cfg.arch_kwargs()), mel_spec_kwargs=ref_shims.MEL_KW, odeint_kwargs=dict(method="euler"), vocab_char_map=vocab)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    from f5_tts.model.utils import list_str_to_idx
+
+    save = dict(pcm=pcm, rms=np.float32(rms), durations=np.asarray(durations, dtype=np.int64))
+    t_ref = 0.0
+    for i, (text, dur) in enumerate(zip(texts, durations)):
+        ids = list_str_to_idx([text], vocab)  # what CFM.sample derives from the string list (cfm.py:108-113)
+        t0 = time.time()
+        with torch.no_grad():
+            out, traj = model.sample(cond=audio, text=[text], duration=dur, **REAL_EXAMPLE["kw"])
+        t_ref += time.time() - t0
+        out_o, _ = O.cfm_sample(sd, cfg, audio, ids, dur, **REAL_EXAMPLE["kw"])
+        d = (out - out_o).abs().max().item()
+        print(f"real_example chunk {i}: {len(text)} tokens, duration {dur} frames, reference {time.time() - t0:.1f}s, out absmax {out.abs().max().item():.3f}, "
+              f"oracle-vs-reference {d:.2e}: {chunks[i]!r}")
+        save[f"ids_{i}"] = ids[0].numpy().astype(np.int64)
+        save[f"out_{i}"] = out.numpy()
+        save[f"traj1_{i}"] = traj[1].numpy()
+        pins[f"real_example_chunk{i}"] = dict(tokens=len(text), duration=dur, oracle_vs_reference_out=d, out_absmax=out.abs().max().item())
+    np.savez_compressed(os.path.join(GOLD, "real_example.npz"), **save)
+    pins["real_example"] = dict(case=REAL_EXAMPLE, ref_text=ref_text, chunks=chunks, prompt_rms=rms, prompt_samples=int(pcm.shape[0]), reference_seconds=t_ref,
+                                source="reference CFM.sample (vocab_char_map given) on infer/examples/basic: basic_ref_en.wav + basic.toml ref_text / gen_text")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also mint the full-size goldens (~1 min of CPU each)")
@@ -226,6 +349,7 @@ def main():
     pin_mel(pins)
     pin_mel_bigvgan(pins)
     golden_vocos(pins)
+    golden_vocos_head(pins)
     only = set(filter(None, args.only.split(",")))
     for name, c in CASES.items():
         if not only or name in only:
@@ -233,6 +357,8 @@ def main():
     for name, c in FULL_CASES.items():
         if (args.full and not only) or name in only:
             run_case(name, c, pins)
+    if (args.full and not only) or "real_example" in only:
+        golden_real_example(pins)
     pins["_meta"] = dict(torch=torch.__version__, reference="/root/reference (SWivid/F5-TTS v1.1.20)", generated_by="oracle/make_golden.py")
     json.dump(pins, open(pins_path, "w"), indent=1, sort_keys=True)
 

@@ -338,6 +338,39 @@ def test_full_size_base_config1_golden():
         eng.close()
 
 
+def test_reference_example_prompt_and_text_golden():
+    """north_star "identical (ref_audio, ref_text, gen_text, seed)": the reference's OWN example — infer/examples/basic/basic_ref_en.wav with
+    basic.toml's transcript and text — taken through its own glue (chunking, RMS rule, duration heuristic, convert_char_to_pinyin with the
+    ASCII branch, list_str_to_idx over its Emilia vocab) and its CFM.sample at the full F5-TTS v1 Base size, one call per text chunk
+    (oracle/make_golden.py::golden_real_example; 148 s + 106 s of reference CPU time).  A real recording instead of 0.1 N(0,1) noise, real
+    token statistics, and sequence lengths the synthetic cases do not have (1829 and 743 frames)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    g = gold("real_example")
+    kw = MG.REAL_EXAMPLE["kw"]
+    cfg = config.PRESETS[MG.REAL_EXAMPLE["preset"]]
+    audio = torch.from_numpy(g["pcm"].astype(np.float32) / 32768.0)[None]
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    assert abs(float(rms) - float(g["rms"])) < 1e-6
+    if rms < 0.1:
+        audio = audio * 0.1 / rms  # utils_infer.py:455-457
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=MG.REAL_EXAMPLE["wseed"]))
+    try:
+        prompt_frames = audio.shape[-1] // 256
+        for i, dur in enumerate(g["durations"].tolist()):
+            ids = torch.from_numpy(g[f"ids_{i}"])[None]
+            for prec, tol in (("fp16x3", MEL_TOL), ("fp32", TIGHT)):
+                out, traj = F5HipCFM(eng, precision=prec).sample(audio.cuda(), ids, dur, **kw)
+                assert tuple(out.shape) == g[f"out_{i}"].shape == (1, dur, 100)
+                e = maxerr(out[:, prompt_frames:], g[f"out_{i}"][:, prompt_frames:])
+                print(f"reference example chunk {i} ({dur} frames) {prec}: generated-mel max-abs {e:.2e}")
+                assert e < tol
+                assert maxerr(traj[1], g[f"traj1_{i}"]) < tol
+    finally:
+        eng.close()
+
+
 def test_full_size_e2_unett_golden():
     """BASELINE.json configs[4] backbone: E2-TTS Base (UNetT, 333 M parameters) at full size against the golden minted by running the
     reference's own UNetT through CFM.sample on CPU (54 s there)."""
@@ -698,6 +731,31 @@ def test_hip_istft_against_the_reference_conv_istft_fixture(engines):
     ref = g["wav"][:, :256 * (T - 1)]
     assert w.shape == ref.shape
     assert maxerr(w, ref) < 5e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name,vname,vseed,frames,hseed", [("vocos_head_ref", "VOCOS_MEL_24K", 2, 96, 31), ("vocos_head_ref_tiny", "VOCOS_TINY", 1, 40, 32)])
+def test_vocos_head_against_the_reference_istft_head(name, vname, vseed, frames, hseed):
+    """f5hip_vocos_head (head.out GEMM -> exp -> clip(1e2) -> cos / sin -> HIP inverse STFT) against the wave the REFERENCE's own ISTFTHead
+    produced (runtime/triton_trtllm/scripts/export_vocoder_to_onnx.py:43-59 + scripts/conv_stft.py, lifted and run by
+    oracle/make_golden.py::golden_vocos_head) for the seeded `head.out` layer and hidden state: the Vocos head pinned as a unit at the full
+    width; row 1 is scaled so that 3 % of its magnitude bins hit the clip."""
+    from f5_tts_amd.engine import F5HipEngine
+
+    vcfg = getattr(config, vname)
+    vsd = synth.synth_vocos_state_dict(vcfg, seed=vseed)
+    hidden = torch.randn(2, frames, vcfg.dim, generator=torch.Generator().manual_seed(hseed))
+    hidden[1] *= 6.0
+    ref = gold(name)["wav"]
+    eng = F5HipEngine(config.DIT_TINY, vcfg, device=0)
+    eng.load_state_dict({**synth.synth_dit_state_dict(config.DIT_TINY, seed=1), **vsd})
+    try:
+        w = eng.vocos_head(hidden.cuda())
+        assert w.shape == ref.shape == (2, 256 * (frames - 1))
+        e, scale = maxerr(w, ref), float(np.abs(ref).max())
+        print(f"{name}: head wave max-abs {e:.2e} of max |wave| {scale:.2e}")
+        assert e < 5e-5 * max(1.0, scale)
+    finally:
+        eng.close()
 
 
 def test_configs2_shaped_batch_golden():

@@ -6,6 +6,11 @@ compiler can vouch for:
   while a DMA is pending — which is why the fragment reads are inline asm).  The disassembly of every gemm_pp kernel is scanned: the
   k-loop of a 3-stage kernel waits with a COUNTED vmcnt only, every kernel has exactly one s_barrier in its k-loop.
 * no kernel of the library spills to scratch.
+* no kernel of the library holds a packed-fp32 instruction in the operand form that loses src1 on gfx950 while another wave on the SIMD
+  issues MFMAs and LDS reads (op_sel: src0 low half from the low register, src1 low half from the HIGH register — found in round 3 as
+  the cause of round 2's "co-residency race"; reproducer tools/probes/pk_opsel_probe.hip, sweep tools/probes/pk_opsel_sweep.hip).  The
+  library is built with -packed-fp32-ops, so hipcc emits no v_pk_{add,mul,fma}_f32 at all; only the reproducer (csrc/race_probe.hip)
+  keeps them.
 """
 import os
 import re
@@ -126,3 +131,32 @@ def test_no_kernel_spills(code_objects):
                 spilled.append((k["name"], k["private_segment_fixed_size"]))
     assert n > 100, n
     assert not spilled, spilled
+
+
+PK_F32 = re.compile(r"^v_pk_(add|mul|fma)_f32\b")
+PK_LOSES_SRC1 = re.compile(r"op_sel:\[0,1[,\]]")  # src0.lo <- low register, src1.lo <- HIGH register (18 of 18 failing forms of the sweep)
+
+
+def test_no_packed_fp32_in_the_form_that_loses_an_operand(code_objects):
+    """hipcc picks the failing form freely (a complex multiply is enough: v_pk_fma_f32 ... op_sel:[0,1,0]); round 2's production tiles
+    carried 480 such instructions and were only safe because their SIMD partners sat in the same epilogue.  Every kernel outside the
+    reproducer must be free of the form — and, with the build flag, of packed fp32 altogether."""
+    bad, packed, kernels = [], 0, 0
+    for co in code_objects:
+        dis = subprocess.run([TOOLS[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        name = None
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+            if m:
+                name = m.group(1)
+                kernels += 1
+                continue
+            ins = ln.split("//")[0].strip()
+            if not name or "Probe" in name or not PK_F32.match(ins):
+                continue
+            packed += 1
+            if PK_LOSES_SRC1.search(ins):
+                bad.append((name[:120], ins))
+    assert kernels > 100, kernels
+    assert not bad, bad[:5]
+    assert packed == 0, f"{packed} packed-fp32 instructions outside the reproducer: was the library built without -packed-fp32-ops?"

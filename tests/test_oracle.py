@@ -41,6 +41,8 @@ def test_pins_recorded():
     pins = json.load(open(os.path.join(GOLD, "pins.json")))
     for name in list(MG.CASES) + list(MG.FULL_CASES):
         assert pins[name]["oracle_vs_reference_out"] < TOL
+    for name in ("real_example_chunk0", "real_example_chunk1", "vocos_head_ref", "vocos_head_ref_tiny"):  # minted from the reference, oracle checked there
+        assert pins[name].get("oracle_vs_reference_out", pins[name].get("oracle_vs_reference")) < TOL
     assert pins["conv_stft"]["inverse_vs_torch_istft"] < 1e-5
     assert pins["conv_stft"]["transform_vs_torch_stft"] < 1e-4
 
@@ -82,6 +84,33 @@ def test_vocos_oracle_golden_roundtrip():
     wav = O.vocos_decode(vsd, mel, vcfg.num_layers)
     assert wav.shape == (1, 256 * (mel.shape[-1] - 1))
     assert np.abs(wav.numpy() - gold("vocos_tiny")["wav"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,vname,vseed,frames,hseed", [("vocos_head_ref", "VOCOS_MEL_24K", 2, 96, 31), ("vocos_head_ref_tiny", "VOCOS_TINY", 1, 40, 32)])
+def test_vocos_head_oracle_matches_reference_golden(name, vname, vseed, frames, hseed):
+    """The oracle's ISTFT head against the wave the reference's own ISTFTHead class produced (export_vocoder_to_onnx.py:43-59 + conv_stft.py)."""
+    vcfg = getattr(config, vname)
+    vsd = synth.synth_vocos_state_dict(vcfg, seed=vseed)
+    hidden = torch.randn(2, frames, vcfg.dim, generator=torch.Generator().manual_seed(hseed))
+    hidden[1] *= 6.0
+    ref = gold(name)["wav"]
+    assert np.abs(O.vocos_head(vsd, hidden).numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_real_example_fixture_is_the_reference_example():
+    """tests/golden/real_example.npz carries the reference's example prompt and token ids; with /root/reference present, rebuild them from
+    the files and compare (the full-size sample itself is compared on the GPU; the oracle's distance to the reference is in pins.json)."""
+    g = gold("real_example")
+    pins = json.load(open(os.path.join(GOLD, "pins.json")))
+    assert g["pcm"].dtype == np.int16 and g["pcm"].shape == (pins["real_example"]["prompt_samples"],) and 5.3 < g["pcm"].shape[0] / 24000 < 5.4
+    assert g["durations"].tolist() == [g["out_0"].shape[1], g["out_1"].shape[1]]
+    if not ref_shims.reference_available():
+        pytest.skip("reference tree not present")
+    audio, pcm, rms, texts, durations, vocab, chunks, ref_text = MG.real_example_inputs()
+    assert np.array_equal(pcm, g["pcm"]) and durations == g["durations"].tolist()
+    for i, t in enumerate(texts):
+        assert [vocab.get(c, 0) for c in t] == g[f"ids_{i}"].tolist()
+    assert ref_text.endswith(". ") and len(chunks) == 2
 
 
 def test_time_grid():

@@ -49,6 +49,18 @@ def main():
                 print(f"qkv {prec} {VARIANTS.get(v, v)} seqs={seqs} nseq={nseq}: st={st} {ms.value * 1e3:.1f} us differing halves {diff.value}", flush=True)
         eng.close()
         return
+    if what == "qkvprobe":  # qkvprobe <seqs> <nseq> <reps> <spec;spec;..>  spec = variant,expt[,abl[,lds_pad[,noise]]]  (csrc/race_probe.hip)
+        seqs, nseq, reps = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        dump = os.environ.get("KB_PROBE_DUMP", "")
+        bad = (C.c_int64 * reps)()
+        for spec in sys.argv[5].split(";"):
+            f = [int(x) for x in spec.split(",")] + [0, 0, 0]
+            v, expt, abl, pad, noise = f[:5]
+            path = f"{dump}.v{v}e{expt}a{abl}p{pad}n{noise}.bin" if dump else ""
+            st = lib.f5hip_bench_qkv_probe(ctx, v, expt, abl, pad, noise, seqs, nseq, reps, bad, path.encode() if path else None)
+            print(f"qkvprobe tile {v} expt {expt} abl {abl} lds_pad {pad} noise {noise} seqs={seqs} nseq={nseq}: st={st} wrong outputs per launch {list(bad)}", flush=True)
+        eng.close()
+        return
     if what == "oneattn":  # oneattn <prec> <batch2> <n> [iters]
         prec, b2, n = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
         iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
