@@ -109,20 +109,27 @@ class F5TTS:
     def infer(self, ref_file, ref_text, gen_text, show_info=print, progress=None, target_rms=0.1, cross_fade_duration=0.15,
               sway_sampling_coef=-1, cfg_strength=2, nfe_step=32, speed=1.0, fix_duration=None, remove_silence=False, file_wave=None,
               file_spec=None, seed=None, vocoder=None):
-        """reference api.py:98-149.  ``seed`` also reaches every chunk's ``sample`` call, which makes multi-chunk requests reproducible
-        under the thread pool (the reference only seeds the global generator)."""
-        if seed is None:
-            seed = random.randint(0, sys.maxsize)
-        seed_everything(seed)
-        self.seed = seed
-        ref_file, ref_text = preprocess_ref_audio_text(ref_file, ref_text, show_info=show_info, transcribe=self._transcribe)
-        wav, sr, spec = I.infer_process(ref_file, ref_text, gen_text, self.ema_model, vocoder if vocoder is not None else self.vocoder,
-                                        self.mel_spec_type, show_info=show_info, progress=progress, target_rms=target_rms,
-                                        cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
-                                        sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration, device=self.device,
-                                        seed=seed % (2**63))
-        if file_wave is not None:
-            self.export_wav(wav, file_wave, remove_silence)
-        if file_spec is not None:
-            self.export_spectrogram(spec, file_spec)
+        """One request, the call surface of reference api.py:98-149: clip / transcribe the prompt, synthesise chunk by chunk, optionally write
+        the wave and the spectrogram.  Returns ``(wave, sample_rate, mel)``.  Unlike the reference, the seed is also handed to every chunk's
+        ``sample`` call — the chunks of one request run on a thread pool, and the global generator alone would not make them reproducible."""
+        self.seed = self._reseed(seed)
+        prompt_file, prompt_text = preprocess_ref_audio_text(ref_file, ref_text, show_info=show_info, transcribe=self._transcribe)
+        sampler_options = dict(target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step, cfg_strength=cfg_strength,
+                               sway_sampling_coef=sway_sampling_coef, speed=speed, fix_duration=fix_duration)
+        wav, sr, spec = I.infer_process(prompt_file, prompt_text, gen_text, self.ema_model, self.vocoder if vocoder is None else vocoder,
+                                        self.mel_spec_type, show_info=show_info, progress=progress, device=self.device,
+                                        seed=self.seed % (2**63), **sampler_options)
+        self._write_outputs(wav, spec, file_wave, file_spec, remove_silence)
         return wav, sr, spec
+
+    @staticmethod
+    def _reseed(seed: Optional[int]) -> int:
+        """A caller-given seed, or a fresh one; either way every generator is reset to it (reference api.py:117-120)."""
+        chosen = random.randint(0, sys.maxsize) if seed is None else seed
+        seed_everything(chosen)
+        return chosen
+
+    def _write_outputs(self, wav, spec, file_wave, file_spec, remove_silence: bool) -> None:
+        for path, write in ((file_wave, lambda p: self.export_wav(wav, p, remove_silence)), (file_spec, lambda p: self.export_spectrogram(spec, p))):
+            if path is not None:
+                write(path)

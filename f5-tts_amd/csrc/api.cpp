@@ -60,6 +60,28 @@ int call_end(f5hip_ctx* ctx, hipStream_t st) {
   ctx->have_last = true;
   return F5HIP_OK;
 }
+// begin() / finish() of one entry point; the destructor finishes a call that leaves through an error return, so that whatever it had
+// already queued on `st` is ordered before the next call's work on the shared workspace (ev_last) and its staging slot gets its event.
+struct CallScope {
+  f5hip_ctx* ctx;
+  hipStream_t st;
+  bool open = false;
+  CallScope(f5hip_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+  CallScope(const CallScope&) = delete;
+  CallScope& operator=(const CallScope&) = delete;
+  int begin() {
+    const int r = call_begin(ctx, st);
+    open = r == F5HIP_OK || ctx->stage.in_call;
+    return r;
+  }
+  int finish() {
+    open = false;
+    return call_end(ctx, st);
+  }
+  ~CallScope() {
+    if (open) (void)call_end(ctx, st);
+  }
+};
 
 int add_slot(f5hip_ctx* ctx, const std::string& name, int64_t numel, bool optional = false) {
   Slot s;
@@ -1610,14 +1632,15 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float*
   const int frames = mel_type == 1 ? (int)((nsamp + 2 * pad - 1024) / 256) + 1 : 1 + (int)(nsamp / 256);
   if (frames <= 0) FAIL(F5HIP_ERR_INVALID, "wave of %lld samples is shorter than one frame", (long long)nsamp);
   hipStream_t st = (hipStream_t)stream;
-  CHK(call_begin(ctx, st));
+  CallScope scope(ctx, st);
+  CHK(scope.begin());
   {
     Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
     HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(),
                       mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(), ctx->cfg.mel_dim, frame_major, pad,
                       mel_type == 1 ? 1e-9f : 0.f, out, st));
   }
-  CHK(call_end(ctx, st));
+  CHK(scope.finish());
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1637,7 +1660,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   for (int b = 0; b < B; ++b)
     if (duration[b] <= 0 || duration[b] > n) FAIL(F5HIP_ERR_INVALID, "duration[%d]=%lld outside (0, n=%d]", b, (long long)duration[b], n);
   hipStream_t st = (hipStream_t)stream;
-  CHK(call_begin(ctx, st));
+  CallScope scope(ctx, st);
+  CHK(scope.begin());
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
   // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 / fp16x3 -> flash attention with plain fp16 operands), 1 force materialised,
@@ -1777,7 +1801,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   }
   ctx->last_B = B;
   ctx->last_n = n;
-  CHK(call_end(ctx, st));
+  CHK(scope.finish());
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1832,7 +1856,8 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
   if (B <= 0 || T < 2) FAIL(F5HIP_ERR_INVALID, "vocos decode needs batch > 0 and frames >= 2");
   hipStream_t st = (hipStream_t)stream;
-  CHK(call_begin(ctx, st));
+  CallScope scope(ctx, st);
+  CHK(scope.begin());
   const auto& v = ctx->vcfg;
   const int C = v.dim, I = v.intermediate_dim, Cin = v.input_channels;
   const int64_t R = (int64_t)B * T;
@@ -1879,7 +1904,7 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
                             nullptr, ctx->va.as<float>(), nullptr, nullptr, C, st));
   }
   CHK(vocos_head(ctx, ctx->va.as<float>(), B, T, out, st));
-  CHK(call_end(ctx, st));
+  CHK(scope.finish());
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1893,12 +1918,13 @@ int f5hip_vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* o
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised");
   if (B <= 0 || T < 2) FAIL(F5HIP_ERR_INVALID, "vocos head needs batch > 0 and frames >= 2");
   hipStream_t st = (hipStream_t)stream;
-  CHK(call_begin(ctx, st));
+  CallScope scope(ctx, st);
+  CHK(scope.begin());
   const int npad = (ctx->vcfg.n_fft + 2 + 3) & ~3;
   HIPCHK(ctx->vlogits.ensure((size_t)B * T * npad * 4));
   HIPCHK(ctx->vframes.ensure((size_t)B * T * ctx->vcfg.n_fft * 4));
   CHK(vocos_head(ctx, hidden, B, T, out, st));
-  CHK(call_end(ctx, st));
+  CHK(scope.finish());
   collect_prof(ctx, st);
   return F5HIP_OK;
 }
@@ -1909,14 +1935,15 @@ int f5hip_istft(f5hip_ctx* ctx, const float* logits, int64_t ld, int B, int T, f
   if (!ctx->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised (the twiddle / window tables are built there)");
   if (B <= 0 || T < 2 || ld < 1026 || (ld & 3)) FAIL(F5HIP_ERR_INVALID, "istft needs batch > 0, frames >= 2, ld >= 1026 and ld %% 4 == 0");
   hipStream_t st = (hipStream_t)stream;
-  CHK(call_begin(ctx, st));
+  CallScope scope(ctx, st);
+  CHK(scope.begin());
   HIPCHK(ctx->vframes.ensure((size_t)B * T * 1024 * 4));
   {
     Prof pr(ctx, st, KC_ISTFT, 0, (double)B * T * ld * 4 + 2.0 * B * T * 1024 * 4 + (double)B * 256.0 * (T - 1) * 4);
     HIPCHK(launch_istft_frames(logits, ld, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
     HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
   }
-  CHK(call_end(ctx, st));
+  CHK(scope.finish());
   collect_prof(ctx, st);
   return F5HIP_OK;
 }

@@ -64,7 +64,16 @@ struct HostStage {
     bool open = false;      // begin() without end(): an error path left copies queued without an event
   } slot[RING];
   int cur = -1;
+  bool in_call = false;  // between begin() and end()
+  bool taken = false;    // this call has claimed a ring slot (its first alloc())
+  // A call claims a ring slot only when it stages something (its first alloc()): entry points that stage nothing (f5hip_mel, f5hip_istft)
+  // neither advance the ring nor make the host wait once RING calls are outstanding.
   hipError_t begin() {
+    in_call = true;
+    taken = false;
+    return hipSuccess;
+  }
+  hipError_t claim() {
     cur = (cur + 1) % RING;
     SlotS& s = slot[cur];
     hipError_t e = hipSuccess;
@@ -74,9 +83,11 @@ struct HostStage {
     s.recorded = false;
     s.open = true;
     for (auto& c : s.chunks) c.used = 0;
+    taken = true;
     return hipSuccess;
   }
   void* alloc(size_t bytes) {
+    if (!taken && claim() != hipSuccess) return nullptr;
     SlotS& s = slot[cur];
     bytes = (bytes + 63) & ~size_t(63);
     for (auto& c : s.chunks)
@@ -88,11 +99,15 @@ struct HostStage {
     s.chunks.push_back(c);
     return c.p;
   }
+  // Always reached once per begin() — the entry points hold a CallScope (api.cpp) whose destructor calls it on every return path — so a
+  // failed call's queued copies get their event too and the slot is reclaimed by an event wait, not by a device-wide synchronise.
   hipError_t end(hipStream_t st) {
+    in_call = false;
+    if (!taken) return hipSuccess;
     SlotS& s = slot[cur];
     if (!s.done) { hipError_t e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming); if (e != hipSuccess) return e; }
     hipError_t e = hipEventRecord(s.done, st);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) return e;  // (the slot stays `open`: the next claim of it synchronises the device)
     s.recorded = true;
     s.open = false;
     return hipSuccess;

@@ -177,6 +177,10 @@ bool pp_applies(const GemmCore& g, int batch) {
          (int64_t)g.a_rows * g.lda * 2 < (int64_t)0x7ff00000 && (int64_t)g.w_rows * g.ldw * 2 < (int64_t)0x7ff00000;
 }
 
+// "this tile does not take this launch" (the caller falls back to the generic kernel): a value no HIP call returns here, so that a real
+// launch failure is never mistaken for it
+constexpr hipError_t PP_NOT_APPLICABLE = hipErrorNotSupported;
+
 template <int NSPLIT, int ID, typename Epi, int ABL = 0>
 hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   using C = PpV<ID>;
@@ -185,18 +189,16 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   static_assert(C::KSP * C::KSS == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the split tiles reuses the ring");
   if constexpr (C::KSS > 1) {  // even / odd tiles alternate the fragment buffers: an even number of k-tiles, a whole pipeline
     const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
-    if (kt % 2 != 0 || kt < C::NS + 1) return hipErrorInvalidValue;
+    if (kt % 2 != 0 || kt < C::NS + 1) return PP_NOT_APPLICABLE;
   }
   if constexpr (C::KSP > 1) {  // each group needs its own whole pipeline: k-tiles split evenly, at least NS + 1 per group
     const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
-    if (kt % C::KSP != 0 || kt / C::KSP < C::NS + 1) return hipErrorInvalidValue;
+    if (kt % C::KSP != 0 || kt / C::KSP < C::NS + 1) return PP_NOT_APPLICABLE;
   }
   auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL, C::KSP, C::KSS>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  if constexpr (ABL != 0) {  // microbenchmark ablations only: the production instantiations get their limit in init_gemm_kernels()
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
-    attr_done = true;
   }
   dim3 grid(((g.M + C::BM - 1) / C::BM) * ((g.N + C::BN - 1) / C::BN), 1, 1);
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;  // which kernel ran (tests, tuning)
@@ -229,13 +231,14 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
     case 68: return launch_pp_one<NSPLIT, 68, Epi>(g, e, s);
     case 69: return launch_pp_one<NSPLIT, 69, Epi>(g, e, s);
     case 70: return launch_pp_one<NSPLIT, 70, Epi>(g, e, s);
-    default: return hipErrorInvalidValue;
+    default: return PP_NOT_APPLICABLE;
   }
 }
 
 // Tile choice.  A launch costs rounds x (time of one workgroup), so prefer the tile whose workgroup count fills whole rounds of the CUs
 // with the largest wave tiles; measured tables: DESIGN.md section 4 (tools/kernel_bench.py, profiles/r02*).
-int pick_pp_variant(const GemmCore& g, bool qkv = false) {
+inline int64_t ktiles_of(const GemmCore& g, int nsplit_planes) { return (int64_t)g.K * 2 * nsplit_planes / GEMM_KTB; }
+int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
   static const int forced = [] { const char* e = getenv("F5HIP_PP_VARIANT"); return e ? atoi(e) : -1; }();  // tuning knob; 0 = never use the pipelined kernel
   if (forced >= 0) return forced;
   static const int f3072 = [] { const char* e = getenv("F5HIP_PP_VARIANT_N3072"); return e ? atoi(e) : -1; }();  // per-shape tuning knobs (tools/)
@@ -246,43 +249,47 @@ int pick_pp_variant(const GemmCore& g, bool qkv = false) {
   if (g.N == 1024 && f1024 >= 0) return f1024;
   // measured on MI355X (profiles/r02b_kernel_bench.md; fp16x3, the DiT Base shapes N = 3072 / 2048 / 1024, K = 1024 / 2048):
   //   M >= 40k   (B = 32): 256x256, 8 waves of 128x64 — 352-377 TF against 322-350 for 128x128 x 2 per CU
-  //   4k .. 40k  (B = 2..16): 256x128, 8 waves of 64x64, 3 stages — 320-355 TF at M = 22k
+  //   4k .. 40k  (B = 2..16): round 2: 256x128, 8 waves of 64x64, 3 stages (320-355 TF at M = 22k); round 3: two workgroups per CU, below
   //   2k .. 4k   (B = 1, one chain of 2 x 1406 rows): one round of 240 workgroups — 192x192 for N = 3072 (62 us against 84 for the
   //              128x64 tiles of gemm.h), 192x128 / 8 waves for N = 2048 (41 against 53), 96x128 for N = 1024 (26 / 45 against 32 / 52)
   //   < 2k       (B = 1, one CFG chain of 1406 rows): 192x128 / 8 waves for N = 3072, 96x128 otherwise
   if (g.M < 512) return 0;  // a handful of row tiles: the generic small tiles
   if (g.M >= 40000) return 50;
-  // (NOT the 4-wave, 2-stage tiles that fit two workgroups per CU — 58 / 62 / 63 / 64, 3-8 % faster here: with two of them co-resident
-  // the fused q|k|v epilogue's rope values came out wrong in a few hundred outputs per launch, run-to-run different, clean as soon as a
-  // CU holds one workgroup; unexplained, so they stay microbenchmark-only.  DESIGN.md section 4, tools/r2_call7.sh)
-  if (g.M >= 4096) return qkv ? 55 : 51;
+  // A few rounds (B = 2 .. 16): the 4-wave, 2-stage tiles that fit TWO workgroups per CU - the two run out of phase, one's prologue and
+  // epilogue under the other's k-loop.  Kept out of the engine in round 2 because of wrong rope values that came and went with the build;
+  // round 3 traced those to a gfx950 packed-fp32 operand fault (Makefile NOPK), not to the tiles.  Measured against
+  // the 8-wave tiles they replace (profiles/r03b_kernel_bench_2percu.log; fp16x3, us): M = 5.6k q|k|v 120 -> 109, FF1 95 -> 73, out / FF2
+  // 48 / 84 -> 43 / 76 (96x128); M = 11k 269 -> 229, 165 -> 141, 97 / 173 -> 77 / 139; M = 22k 518 -> 431, 334 -> 276, 174 / 306 -> 151 / 282.
+  if (g.M >= 4096) return qkv ? 61 : g.N >= 2048 ? 62 : g.M >= 8192 ? 62 : 63;
   // the fused q|k|v projection (rope + scatter epilogue, tools/kernel_bench.py qkv): 192x192 in the one-round regime (63 us against 73
   // for 192x128 / 8 waves), 192x128 / 8 waves for one CFG chain (39 against 43-56) and for a few rounds (230 us at M = 11k against 244)
-  if (qkv && (g.M < 2048 || g.M >= 4096)) return 55;
+  if (qkv && g.M < 2048) return 55;
   // narrow outputs (out-proj, FF2; FF1 of one chain): the k-split 96x128 — two waves per SIMD on one output tile, -10 % against the 4-wave
   // 96x128 (M = 2812: 23.9 / 39.9 us against 26.4 / 44.5; M = 1406: 20.9 / 34.0 / 23.6 against 23.5 / 39.6 / 25.8; profiles/r02c_ksplit.log).
   // For 192x128 it measures the same as the 8 waves of 96x32 (41.0 / 41.3), so that one stays.
-  const int narrow = (g.K % 128 == 0 && g.K >= 512) ? 66 : 59;  // k-split: an even number of k-tiles, a whole pipeline per group
+  const int narrow = (ktiles_of(g, nsplit_planes) % 2 == 0 && ktiles_of(g, nsplit_planes) / 2 >= 3) ? 66 : 59;  // k-split: k-tiles split evenly, a whole pipeline (NS + 1 = 3) per group
   // one round of 240 workgroups (2048 <= M < 4096): the k-step-split 192x192 / 192x128 — 8 waves on the 4-wave tiles' ring, 57.0 against
   // 62.2 us (q|k|v, 192x192 / 4 waves) and 40.0 against 41.2 (FF1, 192x128 / 8 waves of 96x32); profiles/r02e_kss.log
-  const bool even_kt = g.K % 64 == 0 && g.K >= 256;  // k-step split: an even number of k-tiles (fp16: K / 64, fp16x3: K / 32)
+  // k-step split: an even number of k-tiles and a whole pipeline (fp16: K / 64 tiles, fp16x3: K / 32)
+  const int64_t ktiles = ktiles_of(g, nsplit_planes);
+  const bool even_kt = ktiles % 2 == 0 && ktiles >= 4;
   if (g.M >= 2048) return g.N >= 3072 ? (even_kt ? 68 : 56) : g.N >= 2048 ? (even_kt ? 69 : 55) : narrow;
   return g.N >= 3072 ? 55 : narrow;
 }
 
-// EpiStore configurations the block GEMMs use -> wave-tile epilogues of gemm_pp.h; returns hipErrorInvalidValue when the launch is not
+// EpiStore configurations the block GEMMs use -> wave-tile epilogues of gemm_pp.h; returns PP_NOT_APPLICABLE when the launch is not
 // one of them (the caller then runs the generic kernel)
 template <int NSPLIT>
 hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
-  if (!pp_applies<NSPLIT>(g, batch)) return hipErrorInvalidValue;
-  if (variant < 0) variant = pick_pp_variant(g);
-  if (variant < 50) return hipErrorInvalidValue;
+  if (!pp_applies<NSPLIT>(g, batch)) return PP_NOT_APPLICABLE;
+  if (variant < 0) variant = pick_pp_variant(g, NSPLIT == 3 ? 2 : 1);
+  if (variant < 50) return PP_NOT_APPLICABLE;
   constexpr bool PK = NSPLIT == 3;
   const bool plain_out = e.alpha == 1.f && e.bias && !e.out2 && !e.zdiv;
   if (plain_out && e.out16 && !e.out32 && !e.res && !e.colscale && !e.rowmask && (e.act == ACT_GELU_TANH || e.act == ACT_NONE) &&
       (PK ? (e.pk16 && e.out16_lo == e.out16 + 32 && e.ldo16 >= 2 * (int64_t)g.N) : (!e.out16_lo && !e.pk16))) {
     const int64_t ld = PK ? e.ldo16 : (e.ldo16 ? e.ldo16 : e.ldo);
-    if ((int64_t)(g.M + 512) * ld * 2 >= (int64_t)0x7ff00000) return hipErrorInvalidValue;
+    if ((int64_t)(g.M + 512) * ld * 2 >= (int64_t)0x7ff00000) return PP_NOT_APPLICABLE;
     if constexpr (PK) {  // microbenchmark ablations of three tiles: variant = 1000 * code + id; code 1 no epilogue, 2 epilogue without stores,
                          // 4 no LDS-DMA in the loop, 8 no MFMAs, 12 neither (fragment reads + barriers + epilogue)
       if (variant >= 1000 && e.act == ACT_GELU_TANH) {
@@ -302,7 +309,7 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
           F5_ABL(56)
           F5_ABL(59)
 #undef F5_ABL
-          default: return hipErrorInvalidValue;
+          default: return PP_NOT_APPLICABLE;
         }
       }
     }
@@ -310,11 +317,11 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
     return launch_pp<NSPLIT>(g, PpEpiAct16<PK, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
   }
   if (plain_out && e.act == ACT_NONE && e.out32 && e.res == e.out32 && e.ldres == e.ldo && !e.out16 && (!e.rowmask || (e.mask_mode == 1 && e.smask == 0))) {
-    if ((int64_t)(g.M + 512) * e.ldo * 4 >= (int64_t)0x7ff00000) return hipErrorInvalidValue;
+    if ((int64_t)(g.M + 512) * e.ldo * 4 >= (int64_t)0x7ff00000) return PP_NOT_APPLICABLE;
     if (e.colscale) return launch_pp<NSPLIT>(g, PpEpiGateRes<true>{e.bias, e.colscale, e.rowmask, e.out32, e.ldo, g.M, g.N}, variant, s);
     return launch_pp<NSPLIT>(g, PpEpiGateRes<false>{e.bias, nullptr, e.rowmask, e.out32, e.ldo, g.M, g.N}, variant, s);
   }
-  return hipErrorInvalidValue;
+  return PP_NOT_APPLICABLE;
 }
 
 template <typename Epi>
@@ -326,7 +333,8 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   if constexpr (std::is_same<Epi, EpiStore>::value) {
     if ((variant < 0 || variant >= 50) && (op == OP_F16 || op == OP_F16X3)) {
       const hipError_t r = op == OP_F16 ? try_pp_store<1>(g, e, batch, variant, s) : try_pp_store<3>(g, e, batch, variant, s);
-      if (r != hipErrorInvalidValue || variant >= 50) return r;
+      if (r != PP_NOT_APPLICABLE) return r;
+      if (variant >= 50) return hipErrorInvalidValue;  // an explicitly requested pipelined tile that does not take this launch
     }
   }
   switch (op) {
@@ -356,7 +364,7 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
       (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
     GemmCore g = g0;
     if (g.group_m == 0) g.group_m = g.M >= 8192 ? 4 : 1;
-    const int variant = want >= 50 ? want : pick_pp_variant(g, true);
+    const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true);
     const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = (g.M + e.nseq - 1) / e.nseq;
     const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
     if (variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000) {
@@ -367,7 +375,7 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
       p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
       p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb;
       const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
-      if (r != hipErrorInvalidValue) return r;
+      if (r != PP_NOT_APPLICABLE) return r;
     }
   }
   const int gv = want >= 0 && want < 50 ? want : -1;
@@ -380,10 +388,42 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
   return dispatch<EpiQKV>(op, g0, e, 1, gv, s);
 }
 
+namespace {
+template <int NSPLIT, int ID, typename Epi>
+hipError_t set_pp_attr() {
+  using C = PpV<ID>;
+  constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, C::NS, C::KSP>();
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, 0, C::KSP, C::KSS>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+template <int NSPLIT, typename Epi, int... IDS>
+hipError_t set_pp_attrs_ids(std::integer_sequence<int, IDS...>) {
+  hipError_t e = hipSuccess;
+  ((e = e == hipSuccess ? set_pp_attr<NSPLIT, 50 + IDS, Epi>() : e), ...);
+  return e;
+}
+template <int NSPLIT>
+hipError_t set_pp_attrs() {  // every tile id 50 .. 70 x every wave-tile epilogue launch_pp can be asked for
+  constexpr auto ids = std::make_integer_sequence<int, 21>{};
+  hipError_t e;
+  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3, ACT_GELU_TANH>>(ids)) != hipSuccess) return e;
+  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3, ACT_NONE>>(ids)) != hipSuccess) return e;
+  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<true>>(ids)) != hipSuccess) return e;
+  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<false>>(ids)) != hipSuccess) return e;
+  return set_pp_attrs_ids<NSPLIT, PpEpiQKV>(ids);
+}
+}  // namespace
+
+// Dynamic-LDS limits of every kernel of this file, for the CURRENT device: called at context creation (hipFuncSetAttribute is per device
+// and must not run inside a stream capture — the first pipelined launch of a sample call is already inside one).
 hipError_t init_gemm_kernels() {
   hipError_t e = set_attrs_epi<EpiStore>();
   if (e != hipSuccess) return e;
   e = set_attrs_epi<EpiQKV>();
   if (e != hipSuccess) return e;
-  return set_attrs_epi<EpiQKVFast>();
+  e = set_attrs_epi<EpiQKVFast>();
+  if (e != hipSuccess) return e;
+  e = set_pp_attrs<1>();
+  if (e != hipSuccess) return e;
+  return set_pp_attrs<3>();
 }

@@ -237,6 +237,9 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
 int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int lds_pad, int noise, int seqs, int nseq, int reps, int64_t* bad,
                           const char* dump_path) {
   if (!ctx || !bad || seqs <= 0 || nseq <= 1 || reps <= 0) return F5HIP_ERR_INVALID;
+#ifdef F5_HIPEMU
+  return F5HIP_ERR_UNSUPPORTED;  // the reproducer is gfx950 instructions (csrc/race_probe.hip is not part of the host build)
+#else
   std::lock_guard<std::mutex> lk(ctx->mu);
   if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
   if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
@@ -324,6 +327,7 @@ int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int ld
   if (dump) fclose(dump);
   if (s2) (void)hipStreamDestroy(s2);
   return F5HIP_OK;
+#endif
 }
 
 // flash attention over [batch2 * heads, n, 64]; precision FP16 -> plain fp16 operands, FP16X3 -> hi/lo split

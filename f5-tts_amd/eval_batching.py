@@ -27,46 +27,75 @@ from . import dist as fdist
 from . import infer as I
 
 Prompt = Tuple[List[str], List[torch.Tensor], torch.Tensor, List[int], List[int], List]
+MetaRow = Tuple[str, str, str, str, str]  # (utt, prompt_text, prompt_wav, gt_text, gt_wav)
 
 
-def get_seedtts_testset_metainfo(metalst: str) -> List[Tuple[str, str, str, str, str]]:
-    """``utt|prompt_text|prompt_wav|gt_text[|gt_wav]`` lines (utils_eval.py:19-34)."""
-    metainfo = []
-    with open(metalst) as f:
-        for line in f.readlines():
-            parts = line.strip().split("|")
-            if len(parts) == 5:
-                utt, prompt_text, prompt_wav, gt_text, gt_wav = parts
-            elif len(parts) == 4:
-                utt, prompt_text, prompt_wav, gt_text = parts
-                gt_wav = os.path.join(os.path.dirname(metalst), "wavs", utt + ".wav")
-            else:
-                continue
-            if not os.path.isabs(prompt_wav):
-                prompt_wav = os.path.join(os.path.dirname(metalst), prompt_wav)
-            metainfo.append((utt, prompt_text, prompt_wav, gt_text, gt_wav))
-    return metainfo
+# ---- test lists --------------------------------------------------------------------------------------------------------------------
+def _rows(path: str, sep: str):
+    with open(path) as f:
+        for line in f:
+            yield line.strip().split(sep)
 
 
-def get_librispeech_test_clean_metainfo(metalst: str, librispeech_test_clean_path: str) -> List[Tuple[str, str, str, str, str]]:
-    """tab-separated ``ref_utt ref_dur ref_txt gen_utt gen_dur gen_txt`` lines (utils_eval.py:38-52)."""
-    metainfo = []
-    with open(metalst) as f:
-        for line in f.readlines():
-            ref_utt, _ref_dur, ref_txt, gen_utt, _gen_dur, gen_txt = line.strip().split("\t")
-            ref_spk_id, ref_chaptr_id, _ = ref_utt.split("-")
-            ref_wav = os.path.join(librispeech_test_clean_path, ref_spk_id, ref_chaptr_id, ref_utt + ".flac")
-            gen_spk_id, gen_chaptr_id, _ = gen_utt.split("-")
-            gen_wav = os.path.join(librispeech_test_clean_path, gen_spk_id, gen_chaptr_id, gen_utt + ".flac")
-            metainfo.append((gen_utt, ref_txt, ref_wav, " " + gen_txt, gen_wav))
-    return metainfo
+def get_seedtts_testset_metainfo(metalst: str) -> List[MetaRow]:
+    """Seed-TTS list (utils_eval.py:19-34): ``utt|prompt_text|prompt_wav|gt_text`` with an optional fifth ``gt_wav`` field; without it the
+    target recording is ``<list dir>/wavs/<utt>.wav``; a relative prompt path is taken from the list's directory; other lines are skipped."""
+    here = os.path.dirname(metalst)
+    out: List[MetaRow] = []
+    for f in _rows(metalst, "|"):
+        if len(f) not in (4, 5):
+            continue
+        utt, prompt_text, prompt_wav, gt_text = f[:4]
+        gt_wav = f[4] if len(f) == 5 else os.path.join(here, "wavs", utt + ".wav")
+        out.append((utt, prompt_text, prompt_wav if os.path.isabs(prompt_wav) else os.path.join(here, prompt_wav), gt_text, gt_wav))
+    return out
+
+
+def get_librispeech_test_clean_metainfo(metalst: str, librispeech_test_clean_path: str) -> List[MetaRow]:
+    """LibriSpeech-PC test-clean cross-sentence list (utils_eval.py:38-52): six tab-separated fields ``ref_utt ref_dur ref_txt gen_utt
+    gen_dur gen_txt``; an utterance ``spk-chapter-n`` lives at ``<root>/spk/chapter/spk-chapter-n.flac``; the text to generate gets a
+    leading space."""
+    def flac(utt: str) -> str:
+        spk, chapter, _ = utt.split("-")
+        return os.path.join(librispeech_test_clean_path, spk, chapter, utt + ".flac")
+
+    return [(gen_utt, ref_txt, flac(ref_utt), " " + gen_txt, flac(gen_utt)) for ref_utt, _, ref_txt, gen_utt, _, gen_txt in _rows(metalst, "\t")]
 
 
 def padded_mel_batch(ref_mels: Sequence[torch.Tensor]) -> torch.Tensor:
     """[n_mel, T_i] prompts -> zero-padded frame-major batch [B, max T, n_mel] (utils_eval.py:56-66)."""
-    max_mel_length = max(int(mel.shape[-1]) for mel in ref_mels)
-    padded = [F.pad(mel, (0, max_mel_length - mel.shape[-1]), value=0) for mel in ref_mels]
-    return torch.stack(padded).permute(0, 2, 1)
+    longest = max(int(m.shape[-1]) for m in ref_mels)
+    return torch.stack([F.pad(m, (0, longest - m.shape[-1]), value=0) for m in ref_mels]).permute(0, 2, 1)
+
+
+# ---- length classes ----------------------------------------------------------------------------------------------------------------
+class _LengthClass:
+    """The utterances waiting in one length class, column by column as the reference's batch tuple wants them."""
+
+    __slots__ = ("utts", "rms", "mels", "ref_lens", "total_lens", "texts", "frames")
+
+    def __init__(self):
+        self.utts, self.rms, self.mels, self.ref_lens, self.total_lens, self.texts, self.frames = [], [], [], [], [], [], 0
+
+    def add(self, utt, rms, mel, ref_len, total_len, text_list) -> None:
+        self.utts.append(utt); self.rms.append(rms); self.mels.append(mel); self.ref_lens.append(ref_len)
+        self.total_lens.append(total_len); self.texts.extend(text_list); self.frames += total_len
+
+    def take(self) -> Prompt:
+        batch = (self.utts, self.rms, padded_mel_batch(self.mels), self.ref_lens, self.total_lens, self.texts)
+        self.__init__()
+        return batch
+
+
+def _prompt_audio(path: str, load_audio, resample, target_rms: float, target_sample_rate: int):
+    """Prompt recording as the sampler wants it: quiet prompts raised to the target RMS (the measured RMS is kept for the way back),
+    resampled to the model rate (utils_eval.py:110-118)."""
+    audio, sr = load_audio(path)
+    rms = torch.sqrt(torch.mean(torch.square(audio)))
+    if rms < target_rms:
+        audio = audio * target_rms / rms
+    assert audio.shape[-1] > 5000, f"Empty prompt wav: {path}, or audio loader issue."
+    return (resample(audio, sr, target_sample_rate) if sr != target_sample_rate else audio), rms
 
 
 def get_inference_prompt(metainfo, mel_fn: Callable[[torch.Tensor], torch.Tensor], speed: float = 1.0, tokenizer: str = "pinyin",
@@ -74,64 +103,40 @@ def get_inference_prompt(metainfo, mel_fn: Callable[[torch.Tensor], torch.Tensor
                          use_truth_duration: bool = False, infer_batch_size: int = 1, num_buckets: int = 200, min_secs: int = 3,
                          max_secs: int = 40, load_audio: Callable = I.load_wav, resample: Callable = I.resample,
                          shuffle_seed: Optional[int] = 666) -> List[Prompt]:
-    """utils_eval.py:72-205.  ``metainfo``: (utt, prompt_text, prompt_wav, gt_text, gt_wav) tuples; ``mel_fn(wave[1, n]) -> [1, n_mel, T]``
-    is the model's mel front-end (``F5HipCFM.mel_spec``; the reference builds a ``MelSpec`` here, :99-106); ``load_audio`` /
-    ``resample`` stand for ``torchaudio.load`` / ``transforms.Resample`` (:110,116-118).  Returns the reference's list of
-    ``(utts, ref_rms_list, padded_ref_mels[B, T, n_mel], ref_mel_lens, total_mel_lens, final_text_list)`` batches."""
-    prompts_all: List[Prompt] = []
-    min_tokens = min_secs * target_sample_rate // hop_length
-    max_tokens = max_secs * target_sample_rate // hop_length
-    batch_accum = [0] * num_buckets
-    utts, ref_rms_list, ref_mels, ref_mel_lens, total_mel_lens, final_text_list = ([[] for _ in range(num_buckets)] for _ in range(6))
-
-    def flush(b: int) -> None:
-        prompts_all.append((utts[b], ref_rms_list[b], padded_mel_batch(ref_mels[b]), ref_mel_lens[b], total_mel_lens[b], final_text_list[b]))
-        batch_accum[b] = 0
-        utts[b], ref_rms_list[b], ref_mels[b], ref_mel_lens[b], total_mel_lens[b], final_text_list[b] = [], [], [], [], [], []
-
+    """The batch list of utils_eval.py:72-205 for ``metainfo`` rows.  ``mel_fn(wave[1, n]) -> [1, n_mel, T]`` is the model's mel front-end
+    (``F5HipCFM.mel_spec``; the reference builds a ``MelSpec``, :99-106); ``load_audio`` / ``resample`` stand for ``torchaudio.load`` /
+    ``transforms.Resample``.  Every utterance goes to class ``floor((total - lo) / (hi - lo + 1) * num_buckets)`` of its TOTAL frame count
+    (``lo``, ``hi`` = ``min_secs``, ``max_secs`` in frames); a class is emitted as one batch ``(utts, rms, padded mels [B, T, n_mel], prompt
+    frames, total frames, token lists)`` the moment its frames reach ``infer_batch_size``, what is left is emitted class by class at the
+    end, and the list is shuffled with the reference's fixed seed."""
+    assert infer_batch_size > 0, "infer_batch_size should be greater than 0."
+    lo, hi = (secs * target_sample_rate // hop_length for secs in (min_secs, max_secs))
+    classes = [_LengthClass() for _ in range(num_buckets)]
+    batches: List[Prompt] = []
     for utt, prompt_text, prompt_wav, gt_text, gt_wav in metainfo:
-        ref_audio, ref_sr = load_audio(prompt_wav)
-        ref_rms = torch.sqrt(torch.mean(torch.square(ref_audio)))
-        if ref_rms < target_rms:
-            ref_audio = ref_audio * target_rms / ref_rms
-        assert ref_audio.shape[-1] > 5000, f"Empty prompt wav: {prompt_wav}, or audio loader issue."
-        if ref_sr != target_sample_rate:
-            ref_audio = resample(ref_audio, ref_sr, target_sample_rate)
-        if len(prompt_text[-1].encode("utf-8")) == 1:  # a single-byte last character gets a separating space (:121-122)
-            prompt_text = prompt_text + " "
-        text = [prompt_text + gt_text]
-        text_list = I.convert_char_to_pinyin(text, polyphone=polyphone) if tokenizer == "pinyin" else text
-        ref_mel = mel_fn(ref_audio).squeeze(0)  # [n_mel, T]
-        ref_mel_len = int(ref_mel.shape[-1])
-        if use_truth_duration:
+        audio, rms = _prompt_audio(prompt_wav, load_audio, resample, target_rms, target_sample_rate)
+        if len(prompt_text[-1].encode("utf-8")) == 1:  # a single-byte last character is followed by a separating space (:121-122)
+            prompt_text += " "
+        joined = [prompt_text + gt_text]
+        mel = mel_fn(audio).squeeze(0)  # [n_mel, T]
+        ref_len = int(mel.shape[-1])
+        if use_truth_duration:  # the target recording's own length, scaled by the speed (:132-137)
             gt_audio, gt_sr = load_audio(gt_wav)
             if gt_sr != target_sample_rate:
                 gt_audio = resample(gt_audio, gt_sr, target_sample_rate)
-            total_mel_len = ref_mel_len + int(gt_audio.shape[-1] / hop_length / speed)
-        else:
-            ref_text_len = len(prompt_text.encode("utf-8"))
-            gen_text_len = len(gt_text.encode("utf-8"))
-            total_mel_len = ref_mel_len + int(ref_mel_len / ref_text_len * gen_text_len / speed)
-        assert infer_batch_size > 0, "infer_batch_size should be greater than 0."
-        assert min_tokens <= total_mel_len <= max_tokens, (
-            f"Audio {utt} has duration {total_mel_len * hop_length // target_sample_rate}s out of range [{min_secs}, {max_secs}].")
-        b = math.floor((total_mel_len - min_tokens) / (max_tokens - min_tokens + 1) * num_buckets)
-        utts[b].append(utt)
-        ref_rms_list[b].append(ref_rms)
-        ref_mels[b].append(ref_mel)
-        ref_mel_lens[b].append(ref_mel_len)
-        total_mel_lens[b].append(total_mel_len)
-        final_text_list[b].extend(text_list)
-        batch_accum[b] += total_mel_len
-        if batch_accum[b] >= infer_batch_size:
-            flush(b)
-    for b, frames in enumerate(batch_accum):  # residual batches (:186-199)
-        if frames > 0:
-            flush(b)
-    if shuffle_seed is not None:  # "not only leave easy work for last workers" (:201-203); the reference reseeds the global generator
+            total = ref_len + int(gt_audio.shape[-1] / hop_length / speed)
+        else:               # prompt frames per prompt byte, times the bytes to generate (:139-142)
+            total = ref_len + int(ref_len / len(prompt_text.encode("utf-8")) * len(gt_text.encode("utf-8")) / speed)
+        assert lo <= total <= hi, f"Audio {utt} has duration {total * hop_length // target_sample_rate}s out of range [{min_secs}, {max_secs}]."
+        cls = classes[math.floor((total - lo) / (hi - lo + 1) * num_buckets)]
+        cls.add(utt, rms, mel, ref_len, total, I.convert_char_to_pinyin(joined, polyphone=polyphone) if tokenizer == "pinyin" else joined)
+        if cls.frames >= infer_batch_size:
+            batches.append(cls.take())
+    batches.extend(cls.take() for cls in classes if cls.frames > 0)
+    if shuffle_seed is not None:  # long and short batches mixed over the ranks (:201-203); the reference reseeds the global generator
         random.seed(shuffle_seed)
-        random.shuffle(prompts_all)
-    return prompts_all
+        random.shuffle(batches)
+    return batches
 
 
 def batch_cost(prompt: Prompt) -> int:

@@ -217,6 +217,51 @@ def synth_bigvgan_state_dict(cfg: BigVGANConfig, seed: int = 0, raw_weight_norm:
     return sd
 
 
+def stress_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Dynamic-range stress (DiT backbones): what a trained checkpoint has and N(0, 1/sqrt(in)) weights do not — per-tensor scales spread over
+    decades and a few outlier channels.  Every block gets three log-uniform factors s in [1e-3, 1]: to_v is scaled by s_v and to_out by 1/s_v
+    (attention output at 1e-3 of its usual size, re-amplified by weights of up to 1000 times theirs), to_q by s_q and to_k by 1/s_q (same
+    scores, operands decades apart), FF linear 1 by s_f and FF linear 2 by 1/s_f; 2 % of the AdaLN modulation outputs (scale / shift / gate
+    channels) are amplified 4-12 times (heavy-tailed gains -> outlier activation channels).  Same keys, same shapes: loads into the reference
+    unchanged.  Drawn from its own generator, so the unstressed tensors of (cfg, seed) are not disturbed."""
+    assert cfg.backbone == "DiT"
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5000011 * seed + 101)
+    out = {k: v.clone() for k, v in sd.items()}
+    p = "transformer."
+
+    def logu():
+        return float(10.0 ** (-3.0 * torch.rand((), generator=g)))
+
+    for i in range(cfg.depth):
+        b = p + f"transformer_blocks.{i}."
+        sv, sq, sf = logu(), logu(), logu()
+        for key, f in (("attn.to_v", sv), ("attn.to_q", sq), ("ff.ff.0.0", sf)):
+            out[b + key + ".weight"] *= f
+            out[b + key + ".bias"] *= f
+        out[b + "attn.to_out.0.weight"] *= 1.0 / sv
+        out[b + "attn.to_k.weight"] *= 1.0 / sq
+        out[b + "attn.to_k.bias"] *= 1.0 / sq
+        out[b + "ff.ff.2.weight"] *= 1.0 / sf
+        w = out[b + "attn_norm.linear.weight"]
+        pick = torch.rand(w.shape[0], generator=g) < 0.02
+        gain = 4.0 + 8.0 * torch.rand(w.shape[0], generator=g)
+        w[pick] *= gain[pick, None]
+        out[b + "attn_norm.linear.bias"][pick] *= gain[pick]
+    return out
+
+
+def synth_loud_wave(n_samples: int, seed: int = 0, batch: int = 1) -> torch.Tensor:
+    """A prompt that hits the rails: ``0.6 * N(0,1)`` clipped to +-1 (about 10 % of the samples clip; rms ~= 0.55, so the RMS rule of
+    ``utils_infer.py:463-465`` does not rescale it)."""
+    g = torch.Generator(device="cpu")
+    out = []
+    for b in range(batch):
+        g.manual_seed(424243 * (seed + b) + 7)
+        out.append((0.6 * torch.randn(n_samples, generator=g)).clamp(-1.0, 1.0))
+    return torch.stack(out, 0)
+
+
 def synth_wave(n_samples: int, seed: int = 0, batch: int = 1) -> torch.Tensor:
     """``0.1 * N(0,1)`` clipped to +-1: rms ~= 0.1, so the RMS-normalise branch
     (reference ``src/f5_tts/infer/utils_infer.py:463-465``) is a no-op."""

@@ -27,7 +27,7 @@ def gold(name):
 def test_oracle_matches_reference_golden(name):
     c = MG.CASES[name]
     cfg, wav, text, duration, lens = MG.case_inputs(c)
-    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
+    sd = MG.case_weights(c)
     out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, method=c.get("method", "euler"), **c["kw"])
     g = gold(name)
     steps = traj.shape[0] - 1  # duplicate_test shortens the solve (cfm.py:209)

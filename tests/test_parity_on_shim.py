@@ -44,11 +44,13 @@ def shim_engines(engine_emu_lib):  # noqa: F811
     mp.setattr(E.F5HipEngine, "__init__", init_on_cpu)
     cache = {}
 
-    def get(preset, wseed, vocos=False):
-        key = (preset, wseed, vocos)
+    def get(preset, wseed, vocos=False, stress=False):
+        key = (preset, wseed, vocos, stress)
         if key not in cache:
             cfg = config.PRESETS[preset]
             sd = synth.synth_dit_state_dict(cfg, seed=wseed)
+            if stress:
+                sd = synth.stress_dit_state_dict(sd, cfg, seed=wseed)
             vcfg = config.VOCOS_TINY if vocos else None
             eng = E.F5HipEngine(cfg, vcfg, device=0)  # a descriptor only (init_on_cpu)
             if vocos:

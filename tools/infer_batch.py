@@ -48,7 +48,20 @@ def main():
     ap.add_argument("--frames-per-batch", type=int, default=0,
                     help="> 0: form length-bucketed batches with this frame budget (the reference's infer_batch_size, eval/utils_eval.py:72-205; "
                          "f5-tts_amd/eval_batching.py) instead of running the utterances one by one")
+    ap.add_argument("--tokenizer", choices=["pinyin", "char"], default=None,
+                    help="text front-end of BOTH modes: 'pinyin' = convert_char_to_pinyin (what the F5-TTS presets were trained with and what "
+                         "infer_process applies; ASCII text only here, the Chinese G2P packages are absent), 'char' = the characters as they are. "
+                         "Default: pinyin when --vocab is given (the reference's eval_infer_batch.py takes the tokenizer from the model config), "
+                         "char for the built-in ASCII smoke vocabulary")
+    ap.add_argument("--min-secs", type=int, default=3, help="shortest total length the length classes cover (eval/utils_eval.py:72 default)")
+    ap.add_argument("--max-secs", type=int, default=40, help="longest total length the length classes cover (eval/utils_eval.py:72 default)")
     a = ap.parse_args()
+    if a.tokenizer is None:
+        a.tokenizer = "pinyin" if a.vocab else "char"
+    if a.testset == "ls_pc_test_clean":
+        # the list points at LibriSpeech .flac files; this tool reads PCM .wav through the standard library only (no torchaudio / soundfile here)
+        ap.error("--testset ls_pc_test_clean needs a FLAC decoder, which this image does not have: convert test-clean to 16-bit .wav and pass the "
+                 "utterances with --list in the utt|wav|ref_text|gen_text layout (or --testset seedtts, whose prompts are .wav)")
     rank, local, world = fdist.init_distributed()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -98,8 +111,9 @@ def main():
             return (w if w.ndim == 2 else w[None]).float().cpu(), sr
 
         meta = [(uid, ref_text, ref, gen_text, "") for uid, ref, ref_text, gen_text in utts]
-        batches = EB.get_inference_prompt(meta, lambda w: model.mel_spec(w.to(dev)).cpu(), tokenizer="char", infer_batch_size=a.frames_per_batch,
-                                          min_secs=1, max_secs=60, load_audio=load_audio)
+        # same tokens as the one-by-one mode below (infer_process -> convert_char_to_pinyin) and the reference's bucket range unless asked otherwise
+        batches = EB.get_inference_prompt(meta, lambda w: model.mel_spec(w.to(dev)).cpu(), tokenizer=a.tokenizer, infer_batch_size=a.frames_per_batch,
+                                          min_secs=a.min_secs, max_secs=a.max_secs, load_audio=load_audio)
         mine = EB.deal_batches(batches, world)[rank]
         if rank == 0:
             print(f"{len(batches)} batches of <= {max(len(b[0]) for b in batches)} utterances, padding {100 * EB.padding_fraction(batches):.1f} % of the rows")
