@@ -347,6 +347,17 @@ GemmCore core(const void* A, int64_t lda, const void* Wt, int64_t ldw, int M, in
   g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
   return g;
 }
+// a weight operand as a block GEMM takes it: the rows in the operand mode's format and, for the conditioned half-precision copies, the
+// per-output-channel factors that undo the conditioning (GemmCore::w_alpha)
+struct WOp {
+  const void* w;
+  const float* alpha;
+};
+GemmCore core(const void* A, int64_t lda, const WOp& Wt, int64_t ldw, int M, int N, int K) {
+  GemmCore g = core(A, lda, Wt.w, ldw, M, N, K);
+  g.w_alpha = Wt.alpha;
+  return g;
+}
 EpiStore epi_store(float* out32, int64_t ldo, const float* bias, int act = ACT_NONE) {
   EpiStore e{};
   e.alpha = 1.f; e.act = act; e.bias = bias; e.out32 = out32; e.ldo = ldo; e.ldres = ldo;
@@ -365,8 +376,11 @@ struct Stage {
 };
 
 // weight operand of a block GEMM in the given operand mode: fp32 blob rows, plain fp16 rows, or packed hi/lo rows
-const void* wsel(int op, const float* w32, const f16* hi, const f16* pk) {
-  return op == OP_F32 ? (const void*)w32 : op == OP_F16 ? (const void*)hi : (const void*)pk;
+WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f16* pk) {
+  if (op == OP_F32) return WOp{w32, nullptr};
+  const void* w = op == OP_F16 ? (const void*)hi : (const void*)pk;
+  const auto it = ctx->walpha.find(w);
+  return WOp{w, it == ctx->walpha.end() ? nullptr : it->second};
 }
 
 // fp16x3 mode: are the attention SCORES computed from hi/lo-split q and k (3 MFMAs per product)?  Only on request (attn_impl 2: every
@@ -396,6 +410,13 @@ int finalize_impl(f5hip_ctx* ctx) {
   const int64_t cstream_elems = mmdit ? per_block * (c.depth - 1) + 3 * inner * D : 0;  // text stream; the last block only projects q/k/v
   HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
   f16* hp = ctx->half_pool.as<f16>();
+  // weight conditioning (GemmCore::w_alpha): rows of every half-precision weight copy, scale | alpha each
+  const int64_t rows_block = 3 * inner + D + F + D;
+  const int64_t cond_rows = rows_block * c.depth + (skip_elems ? (skip_concat ? (int64_t)(c.depth / 2) * D : D) : 0) + (mmdit ? rows_block * c.depth : 0);
+  HIPCHK(ctx->cond_pool.ensure((size_t)cond_rows * 2 * sizeof(float)));
+  float* cp = ctx->cond_pool.as<float>();
+  ctx->walpha.clear();
+  static const bool no_cond = getenv("F5HIP_NO_WEIGHT_CONDITIONING") != nullptr;  // A/B switch (tests, tools/): round 2's plain split
   ctx->blocks.assign(c.depth, BlockW{});
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = p + (unett ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
@@ -421,9 +442,16 @@ int finalize_impl(f5hip_ctx* ctx) {
     auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk) -> hipError_t {
       hi = hp; hp += rows * K;
       pk = hp; hp += 2 * rows * K;
-      hipError_t e = launch_split_f16(src, rows * K, 1.0f, hi, nullptr, st);
-      if (e != hipSuccess) return e;
-      return launch_split_f16_packed(src, rows, (int)K, pk, st);
+      if (no_cond) {
+        hipError_t e = launch_split_f16(src, rows * K, 1.0f, hi, nullptr, st);
+        if (e != hipSuccess) return e;
+        return launch_split_f16_packed(src, rows, (int)K, pk, st);
+      }
+      float* scale = cp; cp += rows;
+      float* alpha = cp; cp += rows;
+      ctx->walpha[hi] = alpha;
+      ctx->walpha[pk] = alpha;
+      return launch_condition_weight(src, (int)rows, (int)K, scale, alpha, hi, pk, st);
     };
     HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk));
     HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk));
@@ -915,7 +943,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = (core(A, ldA, wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
+    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -1005,7 +1033,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
+      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -1016,14 +1044,14 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = (core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
+      GemmCore g = (core(A, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
+      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -1035,7 +1063,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       HIPCHK(emit_cat(0));
     }
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, D, 2 * D), 0);
-    GemmCore g = core(catbuf, ldC, wsel(op, ctx->wlong, ctx->wlong_hi, ctx->wlong_pk), ldC, M, D, 2 * D);
+    GemmCore g = core(catbuf, ldC, wsel(ctx, op, ctx->wlong, ctx->wlong_hi, ctx->wlong_pk), ldC, M, D, 2 * D);
     HIPCHK(launch_gemm_store(op, g, epi_store(x, D, nullptr), 1, st));
   }
   {  // AdaLayerNorm_Final: chunk order is (scale, shift) (modules.py:344) + proj_out (dit.py:367-368)
@@ -1045,7 +1073,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, fm, fm + D, a32, a_hi, a_lo, D, st, pk, ldA));
     }
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(M, mel, D), 0);
-    GemmCore g = core(A, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
+    GemmCore g = core(A, ldA, wsel(ctx, op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, M, mel, D);
     HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>() + r0 * mel, mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
   if (br < 0) {  // CFG combine + Euler update (cfm.py:190-191, torchdiffeq euler on the given grid)
@@ -1138,7 +1166,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
         HIPCHK(emit_cat(level, 0));
       }
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, 2 * D), 0);
-      GemmCore g = core(cat_ptr(level), ldC, wsel(op, bw.wskip, bw.wskip_hi, bw.wskip_pk), ldC, M, D, 2 * D);
+      GemmCore g = core(cat_ptr(level), ldC, wsel(ctx, op, bw.wskip, bw.wskip_hi, bw.wskip_pk), ldC, M, D, 2 * D);
       HIPCHK(launch_gemm_store(op, g, epi_store(x, D, nullptr), 1, st));
     }
     {  // attn_norm: x_transformers RMSNorm
@@ -1149,7 +1177,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -1160,14 +1188,14 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
-      GemmCore g = core(A, ldA, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
+      GemmCore g = core(A, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
     }
     {  // x = ff(...) + x (unett.py:301)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(op, g, e, 1, st));
@@ -1180,7 +1208,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     }
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops((int64_t)S * n, mel, D), 0);
     const char* Arow1 = reinterpret_cast<const char*>(A) + ldA * (op == OP_F32 ? 4 : 2);  // skip the time token of sequence 0
-    GemmCore g = core(Arow1, ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, n, mel, D);
+    GemmCore g = core(Arow1, ldA, wsel(ctx, op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, n, mel, D);
     g.strideA = (int64_t)ns * ldA;
     EpiStore e = epi_store(ctx->vel.as<float>() + r0n * mel, mel, W(ctx, p + "proj_out.bias"));
     e.zdiv = 1; e.so1 = (int64_t)n * mel; e.so2 = 0;
@@ -1305,14 +1333,14 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
       }
     }
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = core(a_rows(text ? Mx : 0), ldA, text ? wsel(op, bw.wqkv_c, bw.wqkv_c_hi, bw.wqkv_c_pk) : wsel(op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk),
+    GemmCore g = core(a_rows(text ? Mx : 0), ldA, text ? wsel(ctx, op, bw.wqkv_c, bw.wqkv_c_hi, bw.wqkv_c_pk) : wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk),
                       ldA, M, 3 * inner, D);
     HIPCHK(launch_gemm_qkv(op, g, e, st));
     return F5HIP_OK;
   };
   // to_out / to_out_c over the stream's rows of the joint attention output, one GEMM batch per sequence:
   //   state += gate * masked(o . W^T + b)
-  auto out_proj = [&](bool text, const void* Wsel, const float* bias, const float* gate, float* state) -> int {
+  auto out_proj = [&](bool text, const WOp& Wsel, const float* bias, const float* gate, float* state) -> int {
     const int M = text ? nt : n;
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops((int64_t)S * M, D, inner), 0);
     GemmCore g = core(o_base + (int64_t)(text ? n : 0) * ldO * esz, ldO, Wsel, ldO, M, D, inner);
@@ -1325,7 +1353,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     return F5HIP_OK;
   };
   // FeedForward of one stream: state += gate * (gelu_tanh(a . W1^T + b1) . W2^T + b2)
-  auto feed_forward = [&](int M, int64_t row0, const void* W1, const float* b1, const void* W2, const float* b2, const float* gate, float* state) -> int {
+  auto feed_forward = [&](int M, int64_t row0, const WOp& W1, const float* b1, const WOp& W2, const float* b2, const float* gate, float* state) -> int {
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
       GemmCore g = core(a_rows(row0), ldA, W1, ldA, M, F, D);
@@ -1361,20 +1389,20 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, op == OP_F32 ? reinterpret_cast<float*>(o_base) : nullptr,
                       op != OP_F32 ? reinterpret_cast<f16*>(o_base) : nullptr, pk ? reinterpret_cast<f16*>(o_base) + 32 : nullptr, pk, ldO, st, kvlen2, n));
     if (!last) {  // text stream (modules.py:829-837)
-      CHK(out_proj(true, wsel(op, bw.wo_c, bw.wo_c_hi, bw.wo_c_pk), bw.bo_c, mc + 2 * D, cs));
+      CHK(out_proj(true, wsel(ctx, op, bw.wo_c, bw.wo_c_hi, bw.wo_c_pk), bw.bo_c, mc + 2 * D, cs));
       HIPCHK(ln_mod(cs, Mc, Mx, mc + 4 * D, mc + 3 * D));
-      CHK(feed_forward(Mc, Mx, wsel(op, bw.w1_c, bw.w1_c_hi, bw.w1_c_pk), bw.b1_c, wsel(op, bw.w2_c, bw.w2_c_hi, bw.w2_c_pk), bw.b2_c, mc + 5 * D, cs));
+      CHK(feed_forward(Mc, Mx, wsel(ctx, op, bw.w1_c, bw.w1_c_hi, bw.w1_c_pk), bw.b1_c, wsel(ctx, op, bw.w2_c, bw.w2_c_hi, bw.w2_c_pk), bw.b2_c, mc + 5 * D, cs));
     }
     // audio stream (modules.py:839-843)
-    CHK(out_proj(false, wsel(op, bw.wo, bw.wo_hi, bw.wo_pk), bw.bo, mx + 2 * D, x));
+    CHK(out_proj(false, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), bw.bo, mx + 2 * D, x));
     HIPCHK(ln_mod(x, Mx, 0, mx + 4 * D, mx + 3 * D));
-    CHK(feed_forward(Mx, 0, wsel(op, bw.w1, bw.w1_hi, bw.w1_pk), bw.b1, wsel(op, bw.w2, bw.w2_hi, bw.w2_pk), bw.b2, mx + 5 * D, x));
+    CHK(feed_forward(Mx, 0, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), bw.b1, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), bw.b2, mx + 5 * D, x));
   }
   {  // norm_out + proj_out (mmdit.py:259-260)
     const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
     HIPCHK(ln_mod(x, Mx, 0, fm, fm + D));
     Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(Mx, mel, D), 0);
-    GemmCore g = core(a_rows(0), ldA, wsel(op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, Mx, mel, D);
+    GemmCore g = core(a_rows(0), ldA, wsel(ctx, op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, Mx, mel, D);
     HIPCHK(launch_gemm_store(op, g, epi_store(ctx->vel.as<float>(), mel, W(ctx, p + "proj_out.bias")), 1, st));
   }
   {
@@ -1495,7 +1523,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   if (ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
-  DevBuf* bufs[] = {&ctx->half_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
+  DevBuf* bufs[] = {&ctx->half_pool, &ctx->cond_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
                     &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
                     &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->traj_buf, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,

@@ -320,6 +320,39 @@ __global__ void split_f16_packed_kernel(const float* src, int64_t rows, int K, f
     d[32] = l;
   }
 }
+// Weight conditioning (GemmCore::w_alpha): one wave per row of W [rows, K]: scale[r] = 2^e with the row's largest |entry| * 2^e in
+// [2^12, 2^13), alpha[r] = 2^-e; an all-zero row keeps 1.  Then the plain fp16 copy and the packed hi | lo copy of W * scale.
+__global__ __launch_bounds__(256) void row_pow2_scale_kernel(const float* src, int rows, int K, float* scale, float* alpha) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[(int64_t)r * K + k]));
+  m = wave_max(m);
+  if (lane == 0) {
+    int e = 0;
+    if (m > 0.f && m < INFINITY) {
+      int ex;
+      (void)frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+      e = 13 - ex;           // m * 2^e in [2^12, 2^13)
+      e = e > 100 ? 100 : e < -100 ? -100 : e;
+    }
+    scale[r] = ldexpf(1.0f, e);
+    alpha[r] = ldexpf(1.0f, -e);
+  }
+}
+__global__ void split_f16_rows_kernel(const float* src, int64_t rows, int K, const float* rowscale, f16* hi, f16* pk) {
+  const int64_t n = rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / K;
+    const int k = (int)(i - r * K);
+    f16 h, l;
+    split_f16(src[i] * rowscale[r], h, l);
+    hi[i] = h;
+    f16* d = pk + r * 2 * K + pk_off(k, 1);
+    d[0] = h;
+    d[32] = l;
+  }
+}
 __global__ void split_f16_kernel(const float* src, int64_t n, float prescale, f16* hi, f16* lo) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     f16 h, l;
@@ -514,6 +547,12 @@ hipError_t launch_set_token_rows(float* x, const float* t, int S, int nseq, int 
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s) {
   if (K % 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(split_f16_packed_kernel, dim3(grid_1d(rows * K)), dim3(256), 0, s, src, rows, K, dst);
+  return hipGetLastError();
+}
+hipError_t launch_condition_weight(const float* src, int rows, int K, float* scale, float* alpha, f16* hi, f16* pk, hipStream_t s) {
+  if (K % 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(row_pow2_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, scale, alpha);
+  hipLaunchKernelGGL(split_f16_rows_kernel, dim3(grid_1d((int64_t)rows * K)), dim3(256), 0, s, src, (int64_t)rows, K, scale, hi, pk);
   return hipGetLastError();
 }
 hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s) {

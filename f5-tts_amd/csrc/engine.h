@@ -189,6 +189,8 @@ struct f5hip_ctx {
 
   // derived layouts
   DevBuf half_pool;  // all f16 hi/lo copies
+  DevBuf cond_pool;  // per-output-channel conditioning of those copies: scale[rows] | alpha[rows] per weight matrix (GemmCore::w_alpha)
+  std::unordered_map<const void*, const float*> walpha;  // half-precision weight copy (plain or packed) -> its alpha vector
   std::vector<BlockW> blocks;
   std::vector<TextBlockW> tblocks;
   std::vector<VocosLayerW> vlayers;

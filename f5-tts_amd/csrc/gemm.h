@@ -26,7 +26,22 @@ struct GemmCore {
   int a_rows;         // rows of A that exist (<= M): rows beyond are read as zero
   int w_rows;         // rows of W that exist (<= N)
   int group_m;        // tile rasterisation: row-tiles per group (0/1 = channel tiles fastest over the whole grid), see gemm_kernel
+  // Per-output-channel factors that undo the conditioning of W (null = none): the half-precision copies of a weight matrix hold
+  // W[n, :] * 2^e[n], e[n] chosen so that the row's largest entry sits near 2^13 (engine finalize, csrc/api.cpp `carve`) — a row of 1e-5
+  // entries would otherwise be fp16 SUBNORMALS (11 bits, no `lo` part at all).  Every kernel multiplies its accumulators by
+  // w_alpha[n] = 2^-e[n] before the epilogue sees them: exact (powers of two), so results equal those of the unconditioned weights up to
+  // the rounding the conditioning removes.
+  const float* w_alpha;
 };
+
+// acc (4 consecutive output channels n .. n+3) with the weight conditioning undone
+__device__ __forceinline__ float4 unscale4(const GemmCore& g, int n, float4 v) {
+  if (g.w_alpha) {
+    const float4 a = *reinterpret_cast<const float4*>(g.w_alpha + n);
+    v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+  }
+  return v;
+}
 
 // Generic store epilogue:
 //   v = alpha * acc + bias[n];  v = act(v);  v *= colscale[n];
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmCore g, Epi ep
         if constexpr (ABL & 8) {  // no epilogue: keep the accumulators alive
           asm volatile("" ::"v"(acc[j][i][4 * q]), "v"(acc[j][i][4 * q + 1]), "v"(acc[j][i][4 * q + 2]), "v"(acc[j][i][4 * q + 3]));
         } else {
-          if (n < g.N) epi(m, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]), z);
+          if (n < g.N) epi(m, n, unscale4(g, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3])), z);
         }
       }
     }
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_glds_kernel(GemmCore g, E
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = n0 + wn * 32 * TN + i * 32 + 8 * q + 4 * (lane >> 5);
-        if (n < g.N) epi(m, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]), z);
+        if (n < g.N) epi(m, n, unscale4(g, n, make_float4(acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3])), z);
       }
     }
   }

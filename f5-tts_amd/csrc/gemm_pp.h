@@ -336,6 +336,26 @@ struct PpEpiQKV {
   }
 };
 
+// the weight conditioning undone on a wave's accumulator tiles (GemmCore::w_alpha): channels n_w + 32 i + 8 q + 4 (lane >> 5) + 0..3
+template <int TM, int TN>
+__device__ __forceinline__ void pp_unscale(f32x16 (&acc)[TM][TN], const GemmCore& g, int n_w, int lane) {
+  if (!g.w_alpha) return;  // wave-uniform
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int nb = n_w + 32 * i;
+    if (nb >= g.N) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(g.w_alpha + nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        acc[j][i][4 * q] *= a.x; acc[j][i][4 * q + 1] *= a.y; acc[j][i][4 * q + 2] *= a.z; acc[j][i][4 * q + 3] *= a.w;
+      }
+    }
+  }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------
 template <int TM, int TN, int WGM, int WGN, int NS, int KSP = 1>
 constexpr int gemm_pp_lds_bytes() {
@@ -547,6 +567,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
   } else if constexpr (KSP * KSS == 1) {
+    pp_unscale<TM, TN>(acc, g, n0 + wn * 32 * TN, lane);
     epi.template tile<TM, TN>(acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   } else {
     // The two groups hold partial sums of the same tiles.  Tile t = j * TN + i is FINISHED by group (t < NT0 ? 0 : 1): every wave parks the
@@ -579,6 +600,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
             one[0][0][4 * q + 2] = o.z + acc[j][i][4 * q + 2]; one[0][0][4 * q + 3] = o.w + acc[j][i][4 * q + 3];
           }
         }
+        pp_unscale<1, 1>(one, g, n0 + wn * 32 * TN + 32 * i, lane);
         epi.template tile<1, 1>(one, m0 + wm * 32 * TM + 32 * j, n0 + wn * 32 * TN + 32 * i, lane);
       }
     });

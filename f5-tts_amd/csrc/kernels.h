@@ -70,6 +70,9 @@ hipError_t launch_rope_table(const float* inv_freq, int n, int half, float* out,
 hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s);
 // [rows, K] fp32 -> packed fp16x3 operand [rows, 2K]: k-blocks of 32 as [32 hi | 32 lo] (gemm.h), K % 32 == 0
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s);
+// W [rows, K] fp32 -> per-row power-of-two scale (largest entry to [2^12, 2^13)) and its inverse, the plain fp16 copy hi [rows, K] and the
+// packed hi | lo copy pk [rows, 2K] of the scaled rows (GemmCore::w_alpha takes `alpha`)
+hipError_t launch_condition_weight(const float* src, int rows, int K, float* scale, float* alpha, f16* hi, f16* pk, hipStream_t s);
 // conv_pos weights [D, cpg, K] -> per-tap operand layout [G][K][cpg(co)][cpg(ci)] (fp32 + f16 hi/lo)
 hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo, hipStream_t s);
 // [C, 1, 7] depthwise weights -> [7, C]

@@ -86,3 +86,48 @@ def barrier_max_seconds(seconds: float, device: torch.device | None = None) -> f
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def pin_to_gpu_numa(local_rank: int) -> dict:
+    """Keep this rank's host threads on the NUMA node its GPU hangs off (staging copies and launches then stay off the socket
+    interconnect).  Best effort, Linux sysfs only: the PCI address of ``cuda:<local_rank>`` -> ``/sys/bus/pci/devices/<addr>/numa_node`` ->
+    that node's cpulist intersected with the CPUs the process may use.  Returns what it did (bench.py puts it into its line)."""
+    info = {"numa_node": None, "cpus": None, "pinned": False}
+    try:
+        if not torch.cuda.is_available() or not hasattr(os, "sched_setaffinity"):
+            return info
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id  # torch >= 2.x: "0000:0c:00.0"-style string or an int bus number
+        addr = bus.lower() if isinstance(bus, str) else None
+        if addr is None:
+            p = torch.cuda.get_device_properties(local_rank)
+            addr = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+        node = int(open(f"/sys/bus/pci/devices/{addr}/numa_node").read())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        cpus = set(_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())) & set(os.sched_getaffinity(0))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(cpus=len(cpus), pinned=True)
+    except Exception as e:  # containers often hide sysfs: not an error
+        info["error"] = type(e).__name__
+    return info
+
+
+def ranks_seen(device) -> int:
+    """An all-reduce of ones over the job's process group: how many ranks actually took part in a collective (1 without a group)."""
+    if not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(one)
+    return int(one.item())

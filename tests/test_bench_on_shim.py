@@ -21,7 +21,7 @@ LAUNCHER_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"
 
 def run(cmd, lib, timeout=900, expect_fail=False, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_ENV}
-    env.update(F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2", **extra_env)
+    env.update(dict(F5HIP_EMU_LIB=lib._name, OMP_NUM_THREADS="2"), **extra_env)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     if expect_fail:
         assert r.returncode != 0, r.stdout[-1000:]
@@ -52,6 +52,16 @@ def test_plain_gpus_2_command_launches_its_own_two_ranks(engine_emu_lib):  # noq
     assert d["config"]["weight_broadcast_plus_finalize_s"] > 0
     assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim)
     assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
+    assert d["config"]["rccl_ranks_seen"] == 2 and len(d["config"]["host_numa_pinning"]) == 2  # the all-reduce census and every rank's pinning report
+
+
+def test_eight_ranks_name_the_sharded_configuration(engine_emu_lib):  # noqa: F811
+    """World size 8 (BASELINE.json configs[3] is 8 ranks x 32 utterances): every rank takes part in the census, the line carries eight
+    per-rank times, and the workload string says how many utterances over how many GPUs."""
+    d = run([sys.executable, HARNESS, "--gpus", "8", "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib, timeout=2400,
+            OMP_NUM_THREADS="1")
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == d["config"]["rccl_ranks_seen"] == 8
+    assert len(d["config"]["per_rank_ms_per_step"]) == 8 and d["config"]["global_batch"] == 8
 
 
 def test_under_the_drivers_launcher(engine_emu_lib):  # noqa: F811
