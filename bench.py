@@ -176,9 +176,10 @@ def pmc_traffic(a, B):
             d = json.load(open(f))
         except Exception:
             continue
-        if (d.get("precision") == a.precision and d.get("batch") == B and d.get("nfe") == a.nfe and d.get("model") == a.model
-                and d.get("kernel_source_hash") == want):
-            return d.get("hbm_bytes_per_launch"), os.path.basename(f)
+        # bytes per launch do not depend on the number of ODE steps: a pass at a smaller NFE counts (B = 32 at NFE 32 does not finish a
+        # counter pass in the GPU time a round has; tools/pmc_bench.sh runs it at NFE 2)
+        if (d.get("precision") == a.precision and d.get("batch") == B and d.get("model") == a.model and d.get("kernel_source_hash") == want):
+            return d.get("hbm_bytes_per_launch"), os.path.basename(f) + ("" if d.get("nfe") == a.nfe else f" (counter pass at NFE {d.get('nfe')})")
     return None, None
 
 

@@ -387,6 +387,11 @@ WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f1
 // attention operand split; 4: q, k split, P and V plain — the default of round 1).  The default since round 2 is plain fp16 q, k, P, V:
 // measured on every reference-minted golden (tools/attn_precision_check.py) the generated mel moves from <= 1.4e-4 to
 // <= 2.9e-4 max-abs against a 1e-3 tolerance, for a third of the attention's MFMA work.
+// SDPA's default 1/sqrt(dim_head) on q (modules.py:511-520).  The flash kernel takes q with log2(e) folded in as well: its exponentials are
+// base-2 (v_exp_f32) and its scores then need no multiply — and the lazy reference maximum becomes possible (attention_kernel.h LAZY).  The
+// materialised fp32 path (exact_attn) softmaxes natural-log scores.
+float attn_qscale(int dh, bool exact_attn) { return (exact_attn ? 1.0f : 1.4426950408889634f) / sqrtf((float)dh); }
+
 bool split_qk(const f5hip_ctx* ctx, int op) { return op == OP_F16X3 && (ctx->attn_impl == 2 || ctx->attn_impl == 4); }
 
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
@@ -909,7 +914,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
                                  x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
                                  kvlen2, seg2_off, 1, ctx->attn_part.p ? ctx->attn_kv_split : 1,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 : nullptr,
-                                 ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
+                                 ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr,
+                                 /*log2q: flash_qscale() put log2(e) into q*/ 1));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
                                                       // (the two chains are rarely in attention at the same time)
       }
     }
@@ -926,7 +932,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
   const int64_t qoff = (int64_t)s0 * H * ns * dh;
   EpiQKV e{};
   e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
-  e.pe_heads = c.pe_attn_head; e.qscale = 1.0f / sqrtf((float)dh);
+  e.pe_heads = c.pe_attn_head; e.qscale = attn_qscale(dh, exact_attn);
   e.qk_raw = c.qk_norm ? 1 : 0;
   if (exact_attn || c.qk_norm) { e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; }
   if (exact_attn) {
@@ -1317,7 +1323,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     const int M = text ? Mc : Mx, nseq = text ? nt : n;
     EpiQKV e{};
     e.bias = text ? bw.bqkv_c : bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = nseq; e.heads = H; e.dh = dh;
-    e.pe_heads = -1; e.qscale = 1.0f / sqrtf((float)dh);  // rope on every head of both streams, each from position 0 (modules.py:626-636)
+    e.pe_heads = -1; e.qscale = attn_qscale(dh, exact_attn);  // rope on every head of both streams, each from position 0 (modules.py:626-636)
     e.slab_n = ns; e.pos_off = text ? n : 0;
     e.qk_raw = c.qk_norm ? 1 : 0;
     if (exact_attn || c.qk_norm) { e.q32 = ctx->q32.as<float>(); e.k32 = ctx->k32.as<float>(); }
@@ -1381,7 +1387,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     if (c.qk_norm) {
       Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
       HIPCHK(launch_qk_norm_rope(ctx->q32.as<float>(), ctx->k32.as<float>(), bw.qn, bw.kn, ctx->rope.as<float>(), (int64_t)S * H * ns, ns, H, dh, -1,
-                                 1.0f / sqrtf((float)dh), 1e-6f, exact_attn ? nullptr : ctx->q16.as<f16>(),
+                                 attn_qscale(dh, exact_attn), 1e-6f, exact_attn ? nullptr : ctx->q16.as<f16>(),
                                  (!exact_attn && split_qk(ctx, op)) ? ctx->q16_lo.as<f16>() : nullptr,
                                  exact_attn ? nullptr : ctx->k16.as<f16>(),
                                  (!exact_attn && split_qk(ctx, op)) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));

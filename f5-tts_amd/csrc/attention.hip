@@ -43,35 +43,42 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   // latency-bound and pays +3 % for the extra dependent MFMAs at the end of a tile (tools/r2_call30.sh).  F5HIP_ATTN_VALU_SUM=1 / 0 forces.
   static const int vsum_env = [] { const char* v = getenv("F5HIP_ATTN_VALU_SUM"); return v ? atoi(v) : -1; }();
   const bool vsum = vsum_env >= 0 ? vsum_env == 1 : six;
+  // lazy reference maximum (attention_kernel.h LAZY): whenever q carries log2(e); F5HIP_ATTN_LAZY=0 keeps the exact running maximum (A/B)
+  static const bool lazy_off = [] { const char* v = getenv("F5HIP_ATTN_LAZY"); return v && atoi(v) == 0; }();
+  const bool lazy = a.log2q && !lazy_off;
+#define F5_FLASH(NWV, VS, LZ, THREADS) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, NWV, false, VS, LZ>), dim3(a.nwg), dim3(THREADS), lds, s, a)
   if (six) {
     a.nqb = nqb6; a.nwg = bh * nqb6;
-    if (vsum && PVSPLIT == 1) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6, false, true>), dim3(a.nwg), dim3(384), lds, s, a);
-    else hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 6>), dim3(a.nwg), dim3(384), lds, s, a);
+    if (vsum && PVSPLIT == 1) { if (lazy) F5_FLASH(6, true, true, 384); else F5_FLASH(6, true, false, 384); }
+    else { if (lazy) F5_FLASH(6, false, true, 384); else F5_FLASH(6, false, false, 384); }
   } else {
     a.nqb = nqb4; a.nwg = bh * nqb4;
-    if (vsum && PVSPLIT == 1) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4, false, true>), dim3(a.nwg), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, 4>), dim3(a.nwg), dim3(256), lds, s, a);
+    if (vsum && PVSPLIT == 1) { if (lazy) F5_FLASH(4, true, true, 256); else F5_FLASH(4, true, false, 256); }
+    else { if (lazy) F5_FLASH(4, false, true, 256); else F5_FLASH(4, false, false, 256); }
   }
+#undef F5_FLASH
   return hipGetLastError();
 }
-template <int NSPLIT, int PVSPLIT>
-hipError_t set_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     flash_lds_bytes<NSPLIT, PVSPLIT>());
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          flash_lds_bytes<NSPLIT, PVSPLIT>());
-  if (e != hipSuccess) return e;
-  if constexpr (PVSPLIT == 1) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            flash_lds_bytes<NSPLIT, PVSPLIT>());
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            flash_lds_bytes<NSPLIT, PVSPLIT>());
-    if (e != hipSuccess) return e;
-  }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, 6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <int NSPLIT, int PVSPLIT, int NW, bool SPLIT, bool VS, bool LZ>
+hipError_t set_attr_one() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attn_kernel<NSPLIT, PVSPLIT, NW, SPLIT, VS, LZ>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              flash_lds_bytes<NSPLIT, PVSPLIT>());
+}
+template <int NSPLIT, int PVSPLIT>
+hipError_t set_attr() {  // every instantiation launch() can pick
+  hipError_t e;
+  if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, true, false, false>()) != hipSuccess) return e;
+  if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, false, false>()) != hipSuccess) return e;
+  if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, false, true>()) != hipSuccess) return e;
+  if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, false, false>()) != hipSuccess) return e;
+  if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, false, true>()) != hipSuccess) return e;
+  if constexpr (PVSPLIT == 1) {
+    if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, true, false>()) != hipSuccess) return e;
+    if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, true, true>()) != hipSuccess) return e;
+    if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, true, false>()) != hipSuccess) return e;
+    if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, true, true>()) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 }  // namespace
@@ -87,8 +94,9 @@ hipError_t init_attention_kernels() {
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed,
-                             const int32_t* kvlen2, int seg2_off, int co_launches, int kv_split, float* part_o, float* part_ml) {
+                             const int32_t* kvlen2, int seg2_off, int co_launches, int kv_split, float* part_o, float* part_ml, int log2q) {
   FlashArgs a{};
+  a.log2q = log2q;
   a.kv_split = kv_split < 1 ? 1 : kv_split; a.part_o = part_o; a.part_ml = part_ml;
   a.o_packed = o_packed;
   a.kvlen2 = kvlen2; a.seg2_off = seg2_off;

@@ -29,6 +29,9 @@ struct FlashArgs {
   int kv_split;
   float* part_o;
   float* part_ml;
+  // 1: q already carries log2(e) (the QKV epilogue folded it into the 1/sqrt(dh) scale): scores are base-2 logarithms and the exponentials
+  // need no multiply.  0: natural-log scores (tests and microbenchmarks that prepare q themselves).
+  int log2q;
 };
 
 // NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
@@ -42,8 +45,15 @@ constexpr int flash_lds_bytes() {
 // NW: waves per workgroup = 32-row query groups per block.  4 (128 query rows, two workgroups per CU) everywhere except where 6
 // (192 rows, one workgroup per CU) makes the grid fit the chip in ONE round: B = 1, N = 1406 gives 11 x 32 = 352 blocks of 128 rows
 // (CUs with 2 and CUs with 1 workgroup: 69 % balance) but 8 x 32 = 256 blocks of 192 rows.  Only the first 4 waves stage K / V tiles.
-template <int NSPLIT, int PVSPLIT, int NW = 4, bool SPLIT = false, bool VSUM = false>  // VSUM: A/B switch — row sums on the VALU (round 1)
+// LAZY (round 3; needs log2q, not with SPLIT): the running maximum is a REFERENCE, not the exact maximum — it is raised only when a tile
+// exceeds it by more than LAZY_TAU (8: P <= 256, far inside fp16 and fp32 range), which after the first tiles is rare.  The scores then leave the
+// matrix pipe already relative to the reference (the first MFMA of a chain accumulates onto a register tile holding -reference), so the
+// steady-state tile needs no subtraction, no exp of the correction and no rescale of O and the row sum: 32 FMA + 32 multiplies + the
+// lane exchange of the maximum fewer per 64-key tile and wave (of ~215 VALU instructions against 20 MFMAs: the kernel is VALU-bound).
+constexpr float LAZY_TAU = 8.0f;
+template <int NSPLIT, int PVSPLIT, int NW = 4, bool SPLIT = false, bool VSUM = false, bool LAZY = false>  // VSUM: A/B switch — row sums on the VALU (round 1)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(FlashArgs a) {
+  static_assert(!(LAZY && SPLIT), "the key-split partial results carry exact maxima");
   constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
@@ -149,6 +159,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
 
+  const float dom = a.log2q ? 1.0f : LOG2E;  // score units -> base-2 exponent
+  f32x16 negm;                               // LAZY: -reference maximum of this lane's query row in every register (the srcC of a tile's first MFMAs)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  bool first = true;                         // LAZY: the first processed tile fixes the reference at its exact row maximum
+
   // one 64-key tile held in LDS stage `stage`: scores, online softmax, O update
   auto process = [&](int t, int stage) {
     const char* base = smem + stage * STAGE;
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     // ---- S^T = K . Q^T for the 64 keys of the tile --------------------------------------------------
     f32x16 s[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { s[0][r] = LAZY ? negm[r] : 0.f; s[1][r] = LAZY ? negm[r] : 0.f; }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -189,23 +205,48 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-    const float mb = m_new * LOG2E;
-    float rs = 0.f;
+    float alpha = 1.0f, rs = 0.f;
+    if constexpr (LAZY) {
+      // s holds score - reference (base-2 units).  Raise the reference where a row went more than LAZY_TAU above it (and fix it on the first tile)
+      if (f5_wave_any(first || mx > LAZY_TAU)) {
+        const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the row's maximum over both half-waves' keys
+        const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
+        if (!first) {
+          alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+          for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mb));
-        s[kb][r] = p;
-        if constexpr (!MSUM) rs += p;
+        for (int r = 0; r < 16; ++r) { s[0][r] -= delta; s[1][r] -= delta; negm[r] -= delta; }
+        first = false;
       }
-    if constexpr (!MSUM) l_run = l_run * alpha + rs;
-    m_run = m_new;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+          s[kb][r] = p;
+          if constexpr (!MSUM) rs += p;
+        }
+      if constexpr (!MSUM) l_run = l_run * alpha + rs;
+    } else {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * dom);
+      const float mb = m_new * dom;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], dom, -mb));
+          s[kb][r] = p;
+          if constexpr (!MSUM) rs += p;
+        }
+      if constexpr (!MSUM) l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    }
 
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
     f32x16 rsum;
@@ -316,7 +357,7 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a, int64_t
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float l = 0.f;
   for (int s = 0; s < a.kv_split; ++s) {
-    const float w = __builtin_amdgcn_exp2f((ml[2 * s] - m) * LOG2E);  // 0 for a part without valid keys (m_s = -inf)
+    const float w = __builtin_amdgcn_exp2f((ml[2 * s] - m) * (a.log2q ? 1.0f : LOG2E));  // 0 for a part without valid keys (m_s = -inf)
     const float4 v = *reinterpret_cast<const float4*>(a.part_o + (row * a.kv_split + s) * 64 + d4);
     acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
     l = fmaf(w, ml[2 * s + 1], l);

@@ -112,6 +112,15 @@ __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
   lo = (f16)(v - (float)hi);
 }
 
+// wave-uniform: does any lane hold the predicate?
+__device__ __forceinline__ bool f5_wave_any(bool pred) {
+#ifdef F5_HIPEMU
+  return hipemu::wave_any(pred);
+#else
+  return __builtin_amdgcn_ballot_w64(pred) != 0ull;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

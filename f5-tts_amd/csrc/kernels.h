@@ -101,7 +101,8 @@ hipError_t init_attention_kernels();
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s,
                              int o_packed = 0, const int32_t* kvlen2 = nullptr, int seg2_off = 0, int co_launches = 1, int kv_split = 1,
-                             float* part_o = nullptr, float* part_ml = nullptr);
+                             float* part_o = nullptr, float* part_ml = nullptr, int log2q = 0);
+// log2q = 1: q carries log2(e) on top of 1/sqrt(dh) (scores are base-2 logarithms; enables the lazy reference maximum, attention_kernel.h)
 // kv_split > 1: every query block is cut into kv_split workgroups over contiguous key ranges (small batches: more, shorter workgroups);
 // part_o [Bp*heads*n, kv_split, 64] / part_ml [Bp*heads*n, kv_split, 2] fp32 scratch for the unnormalised partial results
 // co_launches: how many identical launches run concurrently on other streams (the cond / uncond chains): enters the block-size choice

@@ -350,8 +350,9 @@ int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, 
   if (fill(tmp, nv, 13u, 1.0f, s) != hipSuccess || launch_split_f16(tmp, nv, 1.0f, vh, vl, s) != hipSuccess) return F5HIP_ERR_HIP;
   const bool x3 = precision == F5HIP_PREC_FP16X3;
   return time_it([&] {
+    static const int log2q = getenv("KB_ATTN_LOG2Q") ? 1 : 0;  // 1: treat q as carrying log2(e) -> the lazy-reference form (timing A/B)
     return launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, qh, x3 ? ql : nullptr, kh, x3 ? kl : nullptr, vh, x3 ? vl : nullptr, ldv, batch2, heads, n, nullptr, oh,
-                             x3 ? ol : nullptr, s);
+                             x3 ? ol : nullptr, s, 0, nullptr, 0, 1, 1, nullptr, nullptr, log2q);
   }, iters, s, avg_ms);
 }
 

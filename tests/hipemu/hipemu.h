@@ -297,6 +297,18 @@ inline float shfl_xor(float v, int mask, int) {
   return r;
 }
 
+// wave vote: does any lane of the wave hold a non-zero predicate?  (the kernels use it through f5_wave_any, common.h)
+inline bool wave_any(bool pred) {
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  w.sh[lane] = pred ? 1.0f : 0.0f;
+  barrier_wait(w.bar);
+  bool r = false;
+  for (int l = 0; l < w.bar.expected; ++l) r = r || w.sh[l] != 0.0f;
+  barrier_wait(w.bar);
+  return r;
+}
+
 inline unsigned shfl_xor_u32(unsigned v, int mask) {
   WaveCtx& w = wv();
   const int lane = blk->cur->lane;

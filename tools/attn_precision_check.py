@@ -22,7 +22,7 @@ for name in names:
         continue
     cfg, wav, text, duration, lens = MG.case_inputs(c)
     eng = F5HipEngine(cfg, None, device=0)
-    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    eng.load_state_dict(MG.case_weights(c))
     g = np.load(os.path.join(GOLD, name + ".npz"))["out"]
     res = []
     for impl in (4, 0):

@@ -25,6 +25,11 @@ def klass(name):
         return "layernorm"
     if "convpos_kernel" in name:
         return "convpos"
+    # the memory-bound kernels north_star names (ConvNeXt text blocks, Vocos blocks, mel front-end, iSTFT) and the per-step update
+    for key in ("dwconv7_ln_kernel", "grn_sumsq_finish_kernel", "grn_sumsq_kernel", "grn_apply_kernel", "text_embed_kernel", "mel_kernel",
+                "istft_frames_kernel", "istft_ola_kernel", "cfg_euler_kernel", "im2col7_kernel"):
+        if key in name:
+            return key[: -len("_kernel")]
     return None
 
 
@@ -37,6 +42,18 @@ def load(d, counter):
             k = klass(r["Kernel_Name"])
             if k:
                 agg[k][0] += float(r["Counter_Value"])
+                agg[k][1] += 1
+    return agg
+
+
+def durations(d):
+    """Average kernel duration per class (us) and launches from a `rocprofv3 --kernel-trace --output-format csv` pass of the same command."""
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = klass(r["Kernel_Name"])
+            if k:
+                agg[k][0] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-3
                 agg[k][1] += 1
     return agg
 
@@ -65,6 +82,13 @@ def main():
     for k in busy:
         if k in res["classes"] and act.get(k, [0, 0])[0] > 0:
             res["classes"][k]["mfma_busy_frac"] = round(busy[k][0] / (act[k][0] / 8.0 * 1024.0), 4)
+    # achieved HBM rate of every class: counter bytes per launch over the average duration of the un-instrumented kernel-trace pass
+    dur = durations(os.path.join(out, "trace"))
+    for k, c in res["classes"].items():
+        if dur.get(k, [0, 0])[1]:
+            c["avg_us"] = round(dur[k][0] / dur[k][1], 3)
+            c["hbm_gbps"] = round((c["fetch_bytes_per_launch_x2"] + c["write_bytes_per_launch"]) / (c["avg_us"] * 1e-6) / 1e9, 1)
+            c["hbm_frac_of_8TBps"] = round(c["hbm_gbps"] / 8000.0, 4)
     dom = "gemm_" + a.precision
     if dom in res["classes"]:
         c = res["classes"][dom]
