@@ -157,6 +157,8 @@ PRESETS = {
     "tiny48": replace(DIT_TINY, dim=768, heads=12),  # 48 channels per conv group (768 / 16), like the Small models, at depth 2
     "tiny_inner512": replace(DIT_TINY, heads=8),  # attention width heads*dim_head = 512 != dim = 256 (modules.py:397-400)
     "tiny_flags": DIT_TINY_FLAGS,
+    "tiny_mask": replace(DIT_TINY, attn_mask_enabled=True),  # key-padding mask alone: what the packed-row path (option "packed_rows") needs
+    "F5TTS_v1_Small_mask": replace(F5TTS_V1_SMALL, attn_mask_enabled=True),
     "tiny_qknorm": replace(DIT_TINY, qk_norm="rms_norm"),
     "tiny_longskip": replace(DIT_TINY, long_skip_connection=True),
     "tiny_avgup": replace(DIT_TINY, text_embedding_average_upsampling=True),

@@ -877,7 +877,7 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
 // ---- attention over [2B * H] (batch', head) slabs of ns tokens: q/k/v were written by the QKV epilogue -------------------------------
 // S sequences starting at sequence s0 of the packed [cond | uncond] batch (o32/o_hi/o_lo/kvlen are already offset by the caller)
 int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
-                  int64_t ldO, hipStream_t st, const int32_t* kvlen2 = nullptr, int seg2_off = 0) {
+                  int64_t ldO, hipStream_t st, const int32_t* kvlen2 = nullptr, int seg2_off = 0, const int32_t* cu_rows = nullptr) {
   const auto& c = ctx->cfg;
   const int H = c.heads, dh = c.dim_head, inner = H * dh;
   const int64_t qoff = (int64_t)s0 * H * n * dh;                      // q/k slabs [seq*H, n, dh]
@@ -915,7 +915,7 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
                                  kvlen2, seg2_off, 1, ctx->attn_part.p ? ctx->attn_kv_split : 1,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 : nullptr,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr,
-                                 /*log2q: flash_qscale() put log2(e) into q*/ 1));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
+                                 /*log2q: flash_qscale() put log2(e) into q*/ 1, cu_rows));  // co_launches stays 1: counting the other CFG chain's launch as concurrent made B=1 8 % slower
                                                       // (the two chains are rarely in attention at the same time)
       }
     }
@@ -926,13 +926,14 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
 // scale).  M rows = sequences [s0, s0 + M/ns) of ns tokens.  With qk_norm the epilogue leaves q and k raw (fp32, bias only) and
 // qk_norm_rope_kernel applies RMSNorm(dim_head) -> rope -> scale and writes what the attention kernels read (modules.py:493-509).
 int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M, int ns, int s0, int op, bool exact_attn, int wbytes,
-            hipStream_t st) {
+            hipStream_t st, const uint32_t* rowinfo = nullptr, int nslab = 0) {
   const auto& c = ctx->cfg;
   const int D = c.dim, H = c.heads, dh = c.dim_head, inner = H * dh;
-  const int64_t qoff = (int64_t)s0 * H * ns * dh;
+  const int64_t qoff = rowinfo ? 0 : (int64_t)s0 * H * ns * dh;
   EpiQKV e{};
   e.bias = bw.bqkv; e.rope_cs = ctx->rope.as<float>(); e.nseq = ns; e.heads = H; e.dh = dh;
   e.pe_heads = c.pe_attn_head; e.qscale = attn_qscale(dh, exact_attn);
+  e.rowinfo = rowinfo; e.nslab = nslab;  // packed rows: rowinfo names the sequences by their index in the whole batch, so the slabs are NOT offset by s0
   e.qk_raw = c.qk_norm ? 1 : 0;
   if (exact_attn || c.qk_norm) { e.q32 = ctx->q32.as<float>() + qoff; e.k32 = ctx->k32.as<float>() + qoff; }
   if (exact_attn) {
@@ -940,7 +941,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     e.vt32 = ctx->vt32.as<float>() + (int64_t)s0 * inner * e.ldvt;
   } else {
     e.ldvt = (ns + 7) & ~7;
-    const int64_t voff = (int64_t)s0 * inner * e.ldvt;
+    const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
     e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
     if (split_qk(ctx, op)) {  // lo planes only for what the flash kernel will read
       e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
@@ -956,6 +957,91 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     Prof pr(ctx, st, KC_ELEMWISE, 0, 2.0 * M * inner * (4.0 + (exact_attn ? 4.0 : 2.0 * (e.q16_lo ? 2 : 1))));
     HIPCHK(launch_qk_norm_rope(e.q32, e.k32, bw.qn, bw.kn, e.rope_cs, (int64_t)(M / ns) * H * ns, ns, H, dh, c.pe_attn_head, e.qscale, 1e-6f,
                                e.q16, e.q16_lo, e.k16, e.k16_lo, st));
+  }
+  return F5HIP_OK;
+}
+
+// ---- the block loop, final norm and output projection of run_step over PACKED rows (option "packed_rows") -------------------------------
+// Rows [p0, p0 + Mp) of the packed order = the valid rows of sequences [s0, s0 + S); x arrives gathered in ctx->xpk.  Same kernels as the
+// padded loop: only the q|k|v epilogue (row -> (sequence, token) from a table) and the attention (output rows from cu_rows, no blocks past a
+// sequence's end) know about the layout; no row mask is needed any more.  The velocity is scattered back to the padded layout (zeros in
+// the padding) for the CFG / Euler update.
+int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int S, int s0, int64_t p0, int Mp, hipStream_t st, int br) {
+  const int step = sg.eidx, nb = ctx->nb;
+  const auto& c = ctx->cfg;
+  const int D = c.dim, mel = c.mel_dim, inner = c.heads * c.dim_head, F = c.ff_inner;
+  const int64_t BN = (int64_t)B * n;
+  const std::string p = "transformer.";
+  float* x = ctx->xpk.as<float>() + p0 * D;
+  const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
+  const int pk = op == OP_F16X3 ? 1 : 0, wbytes = 2;
+  const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
+  f16* a_hi = ctx->a_hi.as<f16>() + p0 * ldA;
+  f16* a_lo = pk ? a_hi + 32 : nullptr;
+  f16* o_all = ctx->o_hi.as<f16>();  // the attention writes row cu_rows[s] + q of the WHOLE packed order
+  f16* o_hi = o_all + p0 * ldO;
+  f16* f_hi = ctx->f_hi.as<f16>() + p0 * ldF;
+  f16* f_lo = pk ? f_hi + 32 : nullptr;
+  const int32_t* kvlen = ctx->kvlen.as<int32_t>() + s0;
+  const int32_t* cu = ctx->cu_rows.as<int32_t>() + s0;
+  const uint32_t* rowinfo = ctx->rowinfo.as<uint32_t>() + p0;
+  const double ln_bytes = (double)Mp * D * (4 + wbytes * (pk ? 2 : 1));
+  for (int i = 0; i < c.depth; ++i) {
+    const BlockW& bw = ctx->blocks[i];
+    const float* md = mods_step + (int64_t)i * 6 * D;
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + D, md, nullptr, a_hi, a_lo, D, st, pk, ldA));
+    }
+    CHK(run_qkv(ctx, bw, a_hi, ldA, Mp, n, s0, op, false, wbytes, st, rowinfo, nb * B));
+    CHK(run_attention(ctx, S, s0, n, op, false, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pk, ldO, st, nullptr, 0, cu));
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, inner), (double)Mp * inner * wbytes + (double)inner * D * wbytes + 2.0 * Mp * D * 4);
+      GemmCore g = core(o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, Mp, D, inner);
+      EpiStore e = epi_store(x, D, bw.bo);
+      e.colscale = md + 2 * D; e.res = x; e.ldres = D;  // every row is a valid row: no mask (modules.py:554-556 zeroes the padding only)
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, nullptr, a_hi, a_lo, D, st, pk, ldA));
+    }
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, F, D), (double)Mp * D * wbytes + (double)F * D * wbytes + (double)Mp * F * wbytes);
+      GemmCore g = core(a_hi, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, Mp, F, D);
+      EpiStore e = epi_store(nullptr, F, bw.b1, ACT_GELU_TANH);
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+    {
+      Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, F), (double)Mp * F * wbytes + (double)F * D * wbytes + 2.0 * Mp * D * 4);
+      GemmCore g = core(f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, Mp, D, F);
+      EpiStore e = epi_store(x, D, bw.b2);
+      e.colscale = md + 5 * D; e.res = x; e.ldres = D;
+      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+    }
+  }
+  {  // AdaLayerNorm_Final + proj_out on the packed rows, then back to the padded layout
+    const float* fm = ctx->fmods.as<float>() + (int64_t)step * 2 * D;
+    {
+      Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
+      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, fm, fm + D, nullptr, a_hi, a_lo, D, st, pk, ldA));
+    }
+    float* vp = ctx->velpk.as<float>() + p0 * mel;
+    {
+      Prof pr(ctx, st, KC_GEMM_MISC, gemm_flops(Mp, mel, D), 0);
+      GemmCore g = core(a_hi, ldA, wsel(ctx, op, W(ctx, p + "proj_out.weight"), ctx->wp_hi.as<f16>(), ctx->wp_pk.as<f16>()), ldA, Mp, mel, D);
+      HIPCHK(launch_gemm_store(op, g, epi_store(vp, mel, W(ctx, p + "proj_out.bias")), 1, st));
+    }
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 2.0 * Mp * mel * 4);
+    float* vel = ctx->vel.as<float>();
+    HIPCHK(hipMemsetAsync(vel + (int64_t)s0 * n * mel, 0, (size_t)S * n * mel * sizeof(float), st));  // the padding moves by zero
+    HIPCHK(launch_scatter_rows(vp, ctx->rowmap.as<int32_t>() + p0, Mp, mel, vel, st));
+  }
+  if (br < 0) {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 4.0 * BN * mel * 4);
+    HIPCHK(launch_cfg_euler(sg.ybase, sg.ydst, ctx->vel.as<float>(), BN * mel, nb == 2, ctx->dt_dev.as<float>() + step, ctx->cfg_dev.as<float>(),
+                            sg.traj, ctx->dbg_vel.as<float>(), st));
   }
   return F5HIP_OK;
 }
@@ -998,6 +1084,17 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, S, n, D, c.conv_pos_groups,
                           c.conv_pos_kernel, x, st));
+  }
+  // Packed rows (option "packed_rows"; tables built by f5hip_sample): from here to the velocity the rows are the VALID rows of this call's
+  // sequences, gathered once — the block GEMMs, LayerNorms and the attention cost sum(lengths), not sequences x longest (the reference's varlen
+  // attention, modules.py:522-543, extended to the row-wise layers, whose padded rows nobody reads).
+  const bool packed = ctx->pk_rows > 0;
+  const int64_t p0 = packed ? ctx->cu_host[s0] : 0;  // first packed row of this call's sequences
+  const int Mp = packed ? (int)(ctx->cu_host[s0 + S] - p0) : M;
+  if (packed) {
+    Prof pr(ctx, st, KC_ELEMWISE, 0, 2.0 * Mp * D * 4);
+    HIPCHK(launch_gather_rows(ctx->x.as<float>(), ctx->rowmap.as<int32_t>() + p0, Mp, D, ctx->xpk.as<float>() + p0 * D, st));
+    return run_blocks_packed(ctx, B, n, sg, op, S, s0, p0, Mp, st, br);
   }
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const int pk = op == OP_F16X3 ? 1 : 0;      // fp16x3 operands are packed hi/lo rows: lo plane = hi + 32 halves, row stride 2K
@@ -1628,6 +1725,7 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "profile") ctx->profile = value != 0;
   else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
   else if (k == "branch_streams") { ctx->branch_streams = (int)value; ctx->ws_epoch++; }
+  else if (k == "packed_rows") { ctx->packed_opt = value ? 1 : 0; ctx->ws_epoch++; }
   else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
     if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
     ctx->attn_kv_split = (int)value;
@@ -1753,6 +1851,39 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
     memcpy(cmk, cond_mask, BN);  // cond_mask is a HOST array of the caller (include/f5hip.h): staged like the rest
     HIPCHK(hipMemcpyAsync(ctx->condmask.p, cmk, BN, hipMemcpyHostToDevice, st));
   }
+  {  // packed rows: only where dropping the padded rows cannot change a valid row — padded keys must already be masked out of the attention
+     // (attn_mask_enabled; with it off the reference lets the padding attend, modules.py:511-520) — and only for what is built (DiT, flash)
+    int64_t valid = 0;
+    for (int b = 0; b < B; ++b) valid += duration[b];
+    const bool packed = ctx->packed_opt && use_mask && c.attn_mask_enabled && c.backbone == 0 && !exact_attn && !c.long_skip_connection && !c.qk_norm &&
+                        ctx->attn_kv_split <= 1 && valid < BN && n < 65536 && 2 * B < 65536;
+    ctx->pk_rows = packed ? nb * valid : 0;
+    if (packed) {
+      const int64_t Mp = ctx->pk_rows;
+      STAGE(int32_t, rm, (size_t)Mp);
+      STAGE(uint32_t, ri, (size_t)Mp);
+      STAGE(int32_t, cu, (size_t)nb * B + 1);
+      ctx->cu_host.assign((size_t)nb * B + 1, 0);
+      int64_t r = 0;
+      for (int s = 0; s < nb * B; ++s) {
+        cu[s] = (int32_t)r;
+        const int64_t len = duration[s % B];
+        for (int64_t t2 = 0; t2 < len; ++t2, ++r) { rm[r] = (int32_t)((int64_t)s * n + t2); ri[r] = ((uint32_t)s << 16) | (uint32_t)t2; }
+      }
+      cu[nb * B] = (int32_t)r;
+      std::copy(cu, cu + nb * B + 1, ctx->cu_host.begin());
+      bool moved = false, mv = false;
+      HIPCHK(ctx->rowmap.ensure((size_t)2 * BN * 4, &mv)); moved |= mv;
+      HIPCHK(ctx->rowinfo.ensure((size_t)2 * BN * 4, &mv)); moved |= mv;
+      HIPCHK(ctx->cu_rows.ensure((size_t)(2 * B + 1) * 4, &mv)); moved |= mv;
+      HIPCHK(ctx->xpk.ensure((size_t)2 * BN * D * 4, &mv)); moved |= mv;
+      HIPCHK(ctx->velpk.ensure((size_t)2 * BN * mel * 4, &mv)); moved |= mv;
+      if (moved) ctx->ws_epoch++;
+      HIPCHK(hipMemcpyAsync(ctx->rowmap.p, rm, (size_t)Mp * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->rowinfo.p, ri, (size_t)Mp * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(ctx->cu_rows.p, cu, (size_t)(nb * B + 1) * 4, hipMemcpyHostToDevice, st));
+    }
+  }
   {
     Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
     HIPCHK(launch_mask_select(cond, ctx->condmask.as<uint8_t>(), BN, mel, ctx->step_cond.as<float>(), st));  // cfm.py:151-153
@@ -1808,7 +1939,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
       tbuf = ctx->traj_buf.as<float>();
     }
     const bool hit = ctx->graph_exec && k.B == B && k.n == n && k.nt == (c.backbone == 2 ? nt : 0) && k.steps == steps && k.prec == precision && k.use_mask == use_mask &&
-                     k.method == ode_method && k.traj == tbuf && k.ws_epoch == ctx->ws_epoch;
+                     k.method == ode_method && k.traj == tbuf && k.ws_epoch == ctx->ws_epoch && k.pk_rows == ctx->pk_rows &&
+                     k.pk_cond == (ctx->pk_rows ? ctx->cu_host[B] : 0);
     if (!hit) {
       if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
       if (!ctx->cap_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
@@ -1821,6 +1953,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
       HIPCHK(hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0));
       (void)hipGraphDestroy(graph);
       k.B = B; k.n = n; k.nt = c.backbone == 2 ? nt : 0; k.steps = steps; k.prec = precision; k.use_mask = use_mask; k.method = ode_method; k.traj = tbuf; k.ws_epoch = ctx->ws_epoch;
+      k.pk_rows = ctx->pk_rows; k.pk_cond = ctx->pk_rows ? ctx->cu_host[B] : 0;
     }
     HIPCHK(hipGraphLaunch(ctx->graph_exec, st));
     if (trajectory)  // states 1..steps (state 0 = y0 was copied above)

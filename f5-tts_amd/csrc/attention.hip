@@ -94,9 +94,11 @@ hipError_t init_attention_kernels() {
 
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s, int o_packed,
-                             const int32_t* kvlen2, int seg2_off, int co_launches, int kv_split, float* part_o, float* part_ml, int log2q) {
+                             const int32_t* kvlen2, int seg2_off, int co_launches, int kv_split, float* part_o, float* part_ml, int log2q, const int32_t* cu_rows) {
   FlashArgs a{};
   a.log2q = log2q;
+  a.cu_rows = cu_rows;
+  if (cu_rows && (kv_split > 1 || !kvlen)) return hipErrorInvalidValue;  // packed rows: the unsplit kernel, lengths required
   a.kv_split = kv_split < 1 ? 1 : kv_split; a.part_o = part_o; a.part_ml = part_ml;
   a.o_packed = o_packed;
   a.kvlen2 = kvlen2; a.seg2_off = seg2_off;

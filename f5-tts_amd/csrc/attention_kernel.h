@@ -32,6 +32,9 @@ struct FlashArgs {
   // 1: q already carries log2(e) (the QKV epilogue folded it into the 1/sqrt(dh) scale): scores are base-2 logarithms and the exponentials
   // need no multiply.  0: natural-log scores (tests and microbenchmarks that prepare q themselves).
   int log2q;
+  // Packed rows (engine option "packed_rows", with kvlen): the output row of query q of sequence b' is cu_rows[b'] + q instead of
+  // b' * n + q, queries >= kvlen[b'] do not exist (their blocks exit at once) — the reference's varlen path, modules.py:522-543.
+  const int32_t* cu_rows;
 };
 
 // NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
@@ -78,6 +81,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     kv_end = min(a.seg2_off + a.kvlen2[bp], n);
     if (hole_lo >= hole_hi) hole_lo = hole_hi = 0;
   }
+  const int q_end = a.cu_rows ? (a.kvlen ? min(a.kvlen[bp], n) : n) : n;  // queries of this sequence that exist
+  if (qb * (32 * NW) >= q_end) return;                                    // (whole workgroup: no barrier has been reached yet)
   const int ntile_all = (kv_end + KT - 1) / KT;
   // tiles [t0, t0 + ntile) of the key range belong to this workgroup
   const int t0 = SPLIT ? (int)((int64_t)ks * ntile_all / a.kv_split) : 0;
@@ -319,9 +324,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     }
     return;
   }
-  if (qrow < n) {
+  if (qrow < q_end) {
     const float inv = 1.0f / l_tot;
-    const int64_t orow = ((int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
+    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll

@@ -549,6 +549,31 @@ hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* d
   hipLaunchKernelGGL(split_f16_packed_kernel, dim3(grid_1d(rows * K)), dim3(256), 0, s, src, rows, K, dst);
   return hipGetLastError();
 }
+namespace {
+template <bool SCATTER>
+__global__ void move_rows_kernel(const float4* src, const int32_t* rowmap, int64_t rows, int C4, float4* dst) {
+  const int64_t total = rows * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C4;
+    const int c = (int)(i - r * C4);
+    const int64_t o = (int64_t)rowmap[r] * C4 + c;
+    if (SCATTER) dst[o] = src[i];
+    else dst[i] = src[o];
+  }
+}
+}  // namespace
+hipError_t launch_gather_rows(const float* src, const int32_t* rowmap, int64_t rows, int C, float* dst, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(move_rows_kernel<false>, dim3(grid_1d(rows * (C / 4))), dim3(256), 0, s, reinterpret_cast<const float4*>(src), rowmap, rows, C / 4,
+                     reinterpret_cast<float4*>(dst));
+  return hipGetLastError();
+}
+hipError_t launch_scatter_rows(const float* src, const int32_t* rowmap, int64_t rows, int C, float* dst, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(move_rows_kernel<true>, dim3(grid_1d(rows * (C / 4))), dim3(256), 0, s, reinterpret_cast<const float4*>(src), rowmap, rows, C / 4,
+                     reinterpret_cast<float4*>(dst));
+  return hipGetLastError();
+}
 hipError_t launch_condition_weight(const float* src, int rows, int K, float* scale, float* alpha, f16* hi, f16* pk, hipStream_t s) {
   if (K % 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(row_pow2_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, scale, alpha);

@@ -221,6 +221,13 @@ struct f5hip_ctx {
   // workspace (grow-only)
   int ws_B = 0, ws_n = 0;
   DevBuf tok, valid, textkeep, rowvalid, condmask, kvlen;
+  // option "packed_rows" (DiT backbone, flash attention, attn_mask_enabled): the block loop of a ragged batch runs over the VALID rows only.
+  // Row r of the packed order (sequence by sequence: cond 0 .. B-1, then uncond) is padded row rowmap[r] = token rowinfo[r] & 0xffff of
+  // sequence rowinfo[r] >> 16; sequence s starts at packed row cu_rows[s].  pk_rows = 0: the padded layout is in use.
+  int packed_opt = 0;
+  int64_t pk_rows = 0;
+  std::vector<int32_t> cu_host;
+  DevBuf rowmap, rowinfo, cu_rows, xpk, velpk;
   DevBuf tx, ta, th, tg, sumsq;
   DevBuf step_cond, cconst, y, h, c1, x;
   DevBuf a32, a_hi, o32, o_hi, f32, f_hi;  // *_hi: plain fp16 rows, or packed hi/lo rows (twice the size) in fp16x3 mode
@@ -246,6 +253,7 @@ struct f5hip_ctx {
   hipGraphExec_t graph_exec = nullptr;
   struct GraphKey {
     int B = 0, n = 0, nt = 0, steps = 0, prec = -1, use_mask = 0, method = 0;
+    int64_t pk_rows = 0, pk_cond = 0;  // packed rows in total / of the cond half (launch sizes of the captured loop)
     float* traj = nullptr;
     uint64_t ws_epoch = 0;
   } graph_key;

@@ -146,6 +146,10 @@ struct EpiQKVT {
   // offsets.  Same indices, same arithmetic on the values (tests/hipemu/qkv_index_check.cpp compares every store of both paths byte for
   // byte at the full sizes).  A compile-time choice: both paths inlined into one epilogue stopped the big tiles' epilogue loops from
   // unrolling (accumulators in scratch; caught by tests/test_isa_hazards.py).
+  // Packed rows (engine option "packed_rows"): row m of the GEMM is token (rowinfo[m] & 0xffff) of sequence (rowinfo[m] >> 16) instead of
+  // token m % nseq of sequence m / nseq — the block GEMMs then run over the VALID rows of a ragged batch only (null = padded layout).
+  const uint32_t* rowinfo;
+  int nslab;            // packed rows: number of sequences the q / k / V^T slabs hold (bounds of the pipelined kernel's buffer descriptors)
   int fast;             // set by epi_qkv_prepare (host bookkeeping; the kernels do not read it)
   int inner_;           // heads * dh
   int dh_shift;         // log2(dh)
@@ -204,14 +208,17 @@ struct EpiQKVT {
       const int which = (n >= inner_ ? 1 : 0) + (n >= 2 * inner_ ? 1 : 0);
       const int c = n - (which == 0 ? 0 : which == 1 ? inner_ : 2 * inner_);
       const int hh = c >> dh_shift, d = c & (dh - 1);
-      const int bp = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift), pos = m - bp * nseq;
+      int bp, pos;
+      if (rowinfo) { const uint32_t ri = rowinfo[m]; bp = (int)(ri >> 16); pos = (int)(ri & 0xffffu); }
+      else { bp = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift); pos = m - bp * nseq; }
       store(which, hh, d, bp, pos, x);
     } else {
       const int inner = heads * dh;
       const int which = n / inner;
       const int c = n - which * inner;
       const int hh = c / dh, d = c - hh * dh;
-      const int bp = m / nseq, pos = m - bp * nseq;
+      int bp = m / nseq, pos = m - bp * nseq;
+      if (rowinfo) { const uint32_t ri = rowinfo[m]; bp = (int)(ri >> 16); pos = (int)(ri & 0xffffu); }
       store(which, hh, d, bp, pos, x);
     }
   }
@@ -224,7 +231,7 @@ inline void epi_qkv_prepare(EpiQKV& e, int M) {
   e.fast = 0;
   const int dh = e.dh, nseq = e.nseq;
   if (dh < 2 || (dh & (dh - 1)) || nseq < 2 || M <= 0 || e.heads <= 0) return;
-  const int64_t bp_max = (M + nseq - 1) / nseq, sn = e.slab_n ? e.slab_n : nseq;
+  const int64_t bp_max = e.rowinfo ? e.nslab : (M + nseq - 1) / nseq, sn = e.slab_n ? e.slab_n : nseq;
   const int64_t lim = (int64_t)1 << 31;
   // largest offsets any store can form: the q / k slabs, the V^T slab (one row past the last channel for the e * ldvt steps), the rope table
   if (bp_max * e.heads * sn * dh >= lim || (bp_max * e.heads * dh + 4) * e.ldvt + sn + e.pos_off >= lim || (int64_t)nseq * dh >= lim) return;

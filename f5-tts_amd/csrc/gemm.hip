@@ -365,7 +365,8 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
     GemmCore g = g0;
     if (g.group_m == 0) g.group_m = g.M >= 8192 ? 4 : 1;
     const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true);
-    const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = (g.M + e.nseq - 1) / e.nseq;
+    // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
+    const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
     const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
     if (variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000) {
       PpEpiQKV p{};
@@ -373,7 +374,7 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
       p.q16 = e.q16; p.k16 = e.k16; p.vt16 = e.vt16; p.q16_lo = e.q16_lo; p.k16_lo = e.k16_lo; p.vt16_lo = e.vt16_lo;
       p.nseq = e.nseq; p.heads = e.heads; p.pe_heads = e.pe_heads; p.slab_n = e.slab_n; p.pos_off = e.pos_off; p.ldvt = (int)e.ldvt;
       p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
-      p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb;
+      p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb; p.rowinfo = e.rowinfo;
       const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
       if (r != PP_NOT_APPLICABLE) return r;
     }

@@ -234,6 +234,7 @@ struct PpEpiQKV {
   int nseq_shift, inner;
   int M, N;
   uint32_t qk_bytes, vt_bytes;  // sizes of the q / k planes and of the V^T planes in bytes (< 2^31)
+  const uint32_t* rowinfo;      // packed rows: (sequence << 16) | token of GEMM row m (EpiQKVT::rowinfo); null = m / nseq, m % nseq
 
   template <int TM, int TN>
   __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
@@ -243,10 +244,18 @@ struct PpEpiQKV {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m_w + 32 * j + r;
-      bp[j] = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift);
-      pos[j] = m - bp[j] * nseq;
+      if (rowinfo) {  // (rows >= M: any valid (sequence, token) will do, their stores are dropped)
+        const uint32_t ri = rowinfo[m < M ? m : M - 1];
+        bp[j] = (int)(ri >> 16);
+        pos[j] = (int)(ri & 0xffffu);
+      } else {
+        bp[j] = (int)((uint32_t)(((uint64_t)(uint32_t)m * nseq_magic) >> 32) >> nseq_shift);
+        pos[j] = m - bp[j] * nseq;
+      }
     }
-    const bool pair_ok = !(nseq & 1) && !(pos_off & 1);
+    // V^T pairs: lanes (2t, 2t + 1) must hold tokens (p, p + 1) of ONE sequence with p even — true for the padded layout with an even nseq,
+    // not for packed rows (a sequence may start at an odd row)
+    const bool pair_ok = !(nseq & 1) && !(pos_off & 1) && !rowinfo;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int nb = n_w + 32 * i;

@@ -72,6 +72,9 @@ hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s);
 // W [rows, K] fp32 -> per-row power-of-two scale (largest entry to [2^12, 2^13)) and its inverse, the plain fp16 copy hi [rows, K] and the
 // packed hi | lo copy pk [rows, 2K] of the scaled rows (GemmCore::w_alpha takes `alpha`)
+// dst[r, :] = src[rowmap[r], :] (gather) / dst[rowmap[r], :] = src[r, :] (scatter) over `rows` rows of C floats (C % 4 == 0)
+hipError_t launch_gather_rows(const float* src, const int32_t* rowmap, int64_t rows, int C, float* dst, hipStream_t s);
+hipError_t launch_scatter_rows(const float* src, const int32_t* rowmap, int64_t rows, int C, float* dst, hipStream_t s);
 hipError_t launch_condition_weight(const float* src, int rows, int K, float* scale, float* alpha, f16* hi, f16* pk, hipStream_t s);
 // conv_pos weights [D, cpg, K] -> per-tap operand layout [G][K][cpg(co)][cpg(ci)] (fp32 + f16 hi/lo)
 hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32, f16* whi, f16* wlo, hipStream_t s);
@@ -101,7 +104,8 @@ hipError_t init_attention_kernels();
 hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f16* k, const f16* k_lo, const f16* vt, const f16* vt_lo,
                              int ldv, int Bp, int heads, int n, const int32_t* kvlen, f16* o16, f16* o16_lo, hipStream_t s,
                              int o_packed = 0, const int32_t* kvlen2 = nullptr, int seg2_off = 0, int co_launches = 1, int kv_split = 1,
-                             float* part_o = nullptr, float* part_ml = nullptr, int log2q = 0);
+                             float* part_o = nullptr, float* part_ml = nullptr, int log2q = 0, const int32_t* cu_rows = nullptr);
+// cu_rows (with kvlen): packed output rows — row cu_rows[b'] + q for query q < kvlen[b'] of sequence b' (FlashArgs::cu_rows)
 // log2q = 1: q carries log2(e) on top of 1/sqrt(dh) (scores are base-2 logarithms; enables the lazy reference maximum, attention_kernel.h)
 // kv_split > 1: every query block is cut into kv_split workgroups over contiguous key ranges (small batches: more, shorter workgroups);
 // part_o [Bp*heads*n, kv_split, 64] / part_ml [Bp*heads*n, kv_split, 2] fp32 scratch for the unnormalised partial results

@@ -96,6 +96,9 @@ CASES = {
     # dynamic-range stress (synth.stress_dit_state_dict): per-tensor weight scales over three decades, outlier AdaLN channels, a clipped prompt
     "tiny_v1_stress": dict(preset="tiny", wseed=1, stress=True, loud=True, nw=256 * 60, wavseed=3, batch=1, nt=40, tseed=2, duration=200, lens=None,
                            kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    # a ragged batch of three with the key-padding mask (attn_mask_enabled): the case the packed-row path must reproduce on its valid rows
+    "tiny_mask_ragged_b3": dict(preset="tiny_mask", wseed=9, nw=256 * 60, wavseed=3, batch=3, nt=40, tseed=2, duration=[200, 163, 97], lens=[61, 50, 33],
+                                pad_from=30, kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
     "tiny_v1_b3_fixed": dict(preset="tiny", wseed=1, nw=256 * 30, wavseed=9, batch=3, nt=20, tseed=6, duration=96, lens=None,
                              kw=dict(steps=6, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
 }
@@ -105,6 +108,9 @@ FULL_CASES = {
                      kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     "small_e2": dict(preset="E2TTS_Small", wseed=0, nw=256 * 200, wavseed=0, batch=1, nt=80, tseed=0, duration=500, lens=None,
                      kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # the Small model with the key-padding mask on a ragged batch of four (lengths 500 / 431 / 333 / 250): packed rows at a real width
+    "small_mask_ragged_b4": dict(preset="F5TTS_v1_Small_mask", wseed=0, nw=256 * 200, wavseed=0, batch=4, nt=80, tseed=0, duration=[500, 431, 333, 250],
+                                 lens=[201, 160, 130, 101], pad_from=50, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[4] backbone at full size: E2-TTS Base (UNetT, depth 24, ff_mult 4), same prompt/duration as config 1
     "e2_base_cfg5": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),

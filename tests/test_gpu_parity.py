@@ -783,6 +783,57 @@ def test_vocos_head_against_the_reference_istft_head(name, vname, vseed, frames,
         eng.close()
 
 
+@pytest.mark.parametrize("branch_streams", [0, 1])
+def test_packed_rows_equal_the_padded_layout_on_the_valid_rows(engines, branch_streams):
+    """Option "packed_rows" (the reference's varlen path, modules.py:522-543, extended to the row-wise layers): a ragged batch with the
+    key-padding mask runs its block loop over the valid rows only.  The valid rows must come out as in the padded layout (same kernels, same
+    per-row arithmetic up to the tile choice) and inside the golden's tolerance; the padding is never read by the reference's callers (utils_eval / utils_infer
+    slice every utterance to its own length)."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    c = MG.CASES["tiny_mask_ragged_b3"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = engines(c["preset"], c["wseed"])
+    g = gold("tiny_mask_ragged_b3")["out"]
+    outs = {}
+    try:
+        eng.set_option("branch_streams", branch_streams)
+        for packed in (0, 1):
+            eng.set_option("packed_rows", packed)
+            for prec in ("fp16x3", "fp16"):
+                out, _ = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+                outs[(packed, prec)] = out.cpu()
+    finally:
+        eng.set_option("packed_rows", 0)
+        eng.set_option("branch_streams", -1)
+    # the row counts differ, so the launch heuristic may pick other tiles (k-split tiles sum in another order): equal up to that rounding
+    for prec, tol, same in (("fp16x3", X3TOL, 1e-4), ("fp16", 2e-2, 1e-2)):
+        for b, d in enumerate(duration.tolist()):
+            a_, p_ = outs[(0, prec)][b, :d], outs[(1, prec)][b, :d]
+            assert maxerr(a_, p_) < same, f"{prec} row {b}: packed differs from padded by {maxerr(a_, p_):.2e}"
+            assert maxerr(p_, g[b, :d]) < tol
+
+
+def test_packed_rows_small_model_golden():
+    """The Small model (dim 768, 18 blocks) with the key-padding mask on a ragged batch of four (500 / 431 / 333 / 250 frames), packed rows
+    against the reference-minted golden on every valid row; 24 % of the padded layout's rows are padding."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["small_mask_ragged_b4"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(MG.case_weights(c))
+    g = gold("small_mask_ragged_b4")["out"]
+    try:
+        eng.set_option("packed_rows", 1)
+        out, _ = F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+        e = max(maxerr(out[b, :d], g[b, :d]) for b, d in enumerate(duration.tolist()))
+        print(f"small model, ragged batch of 4, packed rows, fp16x3: max-abs over the valid rows {e:.2e}")
+        assert e < MEL_TOL
+    finally:
+        eng.close()
+
+
 def test_configs2_shaped_batch_golden():
     """BASELINE.json configs[2] / [3] shape (a batch of fixed-length prompts through the packed cond | uncond schedule, NFE 32) at the full
     model size: 4 distinct utterances against the golden minted by the reference's own CFM.sample (oracle/make_golden.py base_v1_cfg3_b4),

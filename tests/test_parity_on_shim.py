@@ -91,6 +91,11 @@ def test_gpu_suite_function_on_the_shim(shim_engines, fn):
     getattr(G, fn)(shim_engines)
 
 
+@pytest.mark.parametrize("branch_streams", [0, 1])
+def test_packed_rows_on_the_shim(shim_engines, branch_streams):
+    G.test_packed_rows_equal_the_padded_layout_on_the_valid_rows(shim_engines, branch_streams)
+
+
 @pytest.mark.parametrize("nw", [513, 256 * 20 + 255])
 def test_mel_edge_lengths_on_the_shim(shim_engines, nw):
     G.test_mel_edge_lengths(shim_engines, nw)

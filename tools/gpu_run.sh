@@ -1,0 +1,129 @@
+#!/bin/bash
+# tools/gpu_run.sh — the ONE script behind every GPU measurement of this repo.  Run on the GPU box through gpurun:
+#
+#     gpurun --timeout 1800 -- 'bash tools/gpu_run.sh <recipe> [args...]'
+#
+# Every recipe writes under gpurun_out/<tag>/ (merged back by gpurun); what is kept as evidence is copied to profiles/ by hand, named per
+# round (profiles/README.md says which recipe produced which file).  Rounds 1-2 used one throw-away script per call (tools/r2_call*.sh,
+# removed in round 3: `git show 6c9c0d8:tools/r2_call7.sh` still shows any of them).
+#
+#   tests [pytest args]                 the GPU suite (default: tests -m gpu)
+#   bench <tag> [bench.py args]         one bench.py line -> gpurun_out/<tag>/bench.json, summary on stdout
+#   evidence <tag>                      the round-end set: GPU suite, smoke, headline bench lines, rocprofv3 kernel-trace summaries,
+#                                       PMC passes (B = 1 at NFE 16, B = 32 at NFE 2), microbenchmark tables, golden precision sweep
+#   pmc <tag> [bench.py args]           FETCH / WRITE / MFMA-busy counter passes + a kernel-trace pass of one bench.py command
+#   tiles <tag> <M,N,K;..> <variants> [epilogue] [precisions]    tools/kernel_bench.py gemm over shapes x tile ids
+#   qkv <tag> <variants> <seqs nseq>..  the fused q|k|v projection: time + value check against the generic kernel
+#   attn <tag>                          flash attention microbenchmark: exact running maximum vs lazy reference maximum
+#   race <tag> <seqs> <nseq> <reps> <specs>    csrc/race_probe.hip through tools/kernel_bench.py qkvprobe (+ tools/race_dump_analyze.py on
+#                                       every non-empty dump); specs = "tile,expt[,abl[,lds_pad[,noise]]];..."
+#   pkprobe <tag>                       tools/probes/pk_opsel_probe (the standalone reproducer of the packed-fp32 operand fault) and
+#                                       tools/probes/pk_opsel_sweep (every operand selection), with and without partner waves
+#   ragged <tag> [frame budgets]        48 ragged synthetic utterances: bucketed / list order padded / list order packed rows
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+recipe=${1:?recipe}; shift
+cd "$R"
+
+line() {  # one-line summary of a bench.py JSON file
+  python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d.get("roofline", {})
+    print(sys.argv[2], "ms/step", round(d["ms_per_step"], 2), "value", round(d["value"]), "roofline.frac", r.get("frac") and round(r["frac"], 4), "traffic", r.get("traffic"),
+          {k: round(v, 1) for k, v in d.get("kernel_classes_ms", {}).items() if v > 1})
+except Exception as e:
+    print(sys.argv[2], "ERR", e)
+PY
+}
+
+trace() {  # rocprofv3 kernel-trace summary of a bench.py command -> $1/kernel_stats_$2.md
+  local out=$1 tag=$2; shift 2
+  local d=$out/trace_$tag; mkdir -p $d
+  (cd /tmp && TMPDIR=/tmp timeout 1200 rocprofv3 --kernel-trace --stats -d $d -o trace -- python $R/bench.py "$@" --no-cpu-baseline > $d/bench.log 2>&1)
+  local db; db=$(find $d -name "*.db" | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/kernel_stats_$tag.md 2>&1
+  rm -rf $d
+  head -12 $out/kernel_stats_$tag.md | cut -c1-170
+}
+
+pmc() {  # counter passes (separate runs: counters only, never with tracing) + an un-instrumented kernel-trace pass for the durations
+  local out=$1 tag=$2; shift 2
+  local d=$out/pmc_$tag; mkdir -p $d
+  local common="--steps 1 --warmup 0 --no-cpu-baseline --no-graph"
+  ( cd /tmp; export TMPDIR=/tmp
+    timeout 1500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -o fetch -- python $R/bench.py "$@" $common > $d/fetch.log 2>&1
+    timeout 1500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -o write -- python $R/bench.py "$@" $common > $d/write.log 2>&1
+    timeout 1500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $d/mfma -o mfma -- python $R/bench.py "$@" $common > $d/mfma.log 2>&1
+    timeout 1500 rocprofv3 --kernel-trace --output-format csv -d $d/trace -o trace -- python $R/bench.py "$@" $common > $d/trace.log 2>&1 )
+  python tools/pmc_summarize.py $d "$@" > $out/pmc_$tag.json
+  rm -rf $d
+  head -c 1500 $out/pmc_$tag.json
+}
+
+case $recipe in
+tests)
+  timeout 1800 python -m pytest ${@:-tests -q -m gpu} 2>&1 | tail -5 ;;
+bench)
+  tag=${1:?tag}; shift; out=gpurun_out/$tag; mkdir -p $out
+  timeout 1500 python bench.py "$@" > $out/bench.json 2> $out/bench.err; line $out/bench.json "$tag" ;;
+pmc)
+  tag=${1:?tag}; shift; out=gpurun_out/$tag; mkdir -p $out; pmc $out $tag "$@" ;;
+evidence)
+  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
+  timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $out/gpu_tests.log; cat $out/gpu_tests.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/smoke.log
+  timeout 900 python bench.py --steps 10 --warmup 3 > $out/bench_b1.json 2> $out/bench_b1.err
+  timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16 --no-cpu-baseline > $out/bench_b1_fp16.json 2> /dev/null
+  timeout 600 python bench.py --steps 3 --warmup 1 --batch 4 --nfe 32 --no-cpu-baseline > $out/bench_b4_nfe32.json 2> /dev/null
+  timeout 600 python bench.py --steps 3 --warmup 1 --batch 8 --no-cpu-baseline > $out/bench_b8.json 2> /dev/null
+  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --no-cpu-baseline > $out/bench_b32_nfe32.json 2> /dev/null
+  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --precision fp16 --no-cpu-baseline > $out/bench_b32_nfe32_fp16.json 2> /dev/null
+  timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_e2_b8_bigvgan.json 2> /dev/null
+  for f in $out/bench_*.json; do line $f $(basename $f .json); done
+  trace $out b1 --steps 3 --warmup 1
+  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32
+  pmc $out fp16x3_b1 --batch 1 --nfe 16
+  pmc $out fp16x3_b32 --batch 32 --nfe 2
+  B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048;1406,2048,1024;1406,1024,2048"
+  MID="5624,2048,1024;11248,2048,1024;11248,1024,2048;22496,1024,1024;89984,2048,1024;89984,1024,2048"
+  { for epi in 1 2; do KB_SHAPES=$B1 KB_PRECS=fp16x3 KB_EPI=$epi KB_VARIANTS=-1,1,55,56,59,66,68,69 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-330; done
+    for epi in 1 2; do KB_SHAPES=$MID KB_PRECS=fp16x3,fp16 KB_EPI=$epi KB_VARIANTS=-1,50,51,58,61,62,63 timeout 400 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-330; done
+    for sq in "2 1406" "8 1406" "64 1406"; do timeout 300 python tools/kernel_bench.py qkv fp16x3 $sq -1,50,55,61,62,68 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done
+    timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn
+    KB_ATTN_LOG2Q=1 timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn | sed "s/^/lazy /"; } > $out/kernel_bench.log 2>&1
+  tail -12 $out/kernel_bench.log | cut -c1-200
+  [ -x tools/probes/hipblaslt_ref ] && timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
+  timeout 900 python tools/attn_precision_check.py > $out/attn_precision.log 2>&1; tail -6 $out/attn_precision.log ;;
+tiles)
+  tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
+  KB_SHAPES=${2:?shapes} KB_VARIANTS=${3:?variants} KB_EPI=${4:-1} KB_PRECS=${5:-fp16x3} timeout 900 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | cut -c1-340 | tee $out/tiles.log ;;
+qkv)
+  tag=${1:?tag}; variants=${2:?variants}; shift 2; out=gpurun_out/$tag; mkdir -p $out
+  for sq in "$@"; do timeout 600 python tools/kernel_bench.py qkv fp16x3 $sq $variants 20 2>&1 | grep -E "^qkv|QKV_CHECK"; done | tee $out/qkv.log ;;
+attn)
+  tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
+  { echo "== exact running maximum"; timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn
+    echo "== lazy reference maximum (KB_ATTN_LOG2Q=1)"; KB_ATTN_LOG2Q=1 timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn; } | tee $out/attn_ab.log ;;
+race)
+  tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
+  KB_PROBE_DUMP=$R/$out/dump timeout 900 python tools/kernel_bench.py qkvprobe ${2:?seqs} ${3:?nseq} ${4:?reps} "${5:?specs}" 2>&1 | grep -E "qkvprobe|QKV_PROBE|rror" | tee $out/probe.log
+  for f in $out/dump.*.bin; do [ -s $f ] && [ $(stat -c %s $f) -lt 4000000 ] && python tools/race_dump_analyze.py $f $2 $3 16 > ${f%.bin}.txt 2>&1; done
+  rm -f $out/*.bin; head -c 2500 $(ls $out/dump.*.txt 2>/dev/null | head -1) 2>/dev/null ;;
+pkprobe)
+  tag=${1:?tag}; out=$R/gpurun_out/$tag; mkdir -p $out; cd tools/probes
+  for b in pk_opsel_probe pk_opsel_sweep; do [ -x $b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $b $b.hip 2> /dev/null; done
+  { for m in 0 1 4 5 13; do timeout 120 ./pk_opsel_probe 2 $m 20000 | tail -1; done; } > $out/pk_probe.log 2>&1
+  timeout 600 ./pk_opsel_sweep 4000 1 > $out/sweep_partners.log 2>&1; timeout 600 ./pk_opsel_sweep 4000 0 > $out/sweep_alone.log 2>&1
+  cat $out/pk_probe.log; grep -E "FAILS|forms fail" $out/sweep_partners.log | cut -c1-160; tail -1 $out/sweep_alone.log ;;
+ragged)
+  tag=${1:?tag}; shift; out=gpurun_out/$tag; mkdir -p $out
+  for fpb in ${@:-6000 24000}; do
+    echo "== frame budget $fpb: 200 length classes (the reference's bucketing)"; timeout 900 python tools/infer_batch.py --synthetic 48 --frames-per-batch $fpb --attn-mask --out /tmp/o1 2>&1 | tail -2
+    echo "== frame budget $fpb: one class (list order), padded layout"; timeout 900 python tools/infer_batch.py --synthetic 48 --frames-per-batch $fpb --attn-mask --num-buckets 1 --out /tmp/o2 2>&1 | tail -2
+    echo "== frame budget $fpb: one class (list order), packed rows"; timeout 900 python tools/infer_batch.py --synthetic 48 --frames-per-batch $fpb --attn-mask --num-buckets 1 --packed --out /tmp/o3 2>&1 | tail -2
+  done | tee $out/packed_ragged.log ;;
+*)
+  echo "unknown recipe $recipe" >&2; exit 2 ;;
+esac

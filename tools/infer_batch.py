@@ -53,6 +53,11 @@ def main():
                          "infer_process applies; ASCII text only here, the Chinese G2P packages are absent), 'char' = the characters as they are. "
                          "Default: pinyin when --vocab is given (the reference's eval_infer_batch.py takes the tokenizer from the model config), "
                          "char for the built-in ASCII smoke vocabulary")
+    ap.add_argument("--num-buckets", type=int, default=200, help="length classes of the batch formation (eval/utils_eval.py:72 default 200; 1 = no "
+                    "bucketing: batches in list order, as a server without a choice of batches would see them)")
+    ap.add_argument("--attn-mask", action="store_true", help="attn_mask_enabled=True (the model must have been trained with it; the presets ship False): "
+                    "padded keys are masked out of the attention — the precondition of --packed")
+    ap.add_argument("--packed", action="store_true", help="engine option packed_rows: the block loop runs over the valid rows of a ragged batch only")
     ap.add_argument("--min-secs", type=int, default=3, help="shortest total length the length classes cover (eval/utils_eval.py:72 default)")
     ap.add_argument("--max-secs", type=int, default=40, help="longest total length the length classes cover (eval/utils_eval.py:72 default)")
     a = ap.parse_args()
@@ -71,6 +76,9 @@ def main():
         vocab, vsize = I.get_tokenizer(a.vocab)
         from dataclasses import replace
         cfg = replace(cfg, text_num_embeds=vsize)
+    if a.attn_mask:
+        from dataclasses import replace as _replace
+        cfg = _replace(cfg, attn_mask_enabled=True)
     if vocab is None:  # smoke / throughput runs without a vocab.txt: printable ASCII, id 0 = space (the reference's unknown id)
         vocab = {" ": 0, **{chr(c): c - 32 for c in range(33, 127)}}
     eng = F5HipEngine(cfg, vcfg, device=dev)
@@ -86,6 +94,8 @@ def main():
         eng.load_state_dict({**sd, **vsd}, strict=False, finalize=False)
     fdist.broadcast_engine_weights(eng, src=0)
     model, voc = F5HipCFM(eng, vocab_char_map=vocab, precision=a.precision), F5HipVocos(eng)
+    if a.packed:
+        eng.set_option("packed_rows", 1)
 
     if a.synthetic:
         utts = [(f"syn{i:04d}", (synth.synth_wave(24000 * (3 + i % 4), seed=i), 24000), "some call me nature, others call me mother nature.",
@@ -113,7 +123,7 @@ def main():
         meta = [(uid, ref_text, ref, gen_text, "") for uid, ref, ref_text, gen_text in utts]
         # same tokens as the one-by-one mode below (infer_process -> convert_char_to_pinyin) and the reference's bucket range unless asked otherwise
         batches = EB.get_inference_prompt(meta, lambda w: model.mel_spec(w.to(dev)).cpu(), tokenizer=a.tokenizer, infer_batch_size=a.frames_per_batch,
-                                          min_secs=a.min_secs, max_secs=a.max_secs, load_audio=load_audio)
+                                          min_secs=a.min_secs, max_secs=a.max_secs, num_buckets=a.num_buckets, load_audio=load_audio)
         mine = EB.deal_batches(batches, world)[rank]
         if rank == 0:
             print(f"{len(batches)} batches of <= {max(len(b[0]) for b in batches)} utterances, padding {100 * EB.padding_fraction(batches):.1f} % of the rows")
