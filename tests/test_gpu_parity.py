@@ -784,7 +784,7 @@ def test_vocos_head_against_the_reference_istft_head(name, vname, vseed, frames,
 
 
 @pytest.mark.parametrize("branch_streams", [0, 1])
-def test_packed_rows_equal_the_padded_layout_on_the_valid_rows(engines, branch_streams):
+def test_packed_rows_equal_the_padded_layout_on_the_valid_rows(engines, branch_streams, precisions=("fp16x3", "fp16")):
     """Option "packed_rows" (the reference's varlen path, modules.py:522-543, extended to the row-wise layers): a ragged batch with the
     key-padding mask runs its block loop over the valid rows only.  The valid rows must come out as in the padded layout (same kernels, same
     per-row arithmetic up to the tile choice) and inside the golden's tolerance; the padding is never read by the reference's callers (utils_eval / utils_infer
@@ -800,7 +800,7 @@ def test_packed_rows_equal_the_padded_layout_on_the_valid_rows(engines, branch_s
         eng.set_option("branch_streams", branch_streams)
         for packed in (0, 1):
             eng.set_option("packed_rows", packed)
-            for prec in ("fp16x3", "fp16"):
+            for prec in precisions:
                 out, _ = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
                 outs[(packed, prec)] = out.cpu()
     finally:
@@ -808,6 +808,8 @@ def test_packed_rows_equal_the_padded_layout_on_the_valid_rows(engines, branch_s
         eng.set_option("branch_streams", -1)
     # the row counts differ, so the launch heuristic may pick other tiles (k-split tiles sum in another order): equal up to that rounding
     for prec, tol, same in (("fp16x3", X3TOL, 1e-4), ("fp16", 2e-2, 1e-2)):
+        if prec not in precisions:
+            continue
         for b, d in enumerate(duration.tolist()):
             a_, p_ = outs[(0, prec)][b, :d], outs[(1, prec)][b, :d]
             assert maxerr(a_, p_) < same, f"{prec} row {b}: packed differs from padded by {maxerr(a_, p_):.2e}"
