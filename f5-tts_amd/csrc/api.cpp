@@ -1529,10 +1529,11 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Two chains against one, measured with the round-2 tiles at N = 1406 (same box, tools/r2_call23.sh / r2_call24.sh; ms per step):
   //   B = 1: 85.1 / 84.4 (the one-round tiles of a 2812-row launch win)   B = 2: 138 / 156   B = 3: 206 / 251   B = 4: 258 / 284
   //   B = 6: 376 / 432   B = 8: 254 / 269 (NFE 8)   B = 12: 390 / 406   B = 16: 522 / 497   B = 24: 779 / 752   B = 32: 960 / 978
-  // i.e. two chains wherever the second chain fills the partial rounds of the 192- and 256-row tilings (4k .. 40k rows), and again once
-  // each chain alone is in the 256x256 regime.
+  // Round 3, with the two-workgroups-per-CU tiles at 4k .. 40k rows (NFE 8, same box, profiles/r03g_chains.log; one chain / two chains):
+  //   B = 2: 71.1 / 70.8   B = 3: 108.6 / 96.4   B = 4: 130.4 / 125.5   B = 6: 194.9 / 182.4   B = 8: 249.6 / 243.8   B = 12: 370.4 / 369.3
+  //   B = 16: 488.7 / 489.8   B = 24: 740.5 / 729.8 — two chains are never worse any more, so: two chains from B = 2 on.
   const int64_t rows1 = (int64_t)B * n;  // rows of one chain
-  const bool auto_split = (rows1 >= 2048 && rows1 <= 17500) || rows1 >= 40000;
+  const bool auto_split = rows1 >= 2048;
   const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && auto_split));
   if (split && !ctx->side_stream) {
     HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));

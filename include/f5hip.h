@@ -238,6 +238,11 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel
  * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
+ * "packed_rows" (0 off (default) / 1: a ragged batch — use_mask with durations below n — of a DiT with attn_mask_enabled runs its block
+ * loop over the VALID rows only: the reference's varlen attention path, model/modules.py:522-543, extended to the row-wise layers.  Rows past a
+ * sequence's duration then keep the prompt / zero state instead of the values the padded layout would compute for them; the reference's
+ * callers slice every utterance to its own length, utils_infer.py:507, eval_infer_batch.py:199.  Ignored where it cannot apply: key mask
+ * off, qk_norm, long skip, UNetT / MMDiT, the materialised fp32 attention),
  * "attn_kv_split" (1 off (default) / 2..8: flash attention with every query block cut into that many key ranges + a merge kernel —
  * shorter workgroups for small batches, csrc/attention_kernel.h). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
