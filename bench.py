@@ -167,7 +167,7 @@ def kernel_source_hash():
 
 def pmc_traffic(a, B):
     """HBM bytes per launch of the dominant kernel from a rocprofv3 PMC pass of this workload (profiles/*pmc*.json, written by
-    tools/pmc_bench.sh), quoted ONLY if that pass ran the same kernel sources (`kernel_source_hash`); else null."""
+    `tools/gpu_run.sh pmc`), quoted ONLY if that pass ran the same kernel sources (`kernel_source_hash`); else null."""
     import glob
 
     want = kernel_source_hash()
@@ -177,7 +177,7 @@ def pmc_traffic(a, B):
         except Exception:
             continue
         # bytes per launch do not depend on the number of ODE steps: a pass at a smaller NFE counts (B = 32 at NFE 32 does not finish a
-        # counter pass in the GPU time a round has; tools/pmc_bench.sh runs it at NFE 2)
+        # counter pass in the GPU time a round has; `tools/gpu_run.sh counters` runs it at NFE 2)
         if (d.get("precision") == a.precision and d.get("batch") == B and d.get("model") == a.model and d.get("kernel_source_hash") == want):
             return d.get("hbm_bytes_per_launch"), os.path.basename(f) + ("" if d.get("nfe") == a.nfe else f" (counter pass at NFE {d.get('nfe')})")
     return None, None

@@ -11,6 +11,7 @@
 #   bench <tag> [bench.py args]         one bench.py line -> gpurun_out/<tag>/bench.json, summary on stdout
 #   evidence <tag>                      the round-end set: GPU suite, smoke, headline bench lines, rocprofv3 kernel-trace summaries,
 #                                       PMC passes (B = 1 at NFE 16, B = 32 at NFE 2), microbenchmark tables, golden precision sweep
+#   counters <tag>                      the rocprofv3 half of `evidence` alone
 #   pmc <tag> [bench.py args]           FETCH / WRITE / MFMA-busy counter passes + a kernel-trace pass of one bench.py command
 #   tiles <tag> <M,N,K;..> <variants> [epilogue] [precisions]    tools/kernel_bench.py gemm over shapes x tile ids
 #   qkv <tag> <variants> <seqs nseq>..  the fused q|k|v projection: time + value check against the generic kernel
@@ -40,7 +41,7 @@ PY
 
 trace() {  # rocprofv3 kernel-trace summary of a bench.py command -> $1/kernel_stats_$2.md
   local out=$1 tag=$2; shift 2
-  local d=$out/trace_$tag; mkdir -p $d
+  local d=$R/$out/trace_$tag; mkdir -p $d
   (cd /tmp && TMPDIR=/tmp timeout 1200 rocprofv3 --kernel-trace --stats -d $d -o trace -- python $R/bench.py "$@" --no-cpu-baseline > $d/bench.log 2>&1)
   local db; db=$(find $d -name "*.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $out/kernel_stats_$tag.md 2>&1
@@ -50,7 +51,7 @@ trace() {  # rocprofv3 kernel-trace summary of a bench.py command -> $1/kernel_s
 
 pmc() {  # counter passes (separate runs: counters only, never with tracing) + an un-instrumented kernel-trace pass for the durations
   local out=$1 tag=$2; shift 2
-  local d=$out/pmc_$tag; mkdir -p $d
+  local d=$R/$out/pmc_$tag; mkdir -p $d
   local common="--steps 1 --warmup 0 --no-cpu-baseline --no-graph"
   ( cd /tmp; export TMPDIR=/tmp
     timeout 1500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -o fetch -- python $R/bench.py "$@" $common > $d/fetch.log 2>&1
@@ -96,6 +97,12 @@ evidence)
   tail -12 $out/kernel_bench.log | cut -c1-200
   [ -x tools/probes/hipblaslt_ref ] && timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
   timeout 900 python tools/attn_precision_check.py > $out/attn_precision.log 2>&1; tail -6 $out/attn_precision.log ;;
+counters)  # the rocprofv3 half of `evidence` alone (kernel-trace summaries + PMC passes)
+  tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
+  trace $out b1 --steps 3 --warmup 1
+  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32
+  pmc $out fp16x3_b1 --batch 1 --nfe 16
+  pmc $out fp16x3_b32 --batch 32 --nfe 2 ;;
 tiles)
   tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
   KB_SHAPES=${2:?shapes} KB_VARIANTS=${3:?variants} KB_EPI=${4:-1} KB_PRECS=${5:-fp16x3} timeout 900 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | cut -c1-340 | tee $out/tiles.log ;;
