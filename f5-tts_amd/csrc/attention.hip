@@ -46,6 +46,21 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   // lazy reference maximum (attention_kernel.h LAZY): whenever q carries log2(e); F5HIP_ATTN_LAZY=0 keeps the exact running maximum (A/B)
   static const bool lazy_off = [] { const char* v = getenv("F5HIP_ATTN_LAZY"); return v && atoi(v) == 0; }();
   const bool lazy = a.log2q && !lazy_off;
+  // software-pipelined form of the plain-fp16 lazy configuration (attention_kernel.h flash_pipe_kernel) for the one-round 192-row launch,
+  // where SIMDs hold one or two waves and a wave's own phases are all the overlap there is: 32.8 -> 31.8 us at B' = 2 (12.8 against 13.4 ms
+  // per B = 1 sample); with two workgroups per CU it ties or loses (B' = 16: 197.9 against 192.0 us, B' = 64: 829 against 825), so the
+  // 128-row launches keep the phase-by-phase kernel.  F5HIP_ATTN_PIPE=0 / 1: never / also for the 128-row blocks (A/B).
+  static const int pipe_env = [] { const char* v = getenv("F5HIP_ATTN_PIPE"); return v ? atoi(v) : -1; }();
+  if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
+    if (lazy && pipe_env != 0 && (six || pipe_env == 1)) {
+      a.nqb = six ? nqb6 : nqb4; a.nwg = bh * a.nqb;
+      if (six) { if (vsum) hipLaunchKernelGGL((flash_pipe_kernel<6, true>), dim3(a.nwg), dim3(384), lds, s, a);
+                 else hipLaunchKernelGGL((flash_pipe_kernel<6, false>), dim3(a.nwg), dim3(384), lds, s, a); }
+      else { if (vsum) hipLaunchKernelGGL((flash_pipe_kernel<4, true>), dim3(a.nwg), dim3(256), lds, s, a);
+             else hipLaunchKernelGGL((flash_pipe_kernel<4, false>), dim3(a.nwg), dim3(256), lds, s, a); }
+      return hipGetLastError();
+    }
+  }
 #define F5_FLASH(NWV, VS, LZ, THREADS) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, NWV, false, VS, LZ>), dim3(a.nwg), dim3(THREADS), lds, s, a)
   if (six) {
     a.nqb = nqb6; a.nwg = bh * nqb6;
@@ -85,8 +100,16 @@ hipError_t set_attr() {  // every instantiation launch() can pick
 
 bool flash_attn_available() { return true; }
 
+template <int NW, bool VS>
+hipError_t set_attr_pipe() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(flash_pipe_kernel<NW, VS>), hipFuncAttributeMaxDynamicSharedMemorySize, flash_lds_bytes<1, 1>());
+}
+
 hipError_t init_attention_kernels() {
   hipError_t e;
+  if ((e = set_attr_pipe<4, false>()) != hipSuccess || (e = set_attr_pipe<4, true>()) != hipSuccess || (e = set_attr_pipe<6, false>()) != hipSuccess ||
+      (e = set_attr_pipe<6, true>()) != hipSuccess)
+    return e;
   if ((e = set_attr<1, 1>()) != hipSuccess) return e;
   if ((e = set_attr<3, 1>()) != hipSuccess) return e;
   return set_attr<3, 3>();

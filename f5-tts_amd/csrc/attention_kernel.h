@@ -347,6 +347,264 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   }
 }
 
+// ---- LDS fragment reads with hand-placed waits (flash_pipe_kernel) -------------------------------------------------------------------
+// hipcc issues a fragment read right before the MFMA that consumes it, so every MFMA pair waits out an LDS round trip (~100+ cycles under
+// load).  As in gemm_pp.h the reads are inline asm — issued where the source says, early — and each wait names the registers it guards (an
+// in/out operand), so their consumers cannot be scheduled above it.  LDS operations of one wave complete in order: lgkmcnt(N) = all but the
+// N youngest have landed.  Under the host shim these are plain memory reads.
+namespace fa {
+#ifdef F5_HIPEMU
+inline uint32_t lds_addr(const char* p) { return (uint32_t)(p - hipemu::dyn_lds()); }
+template <int OFF>
+inline void read_b128(Frag& f, uint32_t addr) { memcpy(&f, hipemu::dyn_lds() + addr + OFF, 16); }
+template <int OFF>
+inline void read_2b64(Frag& f, uint32_t addr) {  // 8 bytes at OFF and 8 bytes at OFF + 16
+  memcpy(&f, hipemu::dyn_lds() + addr + OFF, 8);
+  memcpy(reinterpret_cast<char*>(&f) + 8, hipemu::dyn_lds() + addr + OFF + 16, 8);
+}
+template <int N>
+inline void landed(Frag&, Frag&) {}
+template <int N>
+inline void landed(Frag (&)[8]) {}
+#else
+__device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+template <int OFF>
+__device__ __forceinline__ void read_b128(Frag& f, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.f) : "v"(addr), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void read_2b64(Frag& f, uint32_t addr) {
+  static_assert(OFF % 8 == 0 && OFF / 8 + 2 < 256, "ds_read2_b64 offsets are 8-bit counts of 8 bytes");
+  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(f.f) : "v"(addr), "n"(OFF / 8), "n"(OFF / 8 + 2));
+}
+template <int N>
+__device__ __forceinline__ void landed(Frag& a, Frag& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.f), "+v"(b.f) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void landed(Frag (&k)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(k[0].f), "+v"(k[1].f), "+v"(k[2].f), "+v"(k[3].f), "+v"(k[4].f), "+v"(k[5].f), "+v"(k[6].f), "+v"(k[7].f) : "n"(N));
+}
+#endif
+}  // namespace fa
+
+// Software-pipelined form of the production configuration (round 3): plain fp16 q, k, P, V; base-2 scores (log2q); lazy reference maximum;
+// unsplit keys.  In flash_attn_kernel a tile is three DEPENDENT phases per wave — score MFMAs, softmax VALU, PV MFMAs — so a wave alone on
+// its SIMD (B = 1: 6 waves on 4 SIMDs) leaves the matrix pipe idle during the exponentials and the VALU idle during the products, and two
+// waves only overlap as far as their phases happen to differ.  Here the scores of tile t + 1 are issued INSIDE the softmax of tile t: one
+// score MFMA (32 cycles of the matrix pipe), then four exponentials + their fp16 conversions (VALU, independent of that MFMA), eight times.
+// LDS staging is skewed to match: ring slot j ("bundle j") holds the K tile j + 1 and the V^T tile j, so an iteration still reads one slot
+// and fills the other; the prologue brings K tile 0 alone.  Same arithmetic as flash_attn_kernel<1, 1, NW, false, VSUM, true> except for
+// the one extra (discarded) score tile past the end.
+// Measured (profiles/r03j_attn_pipe_ab.log): the overlap alone changed nothing (32.6 -> 32.9 us at B' = 2), the early fragment reads on top
+// of it -3 % there and nothing with two workgroups per CU: neither a wave's phase order nor its LDS round trips is what the ~80 cycles
+// per MFMA slot of this kernel are spent on.  The launcher uses this form for the one-round 192-row launch only.
+template <int NW, bool VSUM>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(FlashArgs a) {
+  constexpr int STAGE = K_PLANE + V_PLANE;
+  F5_DYN_LDS(char, smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, ql = lane & 31;
+  const int bid = blockIdx.x;  // XCD-aware placement as flash_attn_kernel
+  const int q8 = a.nwg >> 3, r8 = a.nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int bh = L / a.nqb, qb = L - bh * a.nqb;
+  const int bp = bh / a.heads, hh = bh - bp * a.heads;
+  const int n = a.n;
+  int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n, hole_lo = 0, hole_hi = 0;
+  if (a.kvlen && a.kvlen2) {
+    hole_lo = kv_end;
+    hole_hi = min(a.seg2_off, n);
+    kv_end = min(a.seg2_off + a.kvlen2[bp], n);
+    if (hole_lo >= hole_hi) hole_lo = hole_hi = 0;
+  }
+  const int q_end = a.cu_rows ? (a.kvlen ? min(a.kvlen[bp], n) : n) : n;
+  if (qb * (32 * NW) >= q_end) return;
+  const int ntile = (kv_end + KT - 1) / KT;
+
+  const uint32_t k_bytes = (uint32_t)n * 128u, v_bytes = (uint32_t)(64 * a.ldv) * 2u;
+  const BufRsrc Kr = make_rsrc(a.k + (int64_t)bh * n * 64, k_bytes);
+  const BufRsrc Vr = make_rsrc(a.vt + (int64_t)bh * 64 * a.ldv, v_bytes);
+  const f16* Qp = a.q + (int64_t)bh * n * 64;
+  const int qrow = qb * (32 * NW) + wave * 32 + ql;
+  Frag fq[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    fq[ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+
+  uint32_t k_off[2], v_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256, row = c >> 3, col = c & 7;
+    k_off[i] = (uint32_t)(row * 128 + col * 16);
+    v_off[i] = (uint32_t)(row * a.ldv * 2 + col * 16);
+  }
+  uint4 rk0[2], rv0[2], rk1[2], rv1[2];
+  auto load_bundle = [&](int j, uint4 (&rk)[2], uint4 (&rv)[2]) {  // K tile j + 1 and V^T tile j (j = -1: K tile 0 alone)
+    if (NW > 4 && wave >= 4) return;
+    const uint32_t keyk = (uint32_t)(j + 1) * KT, keyv = (uint32_t)(j < 0 ? 0 : j) * KT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t vkey_off = keyv * 2 + (uint32_t)((tid + i * 256) & 7) * 16;
+      const uint32_t voff = (j >= 0 && vkey_off < (uint32_t)a.ldv * 2) ? v_off[i] + keyv * 2 : OOB_OFF;
+      rk[i] = buffer_load_b128(Kr, k_off[i] + keyk * 128);  // past the last key: zeros (descriptor bounds)
+      rv[i] = buffer_load_b128(Vr, voff);
+    }
+  };
+  auto store_lds = [&](int stage, const uint4 (&rk)[2], const uint4 (&rv)[2]) {
+    if (NW > 4 && wave >= 4) return;
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, col = c & 7;
+      *reinterpret_cast<uint4*>(base + row * K_ROWB + col * 16) = rk[i];
+      char* vd = base + K_PLANE + row * V_ROWB + col * 16;
+      *reinterpret_cast<uint2*>(vd) = make_uint2(rv[i].x, rv[i].y);
+      *reinterpret_cast<uint2*>(vd + 8) = make_uint2(rv[i].z, rv[i].w);
+    }
+  };
+
+  f32x16 o[2], negm, sa[2], sb[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  float l_run = 0.f;
+  bool first = true;
+  Frag ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
+
+  // one iteration: softmax of tile t (its scores `cur`, relative to the reference, were produced by the previous iteration), the scores
+  // of tile t + 1 into `nxt` from the K plane of `stage`, and O += V^T . P^T from its V^T plane.  Fragment reads: all eight K fragments
+  // first (they land under the row maximum), the V^T fragments of key groups 0 and 1 before the score MFMAs, those of groups 2 and 3
+  // as groups 0 and 1 retire.
+  const uint32_t lds_k = fa::lds_addr(smem) + ql * K_ROWB + hi * 16, lds_v = fa::lds_addr(smem) + K_PLANE + ql * V_ROWB + hi * 8;
+  auto step = [&](int t, int stage, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+    const uint32_t aK = lds_k + stage * STAGE, aV0 = lds_v + stage * STAGE, aV1 = aV0 + 32 * V_ROWB;
+    Frag fk[8], fv[4][2];
+    static_for<8>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      fa::read_b128<(i >> 2) * 32 * K_ROWB + (i & 3) * 32>(fk[i], aK);
+    });
+    if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) cur[kb][r] = -INFINITY;
+        }
+    }
+    float mx = cur[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[1][r]);
+    float alpha = 1.0f, rs = 0.f;
+    if (f5_wave_any(first || mx > LAZY_TAU)) {  // raise the reference (rare after the first tiles), as flash_attn_kernel's LAZY branch
+      const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
+      if (!first) {
+        alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { cur[0][r] -= delta; cur[1][r] -= delta; negm[r] -= delta; }
+      first = false;
+    }
+    fa::read_2b64<0>(fv[0][0], aV0);
+    fa::read_2b64<0>(fv[0][1], aV1);
+    fa::read_2b64<32>(fv[1][0], aV0);
+    fa::read_2b64<32>(fv[1][1], aV1);
+    fa::landed<4>(fk);  // the K fragments (older than the four V^T reads)
+    // scores of the next tile (matrix pipe) under the exponentials of this one (VALU)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { nxt[0][r] = negm[r]; nxt[1][r] = negm[r]; }
+    Frag fp[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Mma32<f16>::mma(nxt[i >> 2], fk[i], fq[i & 3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = __builtin_amdgcn_exp2f(cur[i >> 2][4 * (i & 3) + e]);
+        if constexpr (VSUM) rs += p;
+        fp[i >> 1].h[4 * (i & 1) + e] = (f16)p;
+      }
+    }
+    // O^T += V^T . P^T (+ the row sums on the matrix pipe unless VSUM)
+    f32x16 rsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rsum[r] = 0.f;
+    static_for<4>([&](auto G) {  // reads in flight: group g + 1's two (none behind the last group)
+      constexpr int g = decltype(G)::value;
+      fa::landed<(g < 3 ? 2 : 0)>(fv[g][0], fv[g][1]);
+      if constexpr (g < 2) {  // the fragments of group g + 2 behind the MFMAs of group g
+        fa::read_2b64<(g + 2) * 32>(fv[g + 2][0], aV0);
+        fa::read_2b64<(g + 2) * 32>(fv[g + 2][1], aV1);
+      }
+      if constexpr (!VSUM) Mma32<f16>::mma(rsum, ones, fp[g]);
+      Mma32<f16>::mma(o[0], fv[g][0], fp[g]);
+      Mma32<f16>::mma(o[1], fv[g][1], fp[g]);
+    });
+    l_run = l_run * alpha + (VSUM ? rs : rsum[0]);
+  };
+
+  load_bundle(-1, rk0, rv0);
+  load_bundle(0, rk1, rv1);
+  store_lds(1, rk0, rv0);  // K tile 0 -> slot 1
+  store_lds(0, rk1, rv1);  // bundle 0 -> slot 0
+  load_bundle(1, rk1, rv1);
+  __syncthreads();
+  {
+    const char* sK = smem + STAGE + ql * K_ROWB + hi * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[0][r] = 0.f; sa[1][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Frag fk;
+      fk.u = *reinterpret_cast<const uint4*>(sK + (i >> 2) * 32 * K_ROWB + (i & 3) * 32);
+      Mma32<f16>::mma(sa[i >> 2], fk, fq[i & 3]);
+    }
+  }
+  __syncthreads();  // slot 1 is refilled at the end of the first iteration
+  int t = 0;
+  for (; t + 1 < ntile; t += 2) {
+    load_bundle(t + 2, rk0, rv0);
+    __builtin_amdgcn_sched_barrier(0);
+    step(t, 0, sa, sb);
+    store_lds(1, rk1, rv1);
+    __syncthreads();
+    load_bundle(t + 3, rk1, rv1);
+    __builtin_amdgcn_sched_barrier(0);
+    step(t + 1, 1, sb, sa);
+    store_lds(0, rk0, rv0);
+    __syncthreads();
+  }
+  if (t < ntile) step(t, 0, sa, sb);
+
+  const float l_tot = VSUM ? l_run + __shfl_xor(l_run, 32, 64) : l_run;
+  if (qrow < q_end) {
+    const float inv = 1.0f / l_tot;
+    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
+        f16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[db][4 * c + e] * inv;
+          f16 h, l;
+          split_f16(v, h, l);
+          oh[e] = h;
+          ol[e] = l;
+        }
+        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
+        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
+      }
+  }
+}
+
 // merge the kv_split partial results of every query row: O = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s with m = max_s m_s (the
 // same base-2 exponentials as the kernel), then the operand store of the unsplit kernel.  One thread = 4 output features of one row.
 __global__ __launch_bounds__(256) void flash_combine_kernel(FlashArgs a, int64_t rows) {

@@ -1,5 +1,7 @@
 // common.h — shared device helpers for libf5hip (gfx950 / CDNA4 only; wave = 64).
 #pragma once
+#include <type_traits>
+#include <utility>
 #ifdef F5_HIPEMU  // tests/hipemu: the same kernel source compiled for the host (one std::thread per HIP thread)
 #include "hipemu.h"
 #else
@@ -19,6 +21,16 @@ typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (indices usable as immediates / template arguments)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // One 16-byte MFMA operand fragment: 8 halves (k = 8*(lane>>5)+0..7 of a 16-wide k-step of
 // v_mfma_f32_32x32x16_f16) or 4 floats (k = 4*(lane>>5)+j, j-th of four v_mfma_f32_32x32x2_f32:

@@ -23,12 +23,6 @@
 
 #include "gemm.h"
 
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (indices usable as immediates / template arguments)
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
-}
-
 // ---- primitives: amdgcn instructions on the GPU, plain memory operations under the host shim (tests/hipemu) ------------------------
 namespace pp {
 #ifdef F5_HIPEMU

@@ -328,9 +328,11 @@ def test_emulated_library_rejects_what_the_real_one_rejects(emu_lib):
 
 
 # ---- flash attention (csrc/attention_kernel.h): the GPU-proven kernel through the shim, then its key-split variant ---------------------
-def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None):
+def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None, log2q=False):
     bh = Bp * heads
     q = (rng.standard_normal((bh, n, 64)) * 0.5 / 8.0).astype(np.float32)  # pre-scaled by 1/sqrt(64), as the QKV epilogue leaves it
+    if log2q:
+        q *= np.float32(np.log2(np.e))  # ... and by log2(e): the kernel's scores are base-2 logarithms
     k = (rng.standard_normal((bh, n, 64)) * 1.5).astype(np.float32)
     v = rng.standard_normal((bh, n, 64)).astype(np.float32)
     ldv = (n + 7) & ~7
@@ -347,7 +349,7 @@ def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None):
         files["kvlen"] = np.asarray(kvlen, dtype=np.int32)
     val = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit >= 2 else (lambda x: hi(x).astype(np.float64))
     vval = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit == 3 else (lambda x: hi(x).astype(np.float64))
-    s = val(q) @ val(k).transpose(0, 2, 1)
+    s = val(q) @ val(k).transpose(0, 2, 1) * (np.log(2.0) if log2q else 1.0)
     if kvlen is not None:
         for b in range(Bp):
             s[b * heads:(b + 1) * heads, :, kvlen[b]:] = -np.inf
@@ -369,6 +371,18 @@ def test_flash_attention_kernel_and_its_key_split_variant(exe, tmp_path, nsplit,
     got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
     tol = 3e-3 if nsplit < 3 else 2e-5  # P (and V) rounded to fp16 in the PV product unless everything is split
     assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("pipe,n,kvlen", [(4, 200, None), (14, 70, None), (6, 450, [450, 301]), (16, 130, [130, 77]), (4, 64, None), (4, 333, [1, 333])])
+def test_software_pipelined_flash_attention(exe, tmp_path, pipe, n, kvlen):
+    """flash_pipe_kernel (scores of tile t + 1 issued inside the softmax of tile t; skewed K / V^T ring): 4- and 6-wave blocks, row sums on
+    either pipe, one tile, odd and even tile counts, masked tails down to a single valid key."""
+    rng = np.random.default_rng(n + pipe)
+    Bp, heads = 2, 2
+    files, want = _attn_case(rng, Bp, heads, n, 1, kvlen, log2q=True)
+    run(exe, tmp_path, "attn", 1, Bp, heads, n, 1, 1, int(kvlen is not None), pipe, **files)
+    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
+    assert np.abs(got - want).max() < 3e-3 * max(1.0, np.abs(want).max())
 
 
 # ---- the DiT engine itself (api.cpp + every kernel translation unit) on the CPU: the product's own host classes over the shim ------------
