@@ -51,7 +51,33 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   // per B = 1 sample); with two workgroups per CU it ties or loses (B' = 16: 197.9 against 192.0 us, B' = 64: 829 against 825), so the
   // 128-row launches keep the phase-by-phase kernel.  F5HIP_ATTN_PIPE=0 / 1: never / also for the 128-row blocks (A/B).
   static const int pipe_env = [] { const char* v = getenv("F5HIP_ATTN_PIPE"); return v ? atoi(v) : -1; }();
+  // ping-pong form (attention_kernel.h flash_pp_kernel): 8 waves, 256 query rows, the two halves one phase apart.  F5HIP_ATTN_PP=0: off (A/B)
+  static const bool pp_off = [] { const char* v = getenv("F5HIP_ATTN_PP"); return !v || atoi(v) == 0; }();
   if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
+    if (lazy && !pp_off) {
+      static const int prio = [] { const char* v = getenv("F5HIP_ATTN_PP_PRIO"); return v ? atoi(v) : 1; }();
+      a.pp_prio = prio;
+      a.nqb = (a.n + 255) / 256; a.nwg = bh * a.nqb;
+      static const int pabl = [] { const char* v = getenv("F5HIP_ATTN_PP_ABLATE"); return v ? atoi(v) : 0; }();  // microbenchmark only
+      if (pabl == 1) hipLaunchKernelGGL(flash_pp_kernel<1>, dim3(a.nwg), dim3(512), lds, s, a);
+      else if (pabl == 2) hipLaunchKernelGGL(flash_pp_kernel<2>, dim3(a.nwg), dim3(512), lds, s, a);
+      else if (pabl == 3) hipLaunchKernelGGL(flash_pp_kernel<3>, dim3(a.nwg), dim3(512), lds, s, a);
+      else if (pabl == 4) hipLaunchKernelGGL(flash_pp_kernel<4>, dim3(a.nwg), dim3(512), lds, s, a);
+      else if (pabl == 5) hipLaunchKernelGGL(flash_pp_kernel<5>, dim3(a.nwg), dim3(512), lds, s, a);
+      else hipLaunchKernelGGL(flash_pp_kernel<0>, dim3(a.nwg), dim3(512), lds, s, a);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
+    static const int abl = [] { const char* v = getenv("F5HIP_ATTN_ABLATE"); return v ? atoi(v) : 0; }();  // microbenchmark only (garbage results)
+    if (lazy && abl >= 1 && abl <= 7) {  // (the 128-row form, whatever the launch shape)
+      a.nqb = nqb4; a.nwg = bh * a.nqb;
+      static_for<7>([&](auto I) {
+        constexpr int A = decltype(I)::value + 1;
+        if (abl == A) hipLaunchKernelGGL((flash_pipe_kernel<4, false, A>), dim3(a.nwg), dim3(256), lds, s, a);
+      });
+      return hipGetLastError();
+    }
     if (lazy && pipe_env != 0 && (six || pipe_env == 1)) {
       a.nqb = six ? nqb6 : nqb4; a.nwg = bh * a.nqb;
       if (six) { if (vsum) hipLaunchKernelGGL((flash_pipe_kernel<6, true>), dim3(a.nwg), dim3(384), lds, s, a);
@@ -107,6 +133,7 @@ hipError_t set_attr_pipe() {
 
 hipError_t init_attention_kernels() {
   hipError_t e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, flash_lds_bytes<1, 1>())) != hipSuccess) return e;
   if ((e = set_attr_pipe<4, false>()) != hipSuccess || (e = set_attr_pipe<4, true>()) != hipSuccess || (e = set_attr_pipe<6, false>()) != hipSuccess ||
       (e = set_attr_pipe<6, true>()) != hipSuccess)
     return e;

@@ -35,6 +35,7 @@ struct FlashArgs {
   // Packed rows (engine option "packed_rows", with kvlen): the output row of query q of sequence b' is cu_rows[b'] + q instead of
   // b' * n + q, queries >= kvlen[b'] do not exist (their blocks exit at once) — the reference's varlen path, modules.py:522-543.
   const int32_t* cu_rows;
+  int pp_prio;  // flash_pp_kernel: raise the wave priority during the softmax phase (A/B switch F5HIP_ATTN_PP_PRIO, default on)
 };
 
 // NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
@@ -366,6 +367,8 @@ template <int N>
 inline void landed(Frag&, Frag&) {}
 template <int N>
 inline void landed(Frag (&)[8]) {}
+template <int N>
+inline void landed_behind(Frag (&)[8], f32x16&, f32x16&) {}
 #else
 __device__ __forceinline__ uint32_t lds_addr(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 template <int OFF>
@@ -385,6 +388,13 @@ template <int N>
 __device__ __forceinline__ void landed(Frag (&k)[8]) {
   asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(k[0].f), "+v"(k[1].f), "+v"(k[2].f), "+v"(k[3].f), "+v"(k[4].f), "+v"(k[5].f), "+v"(k[6].f), "+v"(k[7].f) : "n"(N));
 }
+// the same wait, additionally ordered behind the MFMAs that produce x and y (pure intrinsics otherwise float above a volatile asm)
+template <int N>
+__device__ __forceinline__ void landed_behind(Frag (&k)[8], f32x16& x, f32x16& y) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(k[0].f), "+v"(k[1].f), "+v"(k[2].f), "+v"(k[3].f), "+v"(k[4].f), "+v"(k[5].f), "+v"(k[6].f), "+v"(k[7].f), "+v"(x), "+v"(y)
+               : "n"(N));
+}
 #endif
 }  // namespace fa
 
@@ -399,7 +409,9 @@ __device__ __forceinline__ void landed(Frag (&k)[8]) {
 // Measured (profiles/r03j_attn_pipe_ab.log): the overlap alone changed nothing (32.6 -> 32.9 us at B' = 2), the early fragment reads on top
 // of it -3 % there and nothing with two workgroups per CU: neither a wave's phase order nor its LDS round trips is what the ~80 cycles
 // per MFMA slot of this kernel are spent on.  The launcher uses this form for the one-round 192-row launch only.
-template <int NW, bool VSUM>
+// ABL (microbenchmark only, results are garbage): 1 no exponentials, 2 no score MFMAs, 3 no PV / row-sum MFMAs, 4 no K / V traffic (global
+// loads, LDS stores; barriers kept), 5 = 4 without the barriers, 6 no row maximum / reference check, 7 = 1 + 6 (no softmax VALU at all).
+template <int NW, bool VSUM, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(FlashArgs a) {
   constexpr int STAGE = K_PLANE + V_PLANE;
   F5_DYN_LDS(char, smem);
@@ -439,8 +451,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
     v_off[i] = (uint32_t)(row * a.ldv * 2 + col * 16);
   }
   uint4 rk0[2], rv0[2], rk1[2], rv1[2];
+  int t_now = 0;  // (ablations 4, 5)
   auto load_bundle = [&](int j, uint4 (&rk)[2], uint4 (&rv)[2]) {  // K tile j + 1 and V^T tile j (j = -1: K tile 0 alone)
     if (NW > 4 && wave >= 4) return;
+    if ((ABL == 4 || ABL == 5) && j > 0) return;
     const uint32_t keyk = (uint32_t)(j + 1) * KT, keyv = (uint32_t)(j < 0 ? 0 : j) * KT;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -451,6 +465,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
     }
   };
   auto store_lds = [&](int stage, const uint4 (&rk)[2], const uint4 (&rv)[2]) {
+    if ((ABL == 4 || ABL == 5) && t_now > 0) return;
     if (NW > 4 && wave >= 4) return;
     char* base = smem + stage * STAGE;
 #pragma unroll
@@ -494,12 +509,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
         }
     }
     float mx = cur[0][0];
+    if constexpr (ABL != 6 && ABL != 7) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[0][r]);
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, cur[0][r]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[1][r]);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, cur[1][r]);
+    }
     float alpha = 1.0f, rs = 0.f;
-    if (f5_wave_any(first || mx > LAZY_TAU)) {  // raise the reference (rare after the first tiles), as flash_attn_kernel's LAZY branch
+    if ((ABL == 6 || ABL == 7) ? first : f5_wave_any(first || mx > LAZY_TAU)) {  // raise the reference (rare after the first tiles), as flash_attn_kernel's LAZY branch
       const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
       if (!first) {
@@ -515,17 +532,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
     fa::read_2b64<0>(fv[0][1], aV1);
     fa::read_2b64<32>(fv[1][0], aV0);
     fa::read_2b64<32>(fv[1][1], aV1);
+    Frag fp[4];
     fa::landed<4>(fk);  // the K fragments (older than the four V^T reads)
     // scores of the next tile (matrix pipe) under the exponentials of this one (VALU)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { nxt[0][r] = negm[r]; nxt[1][r] = negm[r]; }
-    Frag fp[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      Mma32<f16>::mma(nxt[i >> 2], fk[i], fq[i & 3]);
+      if constexpr (ABL != 2) Mma32<f16>::mma(nxt[i >> 2], fk[i], fq[i & 3]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = __builtin_amdgcn_exp2f(cur[i >> 2][4 * (i & 3) + e]);
+        const float p = (ABL == 1 || ABL == 7) ? cur[i >> 2][4 * (i & 3) + e] : __builtin_amdgcn_exp2f(cur[i >> 2][4 * (i & 3) + e]);
         if constexpr (VSUM) rs += p;
         fp[i >> 1].h[4 * (i & 1) + e] = (f16)p;
       }
@@ -541,9 +558,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
         fa::read_2b64<(g + 2) * 32>(fv[g + 2][0], aV0);
         fa::read_2b64<(g + 2) * 32>(fv[g + 2][1], aV1);
       }
-      if constexpr (!VSUM) Mma32<f16>::mma(rsum, ones, fp[g]);
-      Mma32<f16>::mma(o[0], fv[g][0], fp[g]);
-      Mma32<f16>::mma(o[1], fv[g][1], fp[g]);
+      if constexpr (ABL == 3) {  // keep the operands alive without the matrix pipe
+        o[0][g] += fv[g][0].f[0] + (float)fp[g].h[0];
+        o[1][g] += fv[g][1].f[0];
+      } else {
+        if constexpr (!VSUM) Mma32<f16>::mma(rsum, ones, fp[g]);
+        Mma32<f16>::mma(o[0], fv[g][0], fp[g]);
+        Mma32<f16>::mma(o[1], fv[g][1], fp[g]);
+      }
     });
     l_run = l_run * alpha + (VSUM ? rs : rsum[0]);
   };
@@ -568,22 +590,278 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
   __syncthreads();  // slot 1 is refilled at the end of the first iteration
   int t = 0;
   for (; t + 1 < ntile; t += 2) {
+    t_now = t + 1;
     load_bundle(t + 2, rk0, rv0);
     __builtin_amdgcn_sched_barrier(0);
     step(t, 0, sa, sb);
     store_lds(1, rk1, rv1);
-    __syncthreads();
+    if constexpr (ABL != 5) __syncthreads();
     load_bundle(t + 3, rk1, rv1);
     __builtin_amdgcn_sched_barrier(0);
     step(t + 1, 1, sb, sa);
     store_lds(0, rk0, rv0);
-    __syncthreads();
+    if constexpr (ABL != 5) __syncthreads();
   }
   if (t < ntile) step(t, 0, sa, sb);
 
   const float l_tot = VSUM ? l_run + __shfl_xor(l_run, 32, 64) : l_run;
   if (qrow < q_end) {
     const float inv = 1.0f / l_tot;
+    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
+        f16x4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[db][4 * c + e] * inv;
+          f16 h, l;
+          split_f16(v, h, l);
+          oh[e] = h;
+          ol[e] = l;
+        }
+        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
+        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
+      }
+  }
+}
+
+// Ping-pong form (round 3) of the production configuration (plain fp16 q, k, P, V; base-2 scores; lazy reference maximum; unsplit keys; row
+// sums on the matrix pipe).  What the ablations of flash_pipe_kernel showed (profiles/r03j_attn_ablate.log): with two independent 4-wave
+// workgroups per CU the parts of a tile ADD — 20 MFMAs cost their full 30-42 cycles each, the K / V traffic + barriers 20 %, the softmax
+// VALU 10 % — because the two waves of a SIMD run the same code in step and meet on the same pipe in every phase.  Here ONE workgroup of
+// 8 waves owns 256 query rows: waves w and w + 4 share a SIMD, and the two halves run the same per-tile sequence one PHASE apart, a
+// workgroup barrier between phases:
+//     phase 2t      half 0: S(t)   softmax VALU of tile t               half 1: M(t-1)
+//     phase 2t + 1  half 0: M(t)   20 MFMAs: row sums, scores of t+1, PV of t   half 1: S(t)
+// so a SIMD's matrix pipe always has exactly one wave feeding it while the other does its exponentials, its share of the next K / V^T
+// tile's LDS stores and the global loads of the tile after.  K / V^T traffic per query row halves (both halves read the same tiles).
+// Ring slot j & 1 holds bundle j = (K tile j + 1, V^T tile j), read in phases 2j + 1 (half 0) and 2j + 2 (half 1); half 1 writes its half of
+// bundle j in phase 2j - 1, half 0 in phase 2j — neither phase reads that slot (its previous bundle j - 2 was last read in phase 2j - 2).
+// ABL (microbenchmark only, garbage results): 1 no softmax VALU (max, reference check, exponentials), 2 no MFMAs, 3 no K / V traffic (global
+// loads, LDS stores), 4 no fragment reads (register operands), 5 = 1 + 3 (the softmax phase is empty).
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void flash_pp_kernel(FlashArgs a) {
+  constexpr int STAGE = K_PLANE + V_PLANE;
+  F5_DYN_LDS(char, smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = wave >> 2, hi = lane >> 5, ql = lane & 31;
+  const int bid = blockIdx.x;  // XCD-aware placement as flash_attn_kernel
+  const int q8 = a.nwg >> 3, r8 = a.nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+  const int bh = L / a.nqb, qb = L - bh * a.nqb;
+  const int bp = bh / a.heads, hh = bh - bp * a.heads;
+  const int n = a.n;
+  int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n, hole_lo = 0, hole_hi = 0;
+  if (a.kvlen && a.kvlen2) {
+    hole_lo = kv_end;
+    hole_hi = min(a.seg2_off, n);
+    kv_end = min(a.seg2_off + a.kvlen2[bp], n);
+    if (hole_lo >= hole_hi) hole_lo = hole_hi = 0;
+  }
+  const int q_end = a.cu_rows ? (a.kvlen ? min(a.kvlen[bp], n) : n) : n;
+  if (qb * 256 >= q_end) return;  // (whole workgroup, before any barrier)
+  const int ntile = (kv_end + KT - 1) / KT;
+
+  const uint32_t k_bytes = (uint32_t)n * 128u, v_bytes = (uint32_t)(64 * a.ldv) * 2u;
+  const BufRsrc Kr = make_rsrc(a.k + (int64_t)bh * n * 64, k_bytes);
+  const BufRsrc Vr = make_rsrc(a.vt + (int64_t)bh * 64 * a.ldv, v_bytes);
+  const f16* Qp = a.q + (int64_t)bh * n * 64;
+  const int qrow = qb * 256 + wave * 32 + ql;
+  Frag fq[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    fq[ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+
+  // this thread's 16-byte chunk of a K tile (key row tid >> 3) and of a V^T tile (feature row tid >> 3): 512 chunks each
+  const int crow = tid >> 3, ccol = tid & 7;
+  const uint32_t k_off = (uint32_t)(crow * 128 + ccol * 16), v_off = (uint32_t)(crow * a.ldv * 2 + ccol * 16);
+  uint4 rk[2], rv[2];  // two register sets: a bundle is loaded two tiles ahead of its LDS store
+  auto load_bundle = [&](int j, uint4& k4, uint4& v4) {  // K tile j + 1 and V^T tile j (j = -1: K tile 0 alone)
+    const uint32_t keyk = (uint32_t)(j + 1) * KT, keyv = (uint32_t)(j < 0 ? 0 : j) * KT;
+    const uint32_t vkey_off = keyv * 2 + (uint32_t)ccol * 16;
+    k4 = buffer_load_b128(Kr, k_off + keyk * 128);  // past the last key: zeros (descriptor bounds)
+    v4 = buffer_load_b128(Vr, (j >= 0 && vkey_off < (uint32_t)a.ldv * 2) ? v_off + keyv * 2 : OOB_OFF);
+  };
+  auto store_bundle = [&](int slot_, const uint4& k4, const uint4& v4) {
+    char* base = smem + slot_ * STAGE;
+    *reinterpret_cast<uint4*>(base + crow * K_ROWB + ccol * 16) = k4;
+    char* vd = base + K_PLANE + crow * V_ROWB + ccol * 16;
+    *reinterpret_cast<uint2*>(vd) = make_uint2(v4.x, v4.y);
+    *reinterpret_cast<uint2*>(vd + 8) = make_uint2(v4.z, v4.w);
+  };
+
+  f32x16 o[2], negm, sc[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  float l_run = 0.f, alpha = 1.0f;
+  bool first = true;
+  Frag ones, fp[4];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
+  const uint32_t lds_k = fa::lds_addr(smem) + ql * K_ROWB + hi * 16, lds_v = fa::lds_addr(smem) + K_PLANE + ql * V_ROWB + hi * 8;
+
+  // S(t): this half's LDS stores of bundle t + half and the loads of bundle t + half + 2, then the softmax of tile t: sc -> fp (P as fp16)
+  auto softmax_phase = [&](int t, uint4& k4, uint4& v4) {
+    // VALU issue between the two waves of a SIMD goes by priority, then age, and a wave streaming MFMAs is always a candidate: without
+    // the raise the softmax of the younger half crawls beside the older half's matrix phase (tools/probes/mfma_pace_probe.hip: 18x)
+    if (a.pp_prio) __builtin_amdgcn_s_setprio(2);
+    const int b = t + half;
+    if (b >= 1 && ABL != 3 && ABL != 5) {
+      store_bundle(b & 1, k4, v4);
+      load_bundle(b + 2, k4, v4);
+    }
+    if constexpr (ABL == 1 || ABL == 5) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fp[i].f = (f32x4){sc[0][i], sc[0][4 + i], sc[1][i], sc[1][4 + i]};
+      first = false;
+      if (a.pp_prio) __builtin_amdgcn_s_setprio(0);
+      return;
+    }
+    if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) sc[kb][r] = -INFINITY;
+        }
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+    alpha = 1.0f;
+    if (f5_wave_any(first || mx > LAZY_TAU)) {  // raise the reference (rare after the first tiles), as flash_attn_kernel's LAZY branch
+      const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
+      if (!first) {
+        alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sc[0][r] -= delta; sc[1][r] -= delta; negm[r] -= delta; }
+      first = false;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) fp[i >> 3].h[i & 7] = (f16)__builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+    if (a.pp_prio) __builtin_amdgcn_s_setprio(0);
+  };
+  // M(t): row sums of P_t, scores of tile t + 1 from the K plane of slot t & 1, O += V^T . P^T from its V^T plane — 20 MFMAs in a fixed
+  // order in which no two neighbours share an accumulator (a dependent MFMA right behind its producer is fine, one with a wait or a read
+  // in between stalls: MI355X_MICROARCH "one extra issue slot between two MFMAs on the same accumulator"), the two row-sum MFMAs that
+  // need no LDS operand first (they cover the first fragment reads).
+  auto mfma = [&](f32x16& acc, const Frag& x, const Frag& y) {
+    if constexpr (ABL == 2) acc[0] += x.f[0] * y.f[0];
+    else Mma32<f16>::mma(acc, x, y);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto matrix_phase = [&](int st) {
+    const uint32_t aK = lds_k + st * STAGE, aV0 = lds_v + st * STAGE, aV1 = aV0 + 32 * V_ROWB;
+    Frag fk[8], fv[4][2];
+    if constexpr (ABL == 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { fk[i] = fq[i & 3]; fv[i >> 1][i & 1] = fq[i & 3]; }
+    }
+    static_for<8>([&](auto I) {  // issue order = use order: (ks, kb) = (0,0) (0,1) (1,0) ...
+      constexpr int i = decltype(I)::value, kb = i & 1, ks = i >> 1;
+      if constexpr (ABL != 4) fa::read_b128<kb * 32 * K_ROWB + ks * 32>(fk[i], aK);
+    });
+    if constexpr (ABL != 4) {
+      fa::read_2b64<0>(fv[0][0], aV0);
+      fa::read_2b64<0>(fv[0][1], aV1);
+      fa::read_2b64<32>(fv[1][0], aV0);
+      fa::read_2b64<32>(fv[1][1], aV1);
+    }
+    f32x16 ra, rb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ra[r] = 0.f; rb[r] = 0.f; }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(ra, ones, fp[0]);
+    mfma(rb, ones, fp[1]);
+    if constexpr (ABL != 4) fa::landed_behind<4>(fk, ra, rb);  // the K fragments (older than the four V^T reads)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[0][r] = negm[r]; sc[1][r] = negm[r]; }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma(sc[0], fk[0], fq[0]);
+    mfma(sc[1], fk[1], fq[0]);
+    mfma(ra, ones, fp[2]);
+    mfma(sc[0], fk[2], fq[1]);
+    mfma(sc[1], fk[3], fq[1]);
+    mfma(rb, ones, fp[3]);
+    mfma(sc[0], fk[4], fq[2]);
+    mfma(sc[1], fk[5], fq[2]);
+    mfma(sc[0], fk[6], fq[3]);
+    mfma(sc[1], fk[7], fq[3]);
+    static_for<4>([&](auto G) {  // reads in flight: group g + 1's two (none behind the last group)
+      constexpr int g = decltype(G)::value;
+      if constexpr (ABL != 4) {
+        fa::landed<(g < 3 ? 2 : 0)>(fv[g][0], fv[g][1]);
+        if constexpr (g < 2) {
+          fa::read_2b64<(g + 2) * 32>(fv[g + 2][0], aV0);
+          fa::read_2b64<(g + 2) * 32>(fv[g + 2][1], aV1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(o[0], fv[g][0], fp[g]);
+      mfma(o[1], fv[g][1], fp[g]);
+    });
+    l_run = l_run * alpha + (ra[0] + rb[0]);
+  };
+
+  load_bundle(-1, rk[0], rv[0]);
+  load_bundle(0, rk[1], rv[1]);
+  store_bundle(1, rk[0], rv[0]);  // K tile 0 -> slot 1
+  store_bundle(0, rk[1], rv[1]);  // bundle 0 -> slot 0
+  // set 0 is stored at even t, set 1 at odd t; the bundle a half stores at t is t + half
+  load_bundle(half ? 1 : 2, rk[0], rv[0]);
+  load_bundle(half ? 2 : 1, rk[1], rv[1]);
+  __syncthreads();
+  {
+    const char* sK = smem + STAGE + ql * K_ROWB + hi * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Frag fk;
+      fk.u = *reinterpret_cast<const uint4*>(sK + (i >> 2) * 32 * K_ROWB + (i & 3) * 32);
+      Mma32<f16>::mma(sc[i >> 2], fk, fq[i & 3]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();            // slot 1 is refilled from phase 1 on
+  if (half) __syncthreads();  // half 1 runs one phase behind
+  __builtin_amdgcn_sched_barrier(0);
+  int t = 0;
+  // a phase boundary: nothing (an MFMA above all) may be scheduled across it
+  auto phase_end = [&] {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (; t + 1 < ntile; t += 2) {
+    softmax_phase(t, rk[0], rv[0]);
+    phase_end();
+    matrix_phase(0);
+    phase_end();
+    softmax_phase(t + 1, rk[1], rv[1]);
+    phase_end();
+    matrix_phase(1);
+    phase_end();
+  }
+  if (t < ntile) {
+    softmax_phase(t, rk[0], rv[0]);
+    phase_end();
+    matrix_phase(0);
+    phase_end();
+  }
+  if (!half) phase_end();
+
+  if (qrow < q_end) {
+    const float inv = 1.0f / l_run;
     const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
 #pragma unroll
     for (int db = 0; db < 2; ++db)

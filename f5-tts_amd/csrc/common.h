@@ -24,11 +24,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) (indices usable as immediates / template arguments)
 template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+__host__ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
   (f(std::integral_constant<int, I>{}), ...);
 }
 template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
+__host__ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 

@@ -492,4 +492,5 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
