@@ -20,7 +20,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` through gpurun)")
 
 
+def _needs_host_engine(item):
+    return "engine_emu_lib" in getattr(item, "fixturenames", ())
+
+
 def pytest_collection_modifyitems(config, items):
+    # tests over the host build of the engine go last: its compile (tests/hipemu_build.py, ~2 min of one core) then runs beside the others
+    items.sort(key=_needs_host_engine)  # stable
     try:
         import torch
 
@@ -33,3 +39,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_collection_finish(session):
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return
+    except Exception:  # pragma: no cover
+        pass
+    if any(_needs_host_engine(it) and "gpu" not in it.keywords for it in session.items):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hipemu_build
+
+        hipemu_build.start_background()

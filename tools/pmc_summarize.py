@@ -19,7 +19,7 @@ def klass(name):
         if "DF16_Li1" in name or "_Float16, 1" in name:
             return "gemm_fp16"
         return "gemm_fp32"
-    if "flash_attn" in name:
+    if "flash_attn" in name or "flash_pipe" in name or "flash_pp" in name:
         return "flash_attn"
     if "layernorm" in name:
         return "layernorm"
