@@ -59,24 +59,35 @@ template <typename T, int NSPLIT, int TM, int TN>
 hipError_t launch_conv_one(const GemmCore& g, const ConvTaps& tp, const EpiStore& e, int batch, hipStream_t s) {
   constexpr int lds = gemm_lds_bytes<T, NSPLIT, TM, TN, 2, 2>();
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  auto kern = conv_gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (err != hipSuccess) return err;
-    attr_done = true;
-  }
+  auto kern = conv_gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>;  // (dynamic-LDS limit: init_bigvgan_kernels, per device)
   if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
     return hipErrorInvalidValue;
   dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, tp, e);
   return hipGetLastError();
 }
+template <typename T, int NSPLIT, int TM, int TN>
+hipError_t set_conv_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<T, NSPLIT, TM, TN, EpiStore, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             gemm_lds_bytes<T, NSPLIT, TM, TN, 2, 2>());
+}
+template <typename T, int NSPLIT>
+hipError_t set_conv_attrs() {
+  const hipError_t e = set_conv_attr<T, NSPLIT, 2, 1>();
+  return e != hipSuccess ? e : set_conv_attr<T, NSPLIT, 2, 2>();
+}
 template <typename T, int NSPLIT>
 hipError_t launch_conv_op(const GemmCore& g, const ConvTaps& tp, const EpiStore& e, int batch, hipStream_t s) {
   return g.N <= 64 ? launch_conv_one<T, NSPLIT, 2, 1>(g, tp, e, batch, s) : launch_conv_one<T, NSPLIT, 2, 2>(g, tp, e, batch, s);
 }
 }  // namespace
+
+// Dynamic-LDS limits of the implicit-GEMM conv kernels for the CURRENT device: called at context creation (per device; never inside a capture)
+hipError_t init_bigvgan_kernels() {
+  hipError_t e;
+  if ((e = set_conv_attrs<float, 1>()) != hipSuccess || (e = set_conv_attrs<f16, 1>()) != hipSuccess) return e;
+  return set_conv_attrs<f16, 3>();
+}
 
 hipError_t launch_conv_gemm(int op, const GemmCore& g, int ntaps, int shift0, int dstep, int cpad, const EpiStore& e, int batch, hipStream_t s) {
   const int seg = cpad * (op == OP_F16 ? 2 : 4);  // bytes of one tap segment of an operand row (packed fp16x3: 2 planes x 2 bytes)

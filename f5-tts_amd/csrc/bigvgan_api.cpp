@@ -250,6 +250,7 @@ int finalize_impl(f5hip_bigvgan* v) {
   for (const auto& t : v->tensors)
     if (!t.loaded) FAIL(F5HIP_ERR_STATE, "tensor '%s' was never loaded", t.name.c_str());
   HIPCHK(init_gemm_kernels());
+  HIPCHK(init_bigvgan_kernels());
   bv_kaiser_sinc_12(v->filt);
   CHK(make_conv(v, v->conv_pre, "conv_pre", 1));
   v->ups.assign(c.num_upsamples, ConvW{});

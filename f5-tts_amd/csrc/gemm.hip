@@ -85,17 +85,24 @@ int pick_variant(const GemmCore& g, int batch) {
 }
 
 #ifndef F5_HIPEMU
+// the dynamic-LDS limit of every gemm_glds_kernel instantiation launch_tiled can reach (variant 6), for the CURRENT device
+template <typename T, int NSPLIT, typename Epi>
+hipError_t set_glds_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<T, NSPLIT, 2, 1, Epi, 2, 2, 3, 0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             gemm_glds_lds_bytes<T, NSPLIT, 2, 1, 2, 2, 3>());
+}
+template <typename Epi>
+hipError_t set_glds_attrs() {
+  hipError_t e;
+  if ((e = set_glds_attr<float, 1, Epi>()) != hipSuccess) return e;
+  if ((e = set_glds_attr<f16, 1, Epi>()) != hipSuccess) return e;
+  return set_glds_attr<f16, 3, Epi>();
+}
 // direct-to-LDS ring variant of the 128x64 tile (variant id 6)
 template <typename T, int NSPLIT, int TM, int TN, typename Epi, int WGM = 2, int WGN = 2, int NS = 3, int PRIO = 0>
 hipError_t launch_glds(const GemmCore& g, const Epi& e, int batch, hipStream_t s) {
   constexpr int lds = gemm_glds_lds_bytes<T, NSPLIT, TM, TN, WGM, WGN, NS>();
-  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi, WGM, WGN, NS, PRIO>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (err != hipSuccess) return err;
-    attr_done = true;
-  }
+  auto kern = gemm_glds_kernel<T, NSPLIT, TM, TN, Epi, WGM, WGN, NS, PRIO>;  // (dynamic-LDS limit: set_glds_attrs, per device, at context creation)
   if ((int64_t)g.a_rows * g.lda * (int64_t)sizeof(T) >= (int64_t)0x7ff00000 || (int64_t)g.w_rows * g.ldw * (int64_t)sizeof(T) >= (int64_t)0x7ff00000)
     return hipErrorInvalidValue;
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
@@ -424,6 +431,9 @@ hipError_t init_gemm_kernels() {
   if (e != hipSuccess) return e;
   e = set_attrs_epi<EpiQKVFast>();
   if (e != hipSuccess) return e;
+#ifndef F5_HIPEMU
+  if ((e = set_glds_attrs<EpiStore>()) != hipSuccess || (e = set_glds_attrs<EpiQKV>()) != hipSuccess || (e = set_glds_attrs<EpiQKVFast>()) != hipSuccess) return e;
+#endif
   e = set_pp_attrs<1>();
   if (e != hipSuccess) return e;
   return set_pp_attrs<3>();

@@ -19,6 +19,7 @@ hipError_t init_gemm_kernels();
 hipError_t launch_pp_qkv_probe(const GemmCore& g, const EpiQKV& e, int variant, int expt, int abl, int lds_pad, uint32_t* dbg, hipStream_t s);
 hipError_t launch_noise(const void* src, uint32_t bytes, int wgs, int rounds, int kind, int lds_bytes, uint32_t* sink, hipStream_t s);
 hipError_t init_convpos_kernels();
+hipError_t init_bigvgan_kernels();
 
 // ---- elementwise.hip --------------------------------------------------------------------------
 // LayerNorm over the last dim D (D % 4 == 0, D <= 2048), eps inside sqrt.  Either affine (weight/bias) or
