@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libf5hip.so")
+# F5HIP_LIB=/path/to/libf5hip.so: another build of the same ABI (A/B measurements of two builds on one box; tools/gpu_run.sh)
+LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "csrc", "libf5hip.so")
 
 ABI_VERSION = 7  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2

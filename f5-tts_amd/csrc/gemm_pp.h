@@ -588,13 +588,22 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
       }
     });
     __syncthreads();
+    // The partner's copies are read with the inline-asm fragment reads: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS read it can see
+    // (an LDS-DMA might still be in flight, for all it knows), and on gfx9 that counter also holds the STORES of the tile finished just
+    // before — every tile of a wave would wait for the previous tile's global stores to be acknowledged (round 3: found in the disassembly).
+    const uint32_t xbase = pp::lds_base(smem_all) + (uint32_t)((wave * NT * 4) * 64 + lane) * 16u;
     static_for<NT>([&](auto TI) {
       constexpr int ti = decltype(TI)::value, j = ti / TN, i = ti % TN;
       if (grp == (ti < NT0 ? 0 : 1)) {
         f32x16 one[1][1];
+        uint4 ou[4];
+        static_for<4>([&](auto Q) { ou[decltype(Q)::value] = pp::lds_read_b128<(ti * 4 + decltype(Q)::value) * 1024>(xbase); });
+        pp::lds_wait();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 o = xch[((wave * NT + ti) * 4 + q) * 64 + lane];
+          union { uint4 u; float4 f; } cv;
+          cv.u = ou[q];
+          const float4 o = cv.f;
           if (grp == 0) {  // own (group 0) + partner (group 1)
             one[0][0][4 * q] = acc[j][i][4 * q] + o.x; one[0][0][4 * q + 1] = acc[j][i][4 * q + 1] + o.y;
             one[0][0][4 * q + 2] = acc[j][i][4 * q + 2] + o.z; one[0][0][4 * q + 3] = acc[j][i][4 * q + 3] + o.w;
