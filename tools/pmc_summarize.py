@@ -1,4 +1,4 @@
-"""Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench.sh) into HBM bytes per launch per kernel class.
+"""Aggregate rocprofv3 FETCH_SIZE / WRITE_SIZE passes (`tools/gpu_run.sh pmc` / `counters`) into HBM bytes per launch per kernel class.
 FETCH_SIZE / WRITE_SIZE are reported in KiB-units of 1024 B by rocprofv3; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
 for wide coalesced reads, so it is doubled (/opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is uncalibrated."""
 import argparse
