@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[2] uses 32)")
     ap.add_argument("--nfe", type=int, default=16)
-    ap.add_argument("--precision", default="fp16x3", choices=["fp32", "fp16x3", "fp16"])
+    ap.add_argument("--precision", default="fp16x3", choices=["fp32", "fp16x3", "fp16m", "fp16"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="F5TTS_v1_Base")
@@ -299,6 +299,7 @@ def main():
         "rtf": (dt / a.steps) / audio_s, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp16x3": "fp16x3 (fp16 hi/lo split MFMA operands, fp32 accumulate/state)", "fp16": "fp16 (fp32 accumulate/state)",
+                  "fp16m": "fp16m (fp16x3 whose two correction products per 32 k of the DiT block GEMMs are one MX-fp6 MFMA; fp32 accumulate/state)",
                   "fp32": "fp32"}[a.precision],
         "data": "synthetic (seeded 0.1*N(0,1) prompts, uniform token ids, random-init weights of the named architecture)",
         "config": {"workload": f"NOT A BENCHMARK (--tiny): tiny model + tiny Vocos, {duration} frames, NFE={a.nfe}" if a.tiny else
@@ -339,9 +340,10 @@ def main():
         res["roofline"] = {"kernel": "gemm_pp_kernel / gemm_kernel (DiT block QKV / out / FF1 / FF2)", "bound": "mfma", "achieved": ach,
                            "peak": PEAK_TFLOPS_FP16_DENSE, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS_FP16_DENSE,
                            "traffic": traffic, "traffic_source": traffic_file, "avg_launch_us": 1e6 * avg_s, "launches": g["calls"],
-                           "mfma_issue_tflops": ach * (3 if a.precision == "fp16x3" else 1),
+                           "mfma_issue_tflops": ach * {"fp16x3": 3, "fp16m": 1.5}.get(a.precision, 1),
                            "note": "achieved = algorithmic FLOPs (2MNK, SURVEY.md 8d) / avg launch duration, HIP events on the launch "
-                                   "stream; fp16x3 issues 3 fp16 MFMAs per algorithmic product (mfma_issue_tflops = 3x achieved); "
+                                   "stream; fp16x3 issues 3 fp16 MFMAs per algorithmic product (mfma_issue_tflops = 3x achieved), fp16m 2 fp16 + 1 MX-fp6 "
+                                   "MFMA of the same duration per 32 k (1.5x); "
                                    "traffic = HBM bytes per launch from a rocprofv3 PMC pass of the same command over the same kernel "
                                    "sources (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null if no such pass is committed"}
         # the whole path against the same peak: every algorithmic FLOP the step does (GEMMs, attention, conv-pos, vocoder GEMMs) / step time

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "csrc", "libf5hip.so")
 
 ABI_VERSION = 7  # F5HIP_ABI_VERSION in include/f5hip.h
-PREC_FP32, PREC_FP16X3, PREC_FP16 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16}
+PREC_FP32, PREC_FP16X3, PREC_FP16, PREC_FP16M = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16m": PREC_FP16M}
 
 
 class DitConfigC(C.Structure):
@@ -66,6 +66,7 @@ SYMBOLS = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "f5hip_reset_kernel_stats": (C.c_int, [_P]),
     "f5hip_bench_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "f5hip_bench_mx_pack": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "f5hip_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfigC), C.c_int, C.POINTER(_P)]),
     "f5hip_bigvgan_destroy": (C.c_int, [_P]),
     "f5hip_bigvgan_last_error": (C.c_char_p, [_P]),

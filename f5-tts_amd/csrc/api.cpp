@@ -376,9 +376,9 @@ struct Stage {
 };
 
 // weight operand of a block GEMM in the given operand mode: fp32 blob rows, plain fp16 rows, or packed hi/lo rows
-WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f16* pk) {
+WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f16* pk, const f16* mx = nullptr) {
   if (op == OP_F32) return WOp{w32, nullptr};
-  const void* w = op == OP_F16 ? (const void*)hi : (const void*)pk;
+  const void* w = op == OP_F16 ? (const void*)hi : op == OP_F16M ? (const void*)mx : (const void*)pk;
   const auto it = ctx->walpha.find(w);
   return WOp{w, it == ctx->walpha.end() ? nullptr : it->second};
 }
@@ -394,6 +394,7 @@ float attn_qscale(int dh, bool exact_attn) { return (exact_attn ? 1.0f : 1.44269
 
 bool split_qk(const f5hip_ctx* ctx, int op) { return op == OP_F16X3 && (ctx->attn_impl == 2 || ctx->attn_impl == 4); }
 
+// FP16M: fp16x3 everywhere except the four block GEMMs of the DiT backbone, which read MX lines when ctx->mx_call says so (f5hip_sample)
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
 
 // ---- finalize: derived layouts -------------------------------------------------------------------
@@ -413,7 +414,11 @@ int finalize_impl(f5hip_ctx* ctx) {
   const int64_t skip_elems = skip_concat ? (int64_t)(c.depth / 2) * D * 2 * D : (!unett && c.long_skip_connection) ? D * 2 * D : 0;
   const bool mmdit = c.backbone == 2;
   const int64_t cstream_elems = mmdit ? per_block * (c.depth - 1) + 3 * inner * D : 0;  // text stream; the last block only projects q/k/v
-  HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3) * sizeof(f16)));  // plain hi + packed hi/lo
+  // fp16m (fp16 + MX-fp6 correction lines, common.h): the four block GEMMs of the DiT backbone when every one of them is a launch the
+  // pipelined kernel takes (rows of whole 128-byte lines, at least a 3-stage ring of them) and the fused q|k|v epilogue applies
+  ctx->mx_ok = c.backbone == 0 && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
+  const int64_t mx_elems = ctx->mx_ok ? per_block * c.depth * 2 : 0;
+  HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3 + mx_elems) * sizeof(f16)));  // plain hi + packed hi/lo (+ MX lines)
   f16* hp = ctx->half_pool.as<f16>();
   // weight conditioning (GemmCore::w_alpha): rows of every half-precision weight copy, scale | alpha each
   const int64_t rows_block = 3 * inner + D + F + D;
@@ -444,24 +449,30 @@ int finalize_impl(f5hip_ctx* ctx) {
       bw.qn = W(ctx, ba + "q_norm.weight");
       bw.kn = W(ctx, ba + "k_norm.weight");
     }
-    auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk) -> hipError_t {
+    auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk, f16** mx = nullptr) -> hipError_t {
       hi = hp; hp += rows * K;
       pk = hp; hp += 2 * rows * K;
+      if (mx) { *mx = hp; hp += 2 * rows * K; }
       if (no_cond) {
         hipError_t e = launch_split_f16(src, rows * K, 1.0f, hi, nullptr, st);
         if (e != hipSuccess) return e;
+        if (mx && (e = launch_pack_mx_rows(src, K, rows, (int)K, nullptr, *mx, 1, st)) != hipSuccess) return e;
         return launch_split_f16_packed(src, rows, (int)K, pk, st);
       }
       float* scale = cp; cp += rows;
       float* alpha = cp; cp += rows;
       ctx->walpha[hi] = alpha;
       ctx->walpha[pk] = alpha;
-      return launch_condition_weight(src, (int)rows, (int)K, scale, alpha, hi, pk, st);
+      hipError_t e = launch_condition_weight(src, (int)rows, (int)K, scale, alpha, hi, pk, st);
+      if (e != hipSuccess || !mx) return e;
+      ctx->walpha[*mx] = alpha;  // the MX lines hold the same conditioned rows
+      return launch_pack_mx_rows(src, K, rows, (int)K, scale, *mx, 1, st);
     };
-    HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk));
-    HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk));
-    HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk));
-    HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk));
+    const bool mxw = ctx->mx_ok;
+    HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk, mxw ? &bw.wqkv_mx : nullptr));
+    HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk, mxw ? &bw.wo_mx : nullptr));
+    HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk, mxw ? &bw.w1_mx : nullptr));
+    HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk, mxw ? &bw.w2_mx : nullptr));
     if (bw.wskip) HIPCHK(carve(bw.wskip, D, 2 * D, bw.wskip_hi, bw.wskip_pk));
     if (mmdit) {  // text stream of the block (modules.py:791-814)
       const bool last = i == c.depth - 1;
@@ -943,14 +954,14 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     e.ldvt = (ns + 7) & ~7;
     const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
     e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-    if (split_qk(ctx, op)) {  // lo planes only for what the flash kernel will read
+    if (split_qk(ctx, op == OP_F16M ? OP_F16X3 : op)) {  // lo planes only for what the flash kernel will read
       e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
       if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
     }
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk), ldA, M, 3 * inner, D));
+    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk, bw.wqkv_mx), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -975,6 +986,8 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
   float* x = ctx->xpk.as<float>() + p0 * D;
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const int pk = op == OP_F16X3 ? 1 : 0, wbytes = 2;
+  const bool mx = ctx->mx_call;                     // fp16m: the four block GEMMs read MX lines (same row strides as the hi | lo lines)
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
   f16* a_hi = ctx->a_hi.as<f16>() + p0 * ldA;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
@@ -991,34 +1004,34 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
     const float* md = mods_step + (int64_t)i * 6 * D;
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + D, md, nullptr, a_hi, a_lo, D, st, pk, ldA));
+      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + D, md, nullptr, a_hi, a_lo, D, st, pkb, ldA));
     }
-    CHK(run_qkv(ctx, bw, a_hi, ldA, Mp, n, s0, op, false, wbytes, st, rowinfo, nb * B));
-    CHK(run_attention(ctx, S, s0, n, op, false, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pk, ldO, st, nullptr, 0, cu));
+    CHK(run_qkv(ctx, bw, a_hi, ldA, Mp, n, s0, opb, false, wbytes, st, rowinfo, nb * B));
+    CHK(run_attention(ctx, S, s0, n, op, false, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pkb, ldO, st, nullptr, 0, cu));
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, inner), (double)Mp * inner * wbytes + (double)inner * D * wbytes + 2.0 * Mp * D * 4);
-      GemmCore g = core(o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, Mp, D, inner);
+      GemmCore g = core(o_hi, ldO, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldO, Mp, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.res = x; e.ldres = D;  // every row is a valid row: no mask (modules.py:554-556 zeroes the padding only)
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, nullptr, a_hi, a_lo, D, st, pk, ldA));
+      HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, nullptr, a_hi, a_lo, D, st, pkb, ldA));
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, F, D), (double)Mp * D * wbytes + (double)F * D * wbytes + (double)Mp * F * wbytes);
-      GemmCore g = core(a_hi, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, Mp, F, D);
+      GemmCore g = core(a_hi, ldA, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldA, Mp, F, D);
       EpiStore e = epi_store(nullptr, F, bw.b1, ACT_GELU_TANH);
-      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldF;
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, F), (double)Mp * F * wbytes + (double)F * D * wbytes + 2.0 * Mp * D * 4);
-      GemmCore g = core(f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, Mp, D, F);
+      GemmCore g = core(f_hi, ldF, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldF, Mp, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
   }
   {  // AdaLayerNorm_Final + proj_out on the packed rows, then back to the padded layout
@@ -1098,6 +1111,8 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   }
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const int pk = op == OP_F16X3 ? 1 : 0;      // fp16x3 operands are packed hi/lo rows: lo plane = hi + 32 halves, row stride 2K
+  const bool mx = ctx->mx_call;               // fp16m: the four block GEMMs read MX lines (same row strides as the hi | lo lines)
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
   float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
   f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() + r0 * ldA : nullptr;
@@ -1130,34 +1145,34 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     const float* md = mods_step + (int64_t)i * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp (modules.py:323)
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st, pk, ldA));
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st, pkb, ldA));
     }
-    CHK(run_qkv(ctx, bw, A, ldA, M, n, s0, op, exact_attn, wbytes, st));
-    CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    CHK(run_qkv(ctx, bw, A, ldA, M, n, s0, opb, exact_attn, wbytes, st));
+    CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldO, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner));
+      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldO, M, D, inner));
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, a32, a_hi, a_lo, D, st, pk, ldA));
+      HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + 4 * D, md + 3 * D, a32, a_hi, a_lo, D, st, pkb, ldA));
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = (core(A, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D));
+      GemmCore g = (core(A, ldA, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldA, M, F, D));
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
-      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldF;
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F));
+      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldF, M, D, F));
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
   }
   if (catbuf) {  // x = long_skip_connection(cat(x, residual)) (dit.py:364-365)
@@ -1789,7 +1804,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   if (B <= 0 || n <= 0 || steps <= 0 || nt <= 0) FAIL(F5HIP_ERR_INVALID, "batch, n, nt and steps must be positive");
   if (n > 8192 && ctx->cfg.conv_layers > 0) FAIL(F5HIP_ERR_INVALID, "n=%d exceeds the 8192-frame text position table (dit.py:47)", n);
   if (ode_method != 0 && ode_method != 1) FAIL(F5HIP_ERR_UNSUPPORTED, "ode_method %d: only euler (0) and midpoint (1) are built", ode_method);
-  if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
+  if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16M) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
   for (int b = 0; b < B; ++b)
     if (duration[b] <= 0 || duration[b] > n) FAIL(F5HIP_ERR_INVALID, "duration[%d]=%lld outside (0, n=%d]", b, (long long)duration[b], n);
   hipStream_t st = (hipStream_t)stream;
@@ -1804,6 +1819,10 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
   const int mel = c.mel_dim, D = c.dim;
   const int64_t BN = (int64_t)B * n;
+  // fp16m: MX lines for the block GEMMs where they are built (finalize: mx_ok) and the call is one the pipelined kernel and the flash
+  // epilogue take; anything else runs the call in fp16x3 — never less accurate, so the mode needs no error path
+  ctx->mx_call = precision == F5HIP_PREC_FP16M && ctx->mx_ok && !exact_attn && ctx->attn_kv_split <= 1 &&
+                 (2 * BN + 512) * 4 * std::max<int64_t>(std::max<int64_t>(D, c.ff_inner), (int64_t)c.heads * c.dim_head) < (int64_t)0x7ff00000;
 
   // cfg_strength < 1e-5: the reference evaluates only the conditional branch (cfm.py:166-177); otherwise cond + uncond rows are packed
   const int nb = cfg_strength < 1e-5f ? 1 : 2;

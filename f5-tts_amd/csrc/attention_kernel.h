@@ -38,6 +38,46 @@ struct FlashArgs {
   int pp_prio;  // flash_pp_kernel: raise the wave priority during the softmax phase (A/B switch F5HIP_ATTN_PP_PRIO, default on)
 };
 
+// The operand row of the out-projection from a lane's share of a normalised output row: lane (row, hi) owns O[32 db + 8 c + 4 hi + e] =
+// o[db][4 c + e].  o_packed 0: plain fp16 rows, 1: packed hi | lo lines (fp16x3), 2: MX lines (fp16m, common.h) — the lane's 16 features of
+// a 32-block are exactly the k-set of P_hi, so the pack needs no lane exchange.
+__device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16 (&o)[2], float inv, int64_t row, int hh, int hi) {
+  const int64_t orow = row * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
+  if (a.o_packed == 2) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float x[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) x[t] = o[db][t] * inv;
+      uint32_t hv[8], pw[8];
+      mx_pack16<false>(x, hv, pw);
+      char* line = reinterpret_cast<char*>(a.o + orow) + (int64_t)(hh * 2 + db) * 128;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<uint2*>(line + (8 * c + 4 * hi) * 2) = make_uint2(hv[2 * c], hv[2 * c + 1]);
+      *reinterpret_cast<uint4*>(line + 64 + 32 * hi) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+      *reinterpret_cast<uint4*>(line + 80 + 32 * hi) = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+    }
+    return;
+  }
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
+      f16x4 oh, ol;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = o[db][4 * c + e] * inv;
+        f16 h, l;
+        split_f16(v, h, l);
+        oh[e] = h;
+        ol[e] = l;
+      }
+      *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
+      if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
+    }
+}
+
 // NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
 // their rounding matters ~10x more than that of P and V: NSPLIT = 3 with PVSPLIT = 1 keeps near-fp32 scores at 4 instead of 6
 // MFMAs per key-query pair.
@@ -326,25 +366,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     return;
   }
   if (qrow < q_end) {
-    const float inv = 1.0f / l_tot;
-    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
-        f16x4 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = o[db][4 * c + e] * inv;
-          f16 h, l;
-          split_f16(v, h, l);
-          oh[e] = h;
-          ol[e] = l;
-        }
-        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
-        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
-      }
+    flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
   }
 }
 
@@ -606,25 +628,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
 
   const float l_tot = VSUM ? l_run + __shfl_xor(l_run, 32, 64) : l_run;
   if (qrow < q_end) {
-    const float inv = 1.0f / l_tot;
-    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
-        f16x4 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = o[db][4 * c + e] * inv;
-          f16 h, l;
-          split_f16(v, h, l);
-          oh[e] = h;
-          ol[e] = l;
-        }
-        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
-        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
-      }
+    flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
   }
 }
 
@@ -861,25 +865,7 @@ __global__ __launch_bounds__(512, 1) void flash_pp_kernel(FlashArgs a) {
   if (!half) phase_end();
 
   if (qrow < q_end) {
-    const float inv = 1.0f / l_run;
-    const int64_t orow = (a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow) * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int d = pk_off(hh * 64 + db * 32 + 8 * c + 4 * hi, a.o_packed);
-        f16x4 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = o[db][4 * c + e] * inv;
-          f16 h, l;
-          split_f16(v, h, l);
-          oh[e] = h;
-          ol[e] = l;
-        }
-        *reinterpret_cast<f16x4*>(a.o + orow + d) = oh;
-        if (a.o_lo) *reinterpret_cast<f16x4*>(a.o_lo + orow + d) = ol;
-      }
+    flash_store_row(a, o, 1.0f / l_run, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
   }
 }
 

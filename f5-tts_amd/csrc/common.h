@@ -124,6 +124,64 @@ __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
   lo = (f16)(v - (float)hi);
 }
 
+// ---- fp16 + MX-fp6 corrections (operand mode fp16m, round 4) -----------------------------------------------------------------------------
+// The three-term product A_hi W_hi + A_hi W_lo + A_lo W_hi costs three fp16 MFMAs.  Its two correction terms are 2^-11 of the first and
+// only need ~4 significant bits per factor: on gfx950 they fit ONE v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 operands per 32 k, which runs
+// at 4x the fp16 rate (tools/probes/mx6_probe.hip: 2 fp16 + 1 fp6 MFMA take 128 ns where 6 fp16 MFMAs take 268, every CU busy) — 1.5
+// MFMA-equivalents per product instead of 3, at the accuracy of the split (oracle/operand_scheme_emulation.py: 3.07e-4 against 2.67e-4 on
+// the full-size golden with all four block GEMMs in this form).
+//
+// Operand line of the mode = one 32-k block of one row, 128 bytes like the fp16x3 line:
+//   [ 32 hi halves (k order) | P_0 : 32 bytes | P_1 : 32 bytes ],   P_h = 24 bytes of 32 e2m3 elements, 1 scale word, 1 zero word.
+// P_h covers the 16 k-values an accumulator lane of half-wave h owns in a 32-channel tile, k_t = 8 (t / 4) + 4 h + (t % 4), t = 0..15 —
+// so the GEMM and attention epilogues pack it from registers, no lane exchange.  Its elements 2 t, 2 t + 1 are, for an ACTIVATION row,
+// (c6(x[k_t]), l6(x[k_t])) and for a WEIGHT row (l6(w[k_t]), c6(w[k_t])), where c6(v) = e2m3(v / S) is the coarse value, l6(v) =
+// e2m3((v - fp16(v)) 2^11 / S) the fp16 rounding remainder, and S = 2^(E - 2) the block scale (E = exponent of the largest |v| of the 16).
+// The fp6 MFMA multiplies element by element, so it sums c6(x) l6(w) + l6(x) c6(w) over the 32 k of the block, with the per-lane scale
+// bytes 2^(E_x - 2 - 11) and 2^(E_w - 2): exactly the two correction terms.  MFMA lane (row, half g) reads P_g: 32 bytes = the 8-register
+// operand (registers 6, 7 are ignored by the instruction for fp6; register 6 is the scale word, its byte 0 the E8M0 exponent).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x6 __attribute__((ext_vector_type(6)));
+constexpr int MX_MIN_EXP = 16;  // smallest biased exponent a block scale is computed from (keeps both scale bytes > 0; such blocks are ~0)
+
+// 16 values (index t = 4 q + e <-> k = 8 q + 4 h + e) -> their 16 fp16 `hi` halves (two per dword, t order) and the P_h words
+template <bool WEIGHT>
+__device__ __forceinline__ void mx_pack16(const float (&v)[16], uint32_t (&hi)[8], uint32_t (&p)[8]) {
+  float amax = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) amax = fmaxf(amax, fabsf(v[t]));
+  union { float f; uint32_t u; } cv;
+  cv.f = amax;
+  int ex = (int)((cv.u >> 23) & 0xffu);
+  ex = ex < MX_MIN_EXP ? MX_MIN_EXP : ex;
+  const int sb = ex - 2;  // biased exponent of S: the largest element lands in [4, 8)
+  cv.u = (uint32_t)sb << 23;
+  const float S = cv.f;
+  f32x16 c, l;
+#pragma unroll
+  for (int t = 0; t < 16; t += 2) {
+    const f16 h0 = (f16)v[t], h1 = (f16)v[t + 1];
+    union { f16 h[2]; uint32_t u; } pk;
+    pk.h[0] = h0; pk.h[1] = h1;
+    hi[t >> 1] = pk.u;
+    c[t] = v[t]; c[t + 1] = v[t + 1];
+    l[t] = (v[t] - (float)h0) * 2048.0f;  // exact: the remainder has <= 13 significant bits, 2^11 is a power of two
+    l[t + 1] = (v[t + 1] - (float)h1) * 2048.0f;
+  }
+  const u32x6 r = WEIGHT ? __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(l, c, S) : __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(c, l, S);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) p[i] = r[i];
+  p[6] = (uint32_t)(WEIGHT ? sb : sb - 11);
+  p[7] = 0u;
+}
+
+// acc += (the two correction terms of one 32-k block): W's P words in (w0, w1), the activation's in (a0, a1), 16 bytes each
+__device__ __forceinline__ void mx_mma(f32x16& acc, const uint4& w0, const uint4& w1, const uint4& a0, const uint4& a1) {
+  const i32x8 wv = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+  const i32x8 av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc, 2, 2, 0, (int)w1.z, 0, (int)a1.z);
+}
+
 // wave-uniform: does any lane hold the predicate?
 __device__ __forceinline__ bool f5_wave_any(bool pred) {
 #ifdef F5_HIPEMU

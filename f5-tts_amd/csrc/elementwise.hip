@@ -99,6 +99,119 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp16m operand rows (common.h "fp16 + MX-fp6 corrections"): LayerNorm producer and one-time / test packing
+// ---------------------------------------------------------------------------------------------
+// store one half-line: the 16 hi halves of channels 8 q + 4 h + e (two lanes of a pair fill the 64-byte hi region) and the lane's P words
+__device__ __forceinline__ void mx_store_half(char* line, int h, const uint32_t (&hi)[8], const uint32_t (&p)[8]) {
+  // neighbouring lanes (h = 0, 1) hold the two 8-byte halves of every 16-byte chunk q: lane 0 collects chunks 0 and 1, lane 1 chunks 2 and 3
+  uint32_t r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (uint32_t)__shfl_xor((int)(h ? hi[i] : hi[4 + i]), 1, 64);
+  if (h == 0) {
+    *reinterpret_cast<uint4*>(line) = make_uint4(hi[0], hi[1], r[0], r[1]);
+    *reinterpret_cast<uint4*>(line + 16) = make_uint4(hi[2], hi[3], r[2], r[3]);
+  } else {
+    *reinterpret_cast<uint4*>(line + 32) = make_uint4(r[0], r[1], hi[4], hi[5]);
+    *reinterpret_cast<uint4*>(line + 48) = make_uint4(r[2], r[3], hi[6], hi[7]);
+  }
+  *reinterpret_cast<uint4*>(line + 64 + 32 * h) = make_uint4(p[0], p[1], p[2], p[3]);
+  *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[4], p[5], p[6], p[7]);
+}
+
+// LayerNorm / RMSNorm / copy (+ affine | AdaLN modulation) -> MX operand rows.  One wave per row; in pass b lane L owns the 16 channels
+// 32 (32 b + L / 2) + 8 q + 4 (L % 2) + e — exactly one P_h of common.h, so the pack needs no lane exchange (the loads are 16-byte pieces
+// at a 32-byte stride; a lane pair covers a 128-byte line over the four q).
+template <int NB>  // passes: D <= 1024 NB
+__global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
+                                                            const float* __restrict__ weight, const float* __restrict__ bias,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, f16* out16,
+                                                            int64_t ldo16, int mode) {
+  const int lane = threadIdx.x & 63, h = lane & 1;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  const float* A = weight ? weight : scale;
+  const float* Bp = weight ? bias : shift;
+  float4 v[NB][4], pa[NB][4], pb[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 32 * (32 * b + (lane >> 1)) + 8 * q + 4 * h;
+      const bool in = c < D;
+      v[b][q] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pa[b][q] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[b][q] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  float sum = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum += (v[b][q].x + v[b][q].y) + (v[b][q].z + v[b][q].w);
+  const float mean = mode == 0 ? wave_sum(sum) / (float)D : 0.f;
+  float sq = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 32 * (32 * b + (lane >> 1)) + 8 * q + 4 * h;
+      if (c < D) {
+        const float a0 = v[b][q].x - mean, a1 = v[b][q].y - mean, a2 = v[b][q].z - mean, a3 = v[b][q].w - mean;
+        sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    }
+  float rstd;
+  if (mode == 0) rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
+  else if (mode == 1) rstd = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
+  else rstd = 1.0f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int blk = 32 * b + (lane >> 1);
+    float y[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float t[4] = {(v[b][q].x - mean) * rstd, (v[b][q].y - mean) * rstd, (v[b][q].z - mean) * rstd, (v[b][q].w - mean) * rstd};
+      if (weight) { t[0] = t[0] * pa[b][q].x + pb[b][q].x; t[1] = t[1] * pa[b][q].y + pb[b][q].y; t[2] = t[2] * pa[b][q].z + pb[b][q].z; t[3] = t[3] * pa[b][q].w + pb[b][q].w; }
+      else if (scale) { t[0] = t[0] * (1.0f + pa[b][q].x) + pb[b][q].x; t[1] = t[1] * (1.0f + pa[b][q].y) + pb[b][q].y;
+                        t[2] = t[2] * (1.0f + pa[b][q].z) + pb[b][q].z; t[3] = t[3] * (1.0f + pa[b][q].w) + pb[b][q].w; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[4 * q + e] = t[e];
+    }
+    uint32_t hi[8], p[8];
+    mx_pack16<false>(y, hi, p);
+    // (whole waves run the exchange inside mx_store_half; blocks past D of the last pass are dropped here — D % 32 == 0, so both lanes of a pair agree)
+    char* line = reinterpret_cast<char*>(out16 + (int64_t)row * ldo16) + (int64_t)blk * 128;
+    if (32 * blk < D) mx_store_half(line, h, hi, p);
+    else { uint32_t sink[4]; for (int i = 0; i < 4; ++i) sink[i] = (uint32_t)__shfl_xor((int)hi[i], 1, 64); (void)sink; }
+  }
+}
+
+// [rows, K] fp32 (row stride ld) x rowscale[r] -> MX operand rows [rows, 2K halves]; WEIGHT selects which of (coarse, remainder) leads in P
+// (common.h).  One thread per (row, 32-k block, half): finalize (weights) and tests / microbenchmarks (activations), not a hot path.
+template <bool WEIGHT>
+__global__ __launch_bounds__(256) void pack_mx_rows_kernel(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst) {
+  const int upr = K / 16;  // units per row
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (the grid covers whole lane pairs: K / 16 is even)
+  if (i >= rows * upr) return;
+  const int64_t r = i / upr;
+  const int u = (int)(i - r * upr), blk = u >> 1, h = u & 1;
+  const float rs = rowscale ? rowscale[r] : 1.0f;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(src + r * ld + 32 * blk + 8 * q + 4 * h);
+    v[4 * q] = t.x * rs; v[4 * q + 1] = t.y * rs; v[4 * q + 2] = t.z * rs; v[4 * q + 3] = t.w * rs;
+  }
+  uint32_t hi[8], p[8];
+  mx_pack16<WEIGHT>(v, hi, p);
+  char* line = reinterpret_cast<char*>(dst + r * 2 * K) + (int64_t)blk * 128;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(line + (8 * q + 4 * h) * 2) = make_uint2(hi[2 * q], hi[2 * q + 1]);
+  *reinterpret_cast<uint4*>(line + 64 + 32 * h) = make_uint4(p[0], p[1], p[2], p[3]);
+  *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[4], p[5], p[6], p[7]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // text embedding (reference model/backbones/dit.py:86-127)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void text_embed_kernel(const int32_t* __restrict__ tok, const uint8_t* __restrict__ valid,
@@ -443,6 +556,13 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps
                             hipStream_t s, int pk16, int64_t ldo16, int mode) {
   if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
   if (ldo16 == 0) ldo16 = ldo;
+  if (pk16 == 2) {  // MX operand rows (fp16m): a kernel of its own lane layout
+    if (D % 32 || out32 || !out16 || ldo16 % 8 || (reinterpret_cast<uintptr_t>(out16) & 15) || (weight && scale)) return hipErrorInvalidValue;
+    dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (D <= 1024) hipLaunchKernelGGL(layernorm_mx_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode);
+    else hipLaunchKernelGGL(layernorm_mx_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode);
+    return hipGetLastError();
+  }
   // paired 16-byte half stores: whole pairs of 4-channel groups per row, 16-byte aligned rows
   const int pair16 = out16 && D % 8 == 0 && ldo16 % 8 == 0 && (reinterpret_cast<uintptr_t>(out16) & 15) == 0 &&
                      (!out16_lo || (reinterpret_cast<uintptr_t>(out16_lo) & 15) == 0);
@@ -578,6 +698,14 @@ hipError_t launch_condition_weight(const float* src, int rows, int K, float* sca
   if (K % 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(row_pow2_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, scale, alpha);
   hipLaunchKernelGGL(split_f16_rows_kernel, dim3(grid_1d((int64_t)rows * K)), dim3(256), 0, s, src, (int64_t)rows, K, scale, hi, pk);
+  return hipGetLastError();
+}
+hipError_t launch_pack_mx_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s) {
+  if (K % 32 || ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+  const int64_t units = rows * (K / 16);
+  const dim3 grid((unsigned)((units + 255) / 256));
+  if (weight) hipLaunchKernelGGL(pack_mx_rows_kernel<true>, grid, dim3(256), 0, s, src, ld, rows, K, rowscale, dst);
+  else hipLaunchKernelGGL(pack_mx_rows_kernel<false>, grid, dim3(256), 0, s, src, ld, rows, K, rowscale, dst);
   return hipGetLastError();
 }
 hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi, f16* lo, hipStream_t s) {

@@ -177,9 +177,10 @@ F5_PPV(70, 3, 1, 2, 2, 3, 3, +2);  // 192x64,  2 x 4 waves of 96x32, 3 stages = 
 
 // what the pipelined kernel needs from a launch: fp16 operands whose rows are whole 128-byte k-tiles (at least 3 of them), channel
 // count a multiple of 32, one batch, every byte offset of the operands within 31 bits
+constexpr int pp_planes(int nsplit) { return nsplit == 1 ? 1 : 2; }  // 128-byte lines hold 64 k (plain fp16) or 32 k (hi | lo, hi | MX words)
 template <int NSPLIT>
 bool pp_applies(const GemmCore& g, int batch) {
-  const int64_t kbytes = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1);
+  const int64_t kbytes = (int64_t)g.K * 2 * pp_planes(NSPLIT);
   return batch == 1 && g.strideA == 0 && g.strideW == 0 && kbytes % GEMM_KTB == 0 && kbytes / GEMM_KTB >= 3 && g.N % 32 == 0 && g.M >= 1 &&
          (int64_t)g.a_rows * g.lda * 2 < (int64_t)0x7ff00000 && (int64_t)g.w_rows * g.ldw * 2 < (int64_t)0x7ff00000;
 }
@@ -195,11 +196,11 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
   static_assert(C::KSP * C::KSS == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the split tiles reuses the ring");
   if constexpr (C::KSS > 1) {  // even / odd tiles alternate the fragment buffers: an even number of k-tiles, a whole pipeline
-    const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
+    const int64_t kt = (int64_t)g.K * 2 * pp_planes(NSPLIT) / GEMM_KTB;
     if (kt % 2 != 0 || kt < C::NS + 1) return PP_NOT_APPLICABLE;
   }
   if constexpr (C::KSP > 1) {  // each group needs its own whole pipeline: k-tiles split evenly, at least NS + 1 per group
-    const int64_t kt = (int64_t)g.K * 2 * (NSPLIT == 3 ? 2 : 1) / GEMM_KTB;
+    const int64_t kt = (int64_t)g.K * 2 * pp_planes(NSPLIT) / GEMM_KTB;
     if (kt % C::KSP != 0 || kt / C::KSP < C::NS + 1) return PP_NOT_APPLICABLE;
   }
   auto kern = gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, C::NS, C::JG, Epi, ABL, C::KSP, C::KSS>;
@@ -214,8 +215,19 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   return hipGetLastError();
 }
 
+// the tiles instantiated for MX lines (NSPLIT 2): no k-step split (the fp6 correction of a line belongs to one wave), and only the tiles
+// pick_pp_variant can choose in that mode plus their microbenchmark alternatives — every instantiation is a minute of build time
+#define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66)
 template <int NSPLIT, typename Epi>
 hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s) {
+  if constexpr (NSPLIT == 2) {
+    switch (variant) {
+#define F5_CASE(ID) case ID: return launch_pp_one<2, ID, Epi>(g, e, s);
+      F5_MX_TILES(F5_CASE)
+#undef F5_CASE
+      default: return PP_NOT_APPLICABLE;
+    }
+  } else {
   switch (variant) {
     case 50: return launch_pp_one<NSPLIT, 50, Epi>(g, e, s);
     case 51: return launch_pp_one<NSPLIT, 51, Epi>(g, e, s);
@@ -240,12 +252,13 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
     case 70: return launch_pp_one<NSPLIT, 70, Epi>(g, e, s);
     default: return PP_NOT_APPLICABLE;
   }
+  }
 }
 
 // Tile choice.  A launch costs rounds x (time of one workgroup), so prefer the tile whose workgroup count fills whole rounds of the CUs
 // with the largest wave tiles; measured tables: DESIGN.md section 4 (tools/kernel_bench.py, profiles/r02*).
 inline int64_t ktiles_of(const GemmCore& g, int nsplit_planes) { return (int64_t)g.K * 2 * nsplit_planes / GEMM_KTB; }
-int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
+int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool mx = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
   static const int forced = [] { const char* e = getenv("F5HIP_PP_VARIANT"); return e ? atoi(e) : -1; }();  // tuning knob; 0 = never use the pipelined kernel
   if (forced >= 0) return forced;
   static const int f3072 = [] { const char* e = getenv("F5HIP_PP_VARIANT_N3072"); return e ? atoi(e) : -1; }();  // per-shape tuning knobs (tools/)
@@ -260,6 +273,13 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false) {  /
   //   2k .. 4k   (B = 1, one chain of 2 x 1406 rows): one round of 240 workgroups — 192x192 for N = 3072 (62 us against 84 for the
   //              128x64 tiles of gemm.h), 192x128 / 8 waves for N = 2048 (41 against 53), 96x128 for N = 1024 (26 / 45 against 32 / 52)
   //   < 2k       (B = 1, one CFG chain of 1406 rows): 192x128 / 8 waves for N = 3072, 96x128 otherwise
+  if (mx) {  // MX lines (fp16m): the same regimes without the k-step-split tiles; small launches stay on the pipelined kernel (no fallback)
+    if (g.M >= 40000) return 50;
+    if (g.M >= 4096) return qkv ? 61 : g.N >= 2048 ? 62 : g.M >= 8192 ? 62 : 63;
+    const bool ksp_ok = ktiles_of(g, 2) % 2 == 0 && ktiles_of(g, 2) / 2 >= 3;
+    if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : ksp_ok ? 66 : 59;
+    return g.N >= 3072 ? 55 : ksp_ok ? 66 : 59;
+  }
   if (g.M < 512) return 0;  // a handful of row tiles: the generic small tiles
   if (g.M >= 40000) return 50;
   // A few rounds (B = 2 .. 16): the 4-wave, 2-stage tiles that fit TWO workgroups per CU - the two run out of phase, one's prologue and
@@ -289,20 +309,21 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false) {  /
 template <int NSPLIT>
 hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   if (!pp_applies<NSPLIT>(g, batch)) return PP_NOT_APPLICABLE;
-  if (variant < 0) variant = pick_pp_variant(g, NSPLIT == 3 ? 2 : 1);
+  if (variant < 0) variant = pick_pp_variant(g, pp_planes(NSPLIT), false, NSPLIT == 2);
   if (variant < 50) return PP_NOT_APPLICABLE;
-  constexpr bool PK = NSPLIT == 3;
+  constexpr bool PK = NSPLIT != 1;
+  constexpr int FMT = NSPLIT == 3 ? 1 : NSPLIT == 2 ? 2 : 0;  // the operand format the consumer of out16 reads = this launch's own
   const bool plain_out = e.alpha == 1.f && e.bias && !e.out2 && !e.zdiv;
   if (plain_out && e.out16 && !e.out32 && !e.res && !e.colscale && !e.rowmask && (e.act == ACT_GELU_TANH || e.act == ACT_NONE) &&
-      (PK ? (e.pk16 && e.out16_lo == e.out16 + 32 && e.ldo16 >= 2 * (int64_t)g.N) : (!e.out16_lo && !e.pk16))) {
+      (PK ? (e.pk16 == FMT && e.out16_lo == e.out16 + 32 && e.ldo16 >= 2 * (int64_t)g.N) : (!e.out16_lo && !e.pk16))) {
     const int64_t ld = PK ? e.ldo16 : (e.ldo16 ? e.ldo16 : e.ldo);
     if ((int64_t)(g.M + 512) * ld * 2 >= (int64_t)0x7ff00000) return PP_NOT_APPLICABLE;
-    if constexpr (PK) {  // microbenchmark ablations of three tiles: variant = 1000 * code + id; code 1 no epilogue, 2 epilogue without stores,
+    if constexpr (NSPLIT == 3) {  // microbenchmark ablations of three tiles: variant = 1000 * code + id; code 1 no epilogue, 2 epilogue without stores,
                          // 4 no LDS-DMA in the loop, 8 no MFMAs, 12 neither (fragment reads + barriers + epilogue)
       if (variant >= 1000 && e.act == ACT_GELU_TANH) {
-        const PpEpiAct16<true, ACT_GELU_TANH> ep{e.bias, e.out16, ld, g.M, g.N};
-        const PpEpiAct16<true, ACT_GELU_TANH, 1> ens{e.bias, e.out16, ld, g.M, g.N};
-        const PpEpiAct16<true, ACT_GELU_TANH, 2> eds{e.bias, e.out16, ld, g.M, g.N};
+        const PpEpiAct16<1, ACT_GELU_TANH> ep{e.bias, e.out16, ld, g.M, g.N};
+        const PpEpiAct16<1, ACT_GELU_TANH, 1> ens{e.bias, e.out16, ld, g.M, g.N};
+        const PpEpiAct16<1, ACT_GELU_TANH, 2> eds{e.bias, e.out16, ld, g.M, g.N};
         switch (variant) {
 #define F5_ABL(ID)                                                          \
   case 1000 + ID: return launch_pp_one<3, ID, decltype(ep), 1>(g, ep, s);   \
@@ -320,8 +341,8 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
         }
       }
     }
-    if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<PK, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
-    return launch_pp<NSPLIT>(g, PpEpiAct16<PK, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
+    if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
+    return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
   }
   if (plain_out && e.act == ACT_NONE && e.out32 && e.res == e.out32 && e.ldres == e.ldo && !e.out16 && (!e.rowmask || (e.mask_mode == 1 && e.smask == 0))) {
     if ((int64_t)(g.M + 512) * e.ldo * 4 >= (int64_t)0x7ff00000) return PP_NOT_APPLICABLE;
@@ -338,12 +359,17 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   // default: groups of 4 row-tiles once the grid is many waves deep (+2-5 % at M >= 22k, L2-miss traffic / 2), plain order otherwise
   if (g.group_m == 0) g.group_m = gm_env >= 0 ? gm_env : (g.M >= 8192 ? 4 : 1);
   if constexpr (std::is_same<Epi, EpiStore>::value) {
+    if (op == OP_F16M) {  // MX lines: the pipelined kernel or nothing (the engine checks the shapes before it chooses the mode)
+      const hipError_t r = (variant < 0 || variant >= 50) ? try_pp_store<2>(g, e, batch, variant, s) : PP_NOT_APPLICABLE;
+      return r == PP_NOT_APPLICABLE ? hipErrorInvalidValue : r;
+    }
     if ((variant < 0 || variant >= 50) && (op == OP_F16 || op == OP_F16X3)) {
       const hipError_t r = op == OP_F16 ? try_pp_store<1>(g, e, batch, variant, s) : try_pp_store<3>(g, e, batch, variant, s);
       if (r != PP_NOT_APPLICABLE) return r;
       if (variant >= 50) return hipErrorInvalidValue;  // an explicitly requested pipelined tile that does not take this launch
     }
   }
+  if (op == OP_F16M) return hipErrorInvalidValue;
   switch (op) {
     case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, variant, s);
     case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, variant, s);
@@ -367,11 +393,11 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
   e.fast = 0;
   if (!generic) epi_qkv_prepare(e, g0.M);  // fast = 1 when its preconditions hold
   // the pipelined kernel: half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour
-  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
+  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
       (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
     GemmCore g = g0;
     if (g.group_m == 0) g.group_m = g.M >= 8192 ? 4 : 1;
-    const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true);
+    const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true, op == OP_F16M);
     // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
     const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
     const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
@@ -382,10 +408,11 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
       p.nseq = e.nseq; p.heads = e.heads; p.pe_heads = e.pe_heads; p.slab_n = e.slab_n; p.pos_off = e.pos_off; p.ldvt = (int)e.ldvt;
       p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
       p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb; p.rowinfo = e.rowinfo;
-      const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
+      const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : op == OP_F16M ? launch_pp<2>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
       if (r != PP_NOT_APPLICABLE) return r;
     }
   }
+  if (op == OP_F16M) return hipErrorInvalidValue;  // MX lines: no generic-kernel fallback
   const int gv = want >= 0 && want < 50 ? want : -1;
   if (e.fast) {
     static_assert(sizeof(EpiQKVFast) == sizeof(EpiQKV), "same fields");
@@ -410,15 +437,31 @@ hipError_t set_pp_attrs_ids(std::integer_sequence<int, IDS...>) {
   ((e = e == hipSuccess ? set_pp_attr<NSPLIT, 50 + IDS, Epi>() : e), ...);
   return e;
 }
+template <typename Epi>
+hipError_t set_pp_attrs_mx() {
+  hipError_t e = hipSuccess;
+#define F5_ATTR(ID) e = e == hipSuccess ? set_pp_attr<2, ID, Epi>() : e;
+  F5_MX_TILES(F5_ATTR)
+#undef F5_ATTR
+  return e;
+}
 template <int NSPLIT>
 hipError_t set_pp_attrs() {  // every tile id 50 .. 70 x every wave-tile epilogue launch_pp can be asked for
-  constexpr auto ids = std::make_integer_sequence<int, 21>{};
   hipError_t e;
-  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3, ACT_GELU_TANH>>(ids)) != hipSuccess) return e;
-  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3, ACT_NONE>>(ids)) != hipSuccess) return e;
-  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<true>>(ids)) != hipSuccess) return e;
-  if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<false>>(ids)) != hipSuccess) return e;
-  return set_pp_attrs_ids<NSPLIT, PpEpiQKV>(ids);
+  if constexpr (NSPLIT == 2) {
+    if ((e = set_pp_attrs_mx<PpEpiAct16<2, ACT_GELU_TANH>>()) != hipSuccess) return e;
+    if ((e = set_pp_attrs_mx<PpEpiAct16<2, ACT_NONE>>()) != hipSuccess) return e;
+    if ((e = set_pp_attrs_mx<PpEpiGateRes<true>>()) != hipSuccess) return e;
+    if ((e = set_pp_attrs_mx<PpEpiGateRes<false>>()) != hipSuccess) return e;
+    return set_pp_attrs_mx<PpEpiQKV>();
+  } else {
+    constexpr auto ids = std::make_integer_sequence<int, 21>{};
+    if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3 ? 1 : 0, ACT_GELU_TANH>>(ids)) != hipSuccess) return e;
+    if ((e = set_pp_attrs_ids<NSPLIT, PpEpiAct16<NSPLIT == 3 ? 1 : 0, ACT_NONE>>(ids)) != hipSuccess) return e;
+    if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<true>>(ids)) != hipSuccess) return e;
+    if ((e = set_pp_attrs_ids<NSPLIT, PpEpiGateRes<false>>(ids)) != hipSuccess) return e;
+    return set_pp_attrs_ids<NSPLIT, PpEpiQKV>(ids);
+  }
 }
 }  // namespace
 
@@ -435,6 +478,8 @@ hipError_t init_gemm_kernels() {
   if ((e = set_glds_attrs<EpiStore>()) != hipSuccess || (e = set_glds_attrs<EpiQKV>()) != hipSuccess || (e = set_glds_attrs<EpiQKVFast>()) != hipSuccess) return e;
 #endif
   e = set_pp_attrs<1>();
+  if (e != hipSuccess) return e;
+  e = set_pp_attrs<2>();
   if (e != hipSuccess) return e;
   return set_pp_attrs<3>();
 }

@@ -111,9 +111,11 @@ __device__ __forceinline__ uint4 widen(uint32_t (&a)[2], uint32_t (&b)[2]) {
 // + 0..3 (acc[j][i][4 q + e]).  Rows >= M and channels >= N fall outside the buffer descriptors / are skipped per 32-channel tile.
 
 // FeedForward first linear (modules.py:353-364): tanh-GELU(acc + bias) -> the operand rows of the second linear, packed hi/lo (PK) or plain fp16
-template <bool PK, int ACT, int NOSTORE = 0>  // NOSTORE: microbenchmark ablations — 1: the arithmetic without the stores, 2: the same bytes
+// FMT: 0 plain fp16 rows, 1 packed hi | lo rows (fp16x3), 2 MX lines (fp16m: hi | P_0 | P_1, common.h)
+template <int FMT, int ACT, int NOSTORE = 0>  // NOSTORE: microbenchmark ablations — 1: the arithmetic without the stores, 2: the same bytes
                                              // stored lane-linearly (1 KB runs per instruction; WRONG layout: what does the row-strided pattern cost?)
 struct PpEpiAct16 {
+  static constexpr bool PK = FMT != 0;
   const float* bias;
   f16* out;          // [M, ld] halves: PK: [N/32][32 hi | 32 lo], ld = 2N;  plain: [N], ld = N
   int64_t ld;
@@ -133,6 +135,23 @@ struct PpEpiAct16 {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const uint32_t row = (uint32_t)(m_w + 32 * j + r) * (uint32_t)(ld * 2);
+        if constexpr (FMT == 2) {  // the lane's 16 channels 8 q + 4 h + e are exactly the k-set of P_h
+          float x[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = apply_act(ACT, acc[j][i][4 * q + e] + (e == 0 ? b[q].x : e == 1 ? b[q].y : e == 2 ? b[q].z : b[q].w));
+          uint32_t hv[8], pw[8];
+          mx_pack16<false>(x, hv, pw);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            uint32_t a2[2] = {hv[4 * p], hv[4 * p + 1]}, b2[2] = {hv[4 * p + 2], hv[4 * p + 3]};
+            pp::store_b128(R, row + col + (uint32_t)(16 * p + 8 * h) * 2u, pp::widen(a2, b2));
+          }
+          pp::store_b128(R, row + col + 64u + 32u * (uint32_t)h, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+          pp::store_b128(R, row + col + 80u + 32u * (uint32_t)h, make_uint4(pw[4], pw[5], pw[6], pw[7]));
+          continue;
+        }
         uint32_t hi[4][2], lo[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -146,7 +165,7 @@ struct PpEpiAct16 {
           if constexpr (NOSTORE == 2) {
             const uint32_t d = (uint32_t)(((m_w >> 5) + j) * (N >> 5) + (nb >> 5)) * 4096u + (uint32_t)p * 2048u + (uint32_t)lane * 16u;
             pp::store_b128(R, d, pp::widen(hi[2 * p], hi[2 * p + 1]));
-            if constexpr (PK) pp::store_b128(R, d + 1024u, pp::widen(lo[2 * p], lo[2 * p + 1]));
+            if constexpr (FMT == 1) pp::store_b128(R, d + 1024u, pp::widen(lo[2 * p], lo[2 * p + 1]));
             continue;
           }
           if constexpr (NOSTORE == 1) {
@@ -155,7 +174,7 @@ struct PpEpiAct16 {
             continue;
           }
           pp::store_b128(R, o, pp::widen(hi[2 * p], hi[2 * p + 1]));
-          if constexpr (PK) pp::store_b128(R, o + 64u, pp::widen(lo[2 * p], lo[2 * p + 1]));
+          if constexpr (FMT == 1) pp::store_b128(R, o + 64u, pp::widen(lo[2 * p], lo[2 * p + 1]));
         }
       }
     }
@@ -379,7 +398,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   constexpr int NW = WGM * WGN;  // waves of one group
   constexpr int DW = NW * KSS;   // waves that fill one (sub-)stage
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
-  constexpr int NPL = (NSPLIT == 3) ? 2 : 1;
+  constexpr bool MX = NSPLIT == 2;                 // fp16m lines: 32 hi halves | P_0 | P_1 (common.h) — 2 fp16 MFMAs + 1 fp6 MFMA per 32 k
+  constexpr int NPL = (NSPLIT == 3 || MX) ? 2 : 1;
+  constexpr int NFR = MX ? 3 : NPL;                // 16-byte fragments per tile: hi | lo, or hi | the two halves of the lane's P words
   constexpr int KS = NPL == 2 ? 2 : 4;             // 16-wide MFMA k-steps per 128-byte line
   constexpr int KSL = KS / KSS;                    // k-steps one group multiplies per k-tile
   constexpr int PA = BM / 8 / DW, PW = BN / 8 / DW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
@@ -390,6 +411,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   static_assert(TM % JG == 0 && NS >= 2 && NS <= 5 && (NS - 1) * LPT <= 63 && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2,
                 "slot / ring shape (the counted waits are 6-bit immediates)");
   static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
+  static_assert(!MX || KSS == 1, "the fp6 correction needs both k-steps' owner: no k-step split of MX lines");
   F5_DYN_LDS(char, smem_all);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -452,17 +474,19 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   // fragment addressing: lane (row = lane & 31, hi = lane >> 5) reads logical chunk 2 ks + hi (+4 for the lo plane) of its row
   const uint32_t lds0 = pp::lds_base(smem);
   const int frow = (lane & 31) * GEMM_KTB, fswz = ((lane & 31) >> 1) & 7, fhi = lane >> 5;
-  uint32_t fa_addr[NPL][KSL], fw_addr[NPL][KSL];  // + stage offset (updated per k-tile) + 4096 * tile index (immediate)
+  // MX lines: chunks 4 + 2 fhi and 5 + 2 fhi are the lane's P words, read with the line's LAST k-step
+  uint32_t fa_addr[NFR][KSL], fw_addr[NFR][KSL];  // + stage offset (updated per k-tile) + 4096 * tile index (immediate)
 #pragma unroll
-  for (int p = 0; p < NPL; ++p)
+  for (int p = 0; p < NFR; ++p)
 #pragma unroll
     for (int ksl = 0; ksl < KSL; ++ksl) {
       const int ks = KSS == 1 ? ksl : ksl * KSS + grp;  // k-step split: this group's k-steps of the line
-      const uint32_t o = (uint32_t)(frow + (((p * 4 + 2 * ks + fhi) ^ fswz) << 4));
+      const int chunk = (MX && p > 0) ? 4 + 2 * fhi + (p - 1) : p * 4 + 2 * ks + fhi;
+      const uint32_t o = (uint32_t)(frow + ((chunk ^ fswz) << 4));
       fa_addr[p][ksl] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
       fw_addr[p][ksl] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
     }
-  Frag fa[2][NPL][JG], fw[2][NPL][TN];
+  Frag fa[2][NFR][JG], fw[2][NFR][TN];
 
   // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot.
   // Slots are numbered v = parity * SLOTS + s over a PAIR of k-tiles: the fragment buffers alternate with v, so tiles with an odd number
@@ -471,15 +495,17 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   constexpr bool PAIRED = (SLOTS % 2 != 0) || (KSL % 2 != 0);
   auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, v>
     constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-      if constexpr (jg == 0) {
-        const uint32_t wb = fw_addr[p][ks] + soff;
-        static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * 4096>(wb); });
+    static_for<NFR>([&](auto P) {
+      constexpr int p = decltype(P)::value;
+      if constexpr (!MX || p == 0 || ks == KSL - 1) {
+        if constexpr (jg == 0) {
+          const uint32_t wb = fw_addr[p][ks] + soff;
+          static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * 4096>(wb); });
+        }
+        const uint32_t ab = fa_addr[p][ks] + soff;
+        static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * 4096>(ab); });
       }
-      const uint32_t ab = fa_addr[p][ks] + soff;
-      static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * 4096>(ab); });
-    }
+    });
     // (no scheduling fence here: pinning the reads ahead of the slot's MFMAs measured -20 % on the 8-wave tiles and 0 on the 4-wave ones —
     // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
   };
@@ -491,12 +517,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
       for (int i = 0; i < TN; ++i) {
         if constexpr (ABL & 8) {  // keep the fragments alive without the MFMAs
 #ifndef F5_HIPEMU
-          asm volatile("" ::"v"(fw[wbuf][0][i].u.x), "v"(fw[wbuf][NPL - 1][i].u.w), "v"(fa[buf][0][jj].u.x), "v"(fa[buf][NPL - 1][jj].u.w));
+          asm volatile("" ::"v"(fw[wbuf][0][i].u.x), "v"(fw[wbuf][MX ? 0 : NPL - 1][i].u.w), "v"(fa[buf][0][jj].u.x), "v"(fa[buf][MX ? 0 : NPL - 1][jj].u.w));
 #endif
           continue;
         }
         Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][0][jj]);
-        if constexpr (NPL == 2) {
+        if constexpr (MX) {
+          if constexpr (ks == KSL - 1) mx_mma(acc[jg * JG + jj][i], fw[wbuf][1][i].u, fw[wbuf][2][i].u, fa[buf][1][jj].u, fa[buf][2][jj].u);  // both correction terms of the line
+        } else if constexpr (NPL == 2) {
           Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][1][jj]);  // W_hi . A_lo
           Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][1][i], fa[buf][0][jj]);  // W_lo . A_hi
         }

@@ -58,6 +58,38 @@ int time_it(F&& launch, int iters, hipStream_t s, double* avg_ms) {
 
 extern "C" {
 
+// Host-side reading of MX operand rows (common.h "fp16 + MX-fp6 corrections"): rows x K values as [K / 32] lines of 128 bytes, against the
+// fp32 values they should encode.  Reports the largest coarse / remainder error in units of their rounding steps' scale (S and S 2^-11: the
+// format guarantees <= 0.25, 0.5 where the top binade saturates), the count outside the given bounds and the hi halves that are not
+// fp16(ref).  `weight`: the W-side element order (remainder first) and scale byte.
+void mx_lines_check(const f16* lines, const float* ref, int64_t rows, int K, bool weight, double bound_c, double bound_l, double* worst_c, double* worst_l,
+                    size_t* bad, size_t* hi_diff, double* maxv) {
+  auto fp6 = [](unsigned c) { const unsigned ex = (c >> 3) & 3, m = c & 7; const float v = ex == 0 ? m / 8.0f : ldexpf(1.0f + m / 8.0f, (int)ex - 1); return (c & 32) ? -v : v; };
+  for (int64_t r = 0; r < rows; ++r)
+    for (int blk = 0; blk < K / 32; ++blk) {
+      const f16* q = lines + (r * (K / 32) + blk) * 64;
+      const float* x = ref + r * K + blk * 32;
+      for (int k = 0; k < 32; ++k) { const f16 h = (f16)x[k]; *hi_diff += memcmp(&h, &q[k], 2) != 0; }
+      for (int h = 0; h < 2; ++h) {
+        uint32_t w[8];
+        memcpy(w, reinterpret_cast<const char*>(q) + 64 + 32 * h, 32);
+        const int b = (int)(w[6] & 255u);
+        const double S = ldexp(1.0, b + (weight ? 0 : 11) - 127);  // block scale of the coarse values; the remainders carry S 2^-11
+        for (int tt = 0; tt < 16; ++tt) {
+          const int k = 8 * (tt / 4) + 4 * h + (tt % 4);
+          auto code = [&](int el) { const int bit = 6 * el; const uint64_t two = w[bit >> 5] | ((uint64_t)w[(bit >> 5) + 1] << 32); return (unsigned)(two >> (bit & 31)) & 63u; };
+          const double lo = (double)x[k] - (double)(float)q[k];  // what the line's remainder should say (against the hi half the line holds)
+          const double c = fp6(code(2 * tt + (weight ? 1 : 0))) * S, l = fp6(code(2 * tt + (weight ? 0 : 1))) * S / 2048.0;
+          const double ec = fabs(c - x[k]) / S, el = fabs(l - lo) / (S / 2048.0);
+          *worst_c = std::max(*worst_c, ec);
+          *worst_l = std::max(*worst_l, el);
+          *bad += ec > bound_c || el > bound_l || w[7] != 0u || (w[6] >> 8) != 0u;
+          *maxv = std::max(*maxv, fabs((double)x[k]));
+        }
+      }
+    }
+}
+
 // out[M,N] = gelu_tanh(A[M,K] . W[N,K]^T + bias) written as fp32 (fp32 mode) or f16 hi(/lo) planes — the FF1 GEMM of a DiT block.
 int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms) {
   if (!ctx || !avg_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || (K % 8) || (N % 4)) return F5HIP_ERR_INVALID;
@@ -66,13 +98,14 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
   hipStream_t s = nullptr;
   Tmp t;
-  const int op = precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3;
+  const int op = precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : precision == F5HIP_PREC_FP16M ? OP_F16M : OP_F16X3;
+  const bool mx = op == OP_F16M;  // MX lines: same row strides as the packed hi | lo rows; the pipelined tiles only (variant < 0 or >= 50)
   float* a32 = t.get<float>((size_t)M * K);
   float* w32 = t.get<float>((size_t)N * K);
   float* bias = t.get<float>(N);
   float* o32 = t.get<float>((size_t)M * N);
   float* res = t.get<float>((size_t)M * N);
-  const bool x3 = op == OP_F16X3;
+  const bool x3 = op == OP_F16X3 || mx;
   if (x3 && (K % 32 || N % 32)) return F5HIP_ERR_INVALID;
   const size_t pl = x3 ? 2 : 1;  // packed hi/lo rows are twice as long
   f16 *ah = t.get<f16>((size_t)M * K * pl), *wh = t.get<f16>((size_t)N * K * pl), *oh = t.get<f16>((size_t)M * N * pl);
@@ -80,7 +113,9 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   if (fill(a32, (int64_t)M * K, 1u, 1.0f, s) != hipSuccess || fill(w32, (int64_t)N * K, 2u, 0.05f, s) != hipSuccess ||
       fill(bias, N, 3u, 0.02f, s) != hipSuccess)
     return F5HIP_ERR_HIP;
-  if (x3) {
+  if (mx) {
+    if (launch_pack_mx_rows(a32, K, M, K, nullptr, ah, 0, s) != hipSuccess || launch_pack_mx_rows(w32, K, N, K, nullptr, wh, 1, s) != hipSuccess) return F5HIP_ERR_HIP;
+  } else if (x3) {
     if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
   } else if (launch_split_f16(a32, (int64_t)M * K, 1.0f, ah, nullptr, s) != hipSuccess ||
              launch_split_f16(w32, (int64_t)N * K, 1.0f, wh, nullptr, s) != hipSuccess) {
@@ -98,9 +133,53 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   } else {               // 0: bias only, 1: FF1 (tanh-GELU); operand rows of the next GEMM
     e.act = epilogue == 1 ? ACT_GELU_TANH : ACT_NONE;
     if (op == OP_F32) e.out32 = o32;
-    else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = 1; e.ldo16 = 2 * (int64_t)N; } }
+    else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = mx ? 2 : 1; e.ldo16 = 2 * (int64_t)N; } }
   }
-  if (getenv("KB_CHECK")) {  // compare this variant's output with the generic 128x64 tiling (variant 1): bytes and numeric distance
+  if (getenv("KB_CHECK") && mx) {  // MX lines against the three-term product of the same fp32 operands (generic kernel, epilogue 2: fp32 results)
+    if (epilogue != 2) {
+      // the MX rows this launch writes (the next GEMM's operand) against the hi | lo rows of the fp16x3 generic kernel on the same fp32
+      // operands, decoded on the host: hi halves, then per half-line the coarse values and the remainders within their rounding steps
+      f16 *a3 = t.get<f16>((size_t)M * K * 2), *w3 = t.get<f16>((size_t)N * K * 2), *o3 = t.get<f16>((size_t)M * N * 2);
+      if (!a3 || !w3 || !o3 || launch_split_f16_packed(a32, M, K, a3, s) != hipSuccess || launch_split_f16_packed(w32, N, K, w3, s) != hipSuccess) return F5HIP_ERR_HIP;
+      GemmCore g3 = g;
+      g3.A = a3; g3.W = w3;
+      EpiStore e3 = e;
+      e3.out16 = o3; e3.out16_lo = o3 + 32; e3.pk16 = 1;
+      const size_t nh = (size_t)M * N * 2;
+      std::vector<f16> ref(nh), got(nh);
+      if (hipMemsetAsync(oh, 0, nh * 2, s) != hipSuccess || launch_gemm_store_variant(OP_F16X3, g3, e3, 1, 1, s) != hipSuccess ||
+          launch_gemm_store_variant(op, g, e, 1, variant, s) != hipSuccess || hipMemcpyAsync(ref.data(), o3, nh * 2, hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipMemcpyAsync(got.data(), oh, nh * 2, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return F5HIP_ERR_HIP;
+      std::vector<float> xref(nh / 2);
+      for (size_t ln = 0; ln < nh / 64; ++ln)
+        for (int k = 0; k < 32; ++k) xref[ln * 32 + k] = (float)ref[ln * 64 + k] + (float)ref[ln * 64 + 32 + k];
+      size_t hi_diff = 0, bad = 0;
+      const size_t lines = nh / 64;
+      double worst_c = 0, worst_l = 0, maxv = 0;
+      // (the two GEMMs' own results differ by a few 1e-5 relative — up to a remainder step: bounds 0.51 / 1.5 still catch any layout slip,
+      // the exact bounds are f5hip_bench_mx_pack's)
+      mx_lines_check(got.data(), xref.data(), (int64_t)M, N, false, 0.51, 1.5, &worst_c, &worst_l, &bad, &hi_diff, &maxv);
+      fprintf(stderr, "KB_CHECK fp16m variant %d epi %d: %zu lines, %zu hi halves differ from the fp16x3 rows, coarse / remainder errors %.3f / %.3f block steps, %zu out of bounds, max |value| %.3g\n",
+              variant, epilogue, lines, hi_diff, worst_c, worst_l, bad, maxv);
+    } else {
+      f16 *a3 = t.get<f16>((size_t)M * K * 2), *w3 = t.get<f16>((size_t)N * K * 2);
+      if (!a3 || !w3 || launch_split_f16_packed(a32, M, K, a3, s) != hipSuccess || launch_split_f16_packed(w32, N, K, w3, s) != hipSuccess) return F5HIP_ERR_HIP;
+      GemmCore g3 = g;
+      g3.A = a3; g3.W = w3;
+      std::vector<float> ref((size_t)M * N), got((size_t)M * N);
+      for (int pass = 0; pass < 2; ++pass) {
+        if (fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess) return F5HIP_ERR_HIP;
+        if ((pass == 0 ? launch_gemm_store_variant(OP_F16X3, g3, e, 1, 1, s) : launch_gemm_store_variant(op, g, e, 1, variant, s)) != hipSuccess ||
+            hipMemcpyAsync(pass == 0 ? ref.data() : got.data(), res, (size_t)M * N * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return F5HIP_ERR_HIP;
+      }
+      double maxd = 0, maxv = 0, sumd = 0;
+      for (size_t i = 0; i < ref.size(); ++i) { const double d = fabs((double)ref[i] - got[i]); maxd = std::max(maxd, d); sumd += d; maxv = std::max(maxv, (double)fabsf(ref[i])); }
+      fprintf(stderr, "KB_CHECK fp16m variant %d: max |diff| %.3g mean %.3g of max |value| %.3g against the fp16x3 product\n", variant, maxd, sumd / ref.size(), maxv);
+      if (fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess) return F5HIP_ERR_HIP;
+    }
+  } else if (getenv("KB_CHECK")) {  // compare this variant's output with the generic 128x64 tiling (variant 1): bytes and numeric distance
     const bool r32 = epilogue == 2 || op == OP_F32;
     const size_t nb = r32 ? (size_t)M * N * 4 : (size_t)M * N * pl * 2;
     void* outp = epilogue == 2 ? (void*)res : op == OP_F32 ? (void*)o32 : (void*)oh;
@@ -143,6 +222,43 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   return rc;
 }
 
+// The MX operand format end to end on the device (tests): pack_mx_rows_kernel (both operand sides) and the LayerNorm producer against the
+// fp32 values they encode, with the format's own bounds.  out[0..2] = worst coarse error, worst remainder error (block steps), values
+// out of bounds + hi halves that are not fp16(value), for: activations, weights, LayerNorm rows (the last against the fp32 LayerNorm).
+int f5hip_bench_mx_pack(f5hip_ctx* ctx, int rows, int K, double* out9) {
+  if (!ctx || !out9 || rows <= 0 || K <= 0 || K % 32 || K > 2048) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return F5HIP_ERR_HIP;
+  hipStream_t s = nullptr;
+  Tmp t;
+  float *x = t.get<float>((size_t)rows * K), *y = t.get<float>((size_t)rows * K), *sc = t.get<float>(K), *sh = t.get<float>(K);
+  f16* mxr = t.get<f16>((size_t)rows * K * 2);
+  if (!x || !y || !sc || !sh || !mxr) return F5HIP_ERR_HIP;
+  if (fill(x, (int64_t)rows * K, 21u, 3.0f, s) != hipSuccess || fill(sc, K, 22u, 0.5f, s) != hipSuccess || fill(sh, K, 23u, 0.3f, s) != hipSuccess) return F5HIP_ERR_HIP;
+  std::vector<float> ref((size_t)rows * K);
+  std::vector<f16> got((size_t)rows * K * 2);
+  for (int which = 0; which < 3; ++which) {
+    const float* src = x;
+    if (which == 2) {  // AdaLN-modulated LayerNorm: fp32 rows from the fp32 kernel, MX rows from the MX kernel
+      if (launch_layernorm(x, K, rows, K, 1e-6f, nullptr, nullptr, sc, sh, y, nullptr, nullptr, K, s) != hipSuccess ||
+          launch_layernorm(x, K, rows, K, 1e-6f, nullptr, nullptr, sc, sh, nullptr, mxr, mxr + 32, K, s, 2, 2 * (int64_t)K) != hipSuccess)
+        return F5HIP_ERR_HIP;
+      src = y;
+    } else if (launch_pack_mx_rows(x, K, rows, K, nullptr, mxr, which, s) != hipSuccess) {
+      return F5HIP_ERR_HIP;
+    }
+    if (hipMemcpyAsync(ref.data(), src, ref.size() * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(got.data(), mxr, got.size() * 2, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return F5HIP_ERR_HIP;
+    double wc = 0, wl = 0, mv = 0;
+    size_t bad = 0, hd = 0;
+    // LayerNorm: the two kernels sum a row in different lane orders — values one fp32 ulp apart, a remainder step is 2^13 ulps: same bounds
+    mx_lines_check(got.data(), ref.data(), rows, K, which == 1, 0.5001, which == 2 ? 0.27 : 0.2501, &wc, &wl, &bad, &hd, &mv);
+    out9[3 * which] = wc; out9[3 * which + 1] = wl; out9[3 * which + 2] = (double)(bad + (which == 2 ? (hd > (size_t)rows * K / 1000 ? hd : 0) : hd));
+  }
+  return F5HIP_OK;
+}
+
 // The fused q|k|v projection of one block (bias, rope, head scatter into the flash layouts) for `seqs` sequences of nseq tokens, H = 16
 // heads of 64: time of `variant`, and with check != 0 every output plane (q, k hi/lo, V^T) compared byte for byte with the generic kernel
 // of gemm.h (variant 1).  Returns the number of differing bytes in *diff (negative status on errors).
@@ -153,9 +269,10 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
   if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
   hipStream_t s = nullptr;
   Tmp t;
-  const int op = precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3;
+  const bool mx = precision == F5HIP_PREC_FP16M;  // MX operand lines; the reference of the check is the fp16x3 generic kernel (values, to 1e-4)
+  const int op = precision == F5HIP_PREC_FP16 ? OP_F16 : mx ? OP_F16M : OP_F16X3;
   const int H = 16, dh = 64, inner = H * dh, N = 3 * inner, M = seqs * nseq, ldv = (nseq + 7) & ~7;
-  const bool x3 = op == OP_F16X3;
+  const bool x3 = op != OP_F16;
   const size_t pl = x3 ? 2 : 1;
   float* a32 = t.get<float>((size_t)M * K);
   float* w32 = t.get<float>((size_t)N * K);
@@ -163,6 +280,7 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
   float* rope = t.get<float>((size_t)nseq * dh);
   float* invf = t.get<float>(dh / 2);
   f16 *ah = t.get<f16>((size_t)M * K * pl), *wh = t.get<f16>((size_t)N * K * pl);
+  f16 *am = mx ? t.get<f16>((size_t)M * K * 2) : nullptr, *wm = mx ? t.get<f16>((size_t)N * K * 2) : nullptr;
   const size_t nq = (size_t)seqs * H * nseq * dh, nv = (size_t)seqs * H * dh * ldv;
   f16* out[2][6];  // [reference / variant][q, q_lo, k, k_lo, vt, vt_lo]
   for (auto& o : out)
@@ -181,8 +299,11 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
   } else if (launch_split_f16(a32, (int64_t)M * K, 1.0f, ah, nullptr, s) != hipSuccess || launch_split_f16(w32, (int64_t)N * K, 1.0f, wh, nullptr, s) != hipSuccess) {
     return F5HIP_ERR_HIP;
   }
+  if (mx && (!am || !wm || launch_pack_mx_rows(a32, K, M, K, nullptr, am, 0, s) != hipSuccess || launch_pack_mx_rows(w32, K, N, K, nullptr, wm, 1, s) != hipSuccess)) return F5HIP_ERR_HIP;
   GemmCore g{};
   g.A = ah; g.W = wh; g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
+  GemmCore gm = g;  // the launch under test: MX lines in fp16m mode (same strides)
+  if (mx) { gm.A = am; gm.W = wm; }
   auto epi = [&](int which) {
     EpiQKV e{};
     e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = getenv("KB_QKV_PE") ? atoi(getenv("KB_QKV_PE")) : -1; e.qscale = 0.125f; e.ldvt = ldv;
@@ -195,7 +316,7 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
     for (int w = 0; w < 2; ++w) {
       for (int i = 0; i < 6; ++i)
         if (hipMemsetAsync(out[w][i], 0, (i < 4 ? nq : nv) * sizeof(f16), s) != hipSuccess) return F5HIP_ERR_HIP;
-      if (launch_gemm_qkv_variant(op, g, epi(w), w == 0 ? 1 : variant, s) != hipSuccess) return F5HIP_ERR_HIP;
+      if ((w == 0 ? launch_gemm_qkv_variant(mx ? OP_F16X3 : op, g, epi(w), 1, s) : launch_gemm_qkv_variant(op, gm, epi(w), variant, s)) != hipSuccess) return F5HIP_ERR_HIP;
     }
     if (hipStreamSynchronize(s) != hipSuccess) return F5HIP_ERR_HIP;
     // the VALUE of every output (hi + lo in fp16x3) must agree to fp32 rounding: the two kernels contract the rope arithmetic differently
@@ -210,7 +331,7 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
         return F5HIP_ERR_HIP;
       double vmax = 0;
       for (size_t j = 0; j < n; ++j) vmax = std::max(vmax, (double)fabsf((float)ah[j]));
-      const double tol = (x3 ? 4e-6 : 2e-3) * std::max(vmax, 1e-3);
+      const double tol = (mx ? 1e-4 : x3 ? 4e-6 : 2e-3) * std::max(vmax, 1e-3);
       int64_t nb = 0, first = -1, nbytes = 0;
       double maxd = 0;
       for (size_t j = 0; j < n; ++j) {
@@ -220,14 +341,14 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
         maxd = std::max(maxd, d);
         if (memcmp(&ah[j], &bh[j], 2) != 0) ++nbytes;
       }
-      if (pl3 == 2 && nbytes && variant < 65) { nb += nbytes; }  // (the k-split tiles, 65.., sum in another order: values only)
+      if (pl3 == 2 && nbytes && variant < 65 && !mx) { nb += nbytes; }  // (the k-split tiles, 65.., sum in another order: values only)
       if (nb) fprintf(stderr, "QKV_CHECK variant %d plane %s: %lld of %zu values differ by more than %.3g (first at %lld), max |diff| %.3g of max |value| %.3g\n", variant,
                       pl3 == 0 ? "q" : pl3 == 1 ? "k" : "v^T", (long long)nb, n, tol, (long long)first, maxd, vmax);
       bad += nb;
     }
   }
   if (diff) *diff = bad;
-  return time_it([&] { return launch_gemm_qkv_variant(op, g, epi(1), variant, s); }, iters, s, avg_ms);
+  return time_it([&] { return launch_gemm_qkv_variant(op, gm, epi(1), variant, s); }, iters, s, avg_ms);
 }
 
 // Reproducer of round 2's co-residency fault in the fused q|k|v epilogue (race_probe.hip): `reps` launches of tile `variant` with the

@@ -49,8 +49,11 @@ enum {
 /* GEMM operand precision of the per-step DiT path (everything else is always fp32):
  *   FP32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                     — parity mode
  *   FP16X3  fp16 hi/lo split operands, 3 MFMAs per product, fp32 accum    — ~fp32 accuracy
- *   FP16    fp16 operands, fp32 accumulate (what the reference runs on GPU: utils_infer.py:191-199) */
-enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2 };
+ *   FP16    fp16 operands, fp32 accumulate (what the reference runs on GPU: utils_infer.py:191-199)
+ *   FP16M   FP16X3 with the two correction terms of every product of the DiT block GEMMs (q|k|v, out, FF1, FF2) taken as ONE MX-fp6
+ *           matrix instruction per 32 k instead of two fp16 ones (1.5 MFMA-equivalents per product instead of 3; same accuracy class:
+ *           DESIGN.md section 2).  Backbones / shapes / options the MX path is not built for run as FP16X3 (never less accurate). */
+enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2, F5HIP_PREC_FP16M = 3 };
 
 /* Architecture of the backbone: the keyword arguments of reference src/f5_tts/model/backbones/dit.py:171-192 (DiT) /
  * unett.py:109-128 (UNetT) that change inference arithmetic. */
@@ -260,6 +263,7 @@ int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
  *              128x128, 256x128, 128x256, 256x256 tiles (rows x output channels)
  *   attention: the flash kernel over [batch2*heads, n, 64] (precision FP16 or FP16X3) */
 int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms);
+int f5hip_bench_mx_pack(f5hip_ctx* ctx, int rows, int K, double* out9);
 int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff);
 int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms);
 /* Reproducer of a co-residency fault found in round 2 (csrc/race_probe.hip; no reference counterpart): `reps`

@@ -1,0 +1,191 @@
+"""How many matrix-core products does a block GEMM need?  (test infrastructure, CPU only — never on the product path)
+
+The `fp16x3` operand mode of the HIP path computes every block-GEMM product as `A_hi W_hi + A_hi W_lo + A_lo W_hi` (fp16 planes, fp32
+accumulate): three fp16 MFMAs per product.  VERDICT r03 asks whether the q|k|v and out-projection GEMMs — whose results (q, k, v) or
+inputs (the attention output) pass through fp16 anyway — need the third MFMA.  This script answers on the CPU, at the full model size,
+against goldens minted from the reference, by EMULATING candidate operand schemes inside the oracle's `F.linear` (fp32 accumulate, exactly
+the planes the kernel would multiply), with the attention operands rounded to fp16 as the engine's default does:
+
+    x3    A_hi W_hi + A_hi W_lo + A_lo W_hi        (the shipped scheme: calibrates the emulation against the GPU's measured error)
+    ahi   A_hi (W_hi + W_lo)                        (activations at 11 bits: 2 MFMAs)
+    whi   (A_hi + A_lo) W_hi                        (weights at 11 bits: 2 MFMAs)
+    x1    A_hi W_hi                                 (plain fp16)
+    mx6   A_hi W_hi + mx6(A_hi) mx6(W_lo) + mx6(A_lo) mx6(W_hi)
+          the two correction terms as MX-fp6 (e2m3, one power-of-two scale per 32 consecutive k): gfx950 runs
+          v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 operands at 4x the fp16 rate, so this product costs 1 + 2/4 = 1.5 fp16 MFMAs
+    mx8   the same with e4m3 elements (2x the fp16 rate: 2.0 fp16 MFMAs; same 4-bit significand, wider exponent)
+    mx4   the same with e2m1 elements (fp4)
+
+    python oracle/operand_scheme_emulation.py --case base_v1_cfg1 --runs "all=x3;qkv=ahi;qkv=whi;out=ahi;all=mx6"
+
+A run is `class[+class..]=scheme[,class=scheme..]`; classes qkv, out, ff1, ff2, all; classes a run does not name use x3.
+Weights are conditioned like the engine's (row n scaled by a power of two so that its largest entry sits in [2^12, 2^13), undone exactly).
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import f5_tts_amd  # noqa: E402,F401
+from oracle import f5_oracle as O  # noqa: E402
+from oracle import make_golden as MG  # noqa: E402
+
+_PAT = [
+    (re.compile(r"attn\.to_[qkv]\.weight$"), "qkv"),
+    (re.compile(r"attn\.to_out\.0\.weight$"), "out"),
+    (re.compile(r"ff\.ff\.0\.0\.weight$"), "ff1"),
+    (re.compile(r"ff\.ff\.2\.weight$"), "ff2"),
+    (re.compile(r"\.4\.ff\.0\.0\.weight$"), "ff1"),  # UNetT layers
+    (re.compile(r"\.4\.ff\.2\.weight$"), "ff2"),
+]
+GEMMS = ["qkv", "out", "ff1", "ff2"]
+
+
+def r16(x):
+    return x.half().float()
+
+
+def mx_quant(x, fmt):
+    """Round to an MX block format: blocks of 32 along the last axis share a power-of-two scale; elements e2m3 / e4m3 / e2m1."""
+    k = x.shape[-1]
+    assert k % 32 == 0
+    xb = x.reshape(*x.shape[:-1], k // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    top = dict(e2m3=7.5, e4m3=448.0, e2m1=6.0)[fmt]
+    emax = dict(e2m3=2, e4m3=8, e2m1=2)[fmt]           # exponent of the largest binade of the element format
+    e = torch.floor(torch.log2(amax.clamp_min(1e-38))) - emax
+    y = xb / torch.exp2(e)
+    # the block maximum may round above the format's largest value: move such blocks one binade down
+    bump = (y.abs().amax(-1, keepdim=True) > top * (1 + 2.0 ** -(dict(e2m3=5, e4m3=5, e2m1=3)[fmt])))
+    e = e + bump.to(e.dtype)
+    s = torch.exp2(e)
+    y = xb / s
+    a = y.abs()
+    mant = dict(e2m3=3, e4m3=3, e2m1=1)[fmt]
+    emin = dict(e2m3=0, e4m3=-6, e2m1=0)[fmt]          # exponent of the smallest normal binade
+    be = torch.floor(torch.log2(a.clamp_min(2.0 ** (emin - 40)))).clamp_min(emin)
+    step = torch.exp2(be - mant)
+    q = (torch.round(a / step) * step).clamp_max(top)
+    out = torch.sign(y) * q * s
+    out = torch.where(amax > 0, out, torch.zeros_like(out))
+    return out.reshape(x.shape)
+
+
+class Schemes:
+    """Stands in for `torch.nn.functional` inside the oracle module."""
+
+    def __init__(self, sd, plan):
+        self.plan = plan  # class -> scheme
+        self.cls = {}
+        for k, v in sd.items():
+            for pat, c in _PAT:
+                if pat.search(k):
+                    self.cls[id(v)] = c
+        self.wc = {}
+
+    def __getattr__(self, name):
+        return getattr(TF, name)
+
+    def _w(self, w):
+        k = id(w)
+        if k not in self.wc:
+            amax = w.abs().amax(1, keepdim=True).clamp_min(1e-30)
+            alpha = torch.exp2(12 - torch.floor(torch.log2(amax)))      # row maximum -> [2^12, 2^13)
+            ws = w * alpha
+            hi = r16(ws)
+            lo = r16(ws - hi)
+            self.wc[k] = dict(alpha=alpha.reshape(-1), hi=hi, lo=lo)
+        return self.wc[k]
+
+    def _wq(self, w, name, fmt):
+        c = self._w(w)
+        key = name + fmt
+        if key not in c:
+            c[key] = mx_quant(c[name], fmt)
+        return c[key]
+
+    def linear(self, x, w, b=None):
+        cl = self.cls.get(id(w))
+        if cl is None:
+            return TF.linear(x, w, b)
+        sch = self.plan.get(cl, "x3")
+        c = self._w(w)
+        xh = r16(x)
+        xl = r16(x - xh)
+        if sch == "x3":
+            y = TF.linear(xh, c["hi"]) + (TF.linear(xh, c["lo"]) + TF.linear(xl, c["hi"]))
+        elif sch == "ahi":
+            y = TF.linear(xh, c["hi"]) + TF.linear(xh, c["lo"])
+        elif sch == "whi":
+            y = TF.linear(xh, c["hi"]) + TF.linear(xl, c["hi"])
+        elif sch == "x1":
+            y = TF.linear(xh, c["hi"])
+        elif sch in ("mx6", "mx8", "mx4"):
+            fmt = dict(mx6="e2m3", mx8="e4m3", mx4="e2m1")[sch]
+            y = TF.linear(xh, c["hi"]) + (TF.linear(mx_quant(xh, fmt), self._wq(w, "lo", fmt)) + TF.linear(mx_quant(xl, fmt), self._wq(w, "hi", fmt)))
+        else:
+            raise ValueError(sch)
+        y = y / c["alpha"]
+        return y if b is None else y + b
+
+    def scaled_dot_product_attention(self, q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False):
+        # the engine's default: plain fp16 q (pre-scaled), k, P, V; fp32 softmax and accumulators
+        q = r16(q * (q.shape[-1] ** -0.5))
+        k = r16(k)
+        s = q @ k.transpose(-1, -2)
+        if attn_mask is not None:
+            s = s.masked_fill(~attn_mask, float("-inf"))
+        m = s.amax(-1, keepdim=True)
+        e = torch.exp(s - m)
+        e16 = r16(e)
+        return (e16 @ r16(v)) / e16.sum(-1, keepdim=True)
+
+
+def parse_run(spec):
+    plan = {}
+    for part in spec.split(","):
+        cl, sch = part.split("=")
+        for c in (GEMMS if cl == "all" else cl.split("+")):
+            plan[c] = sch
+    return plan
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="base_v1_cfg1")
+    ap.add_argument("--runs", default="all=x3;qkv=ahi;qkv=whi;out=ahi;out=whi;all=mx6")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    c = MG.FULL_CASES[a.case]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    sd = MG.case_weights(c)
+    gold = torch.as_tensor(np.load(os.path.join(ROOT, "tests", "golden", a.case + ".npz"))["out"])
+    ref_len = wav.shape[-1] // 256
+    res = {}
+    for spec in a.runs.split(";"):
+        t0 = time.perf_counter()
+        O.F = Schemes(sd, parse_run(spec))
+        try:
+            out, _ = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
+        finally:
+            O.F = TF
+        d = (out - gold)[:, ref_len:].abs()
+        res[spec] = dict(max_abs=d.max().item(), mean_abs=d.mean().item(), rms=d.pow(2).mean().sqrt().item())
+        print(f"{a.case:16s} {spec:34s} max-abs {res[spec]['max_abs']:.3e}  mean-abs {res[spec]['mean_abs']:.3e}  rms {res[spec]['rms']:.3e}"
+              f"   ({time.perf_counter() - t0:.0f} s)", flush=True)
+        if a.out:
+            json.dump(res, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

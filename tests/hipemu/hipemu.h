@@ -186,6 +186,7 @@ struct Fiber {
 struct WaveCtx {
   Barrier bar;
   float a[64][8], b[64][8], sh[64];
+  float qa[64][32], qb[64][32];  // decoded MX operands (mfma_scale_32x32x64_fp6)
 };
 struct BlockCtx {
   Barrier bar;
@@ -283,6 +284,70 @@ inline f16v mfma_32x32x2_f32(float a, float b, f16v c, int, int, int) {
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
     c[r] += w.a[i][0] * w.b[j][0] + w.a[i + 32][0] * w.b[j + 32][0];
+  }
+  barrier_wait(w.bar);
+  return c;
+}
+// ---- MX-fp6 (gfx950; semantics measured on the GPU by tools/probes/mx6_probe.hip, profiles/r04a_mx6_probe.log) ---------------------
+// e2m3: sign | 2 exponent bits (bias 1) | 3 mantissa bits; values 0, 0.125 .. 0.875 (subnormal), 1 .. 7.5.  Element e of a 32-element
+// operand sits in bits [6 e, 6 e + 6) of the little-endian register tuple.
+typedef unsigned u6 __attribute__((ext_vector_type(6)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+inline float fp6_decode(unsigned c) {
+  const unsigned e = (c >> 3) & 3, m = c & 7;
+  const float v = e == 0 ? m / 8.0f : ldexpf(1.0f + m / 8.0f, (int)e - 1);
+  return (c & 32) ? -v : v;
+}
+inline unsigned fp6_encode(float x) {  // round to nearest even, saturate at 7.5, keep the sign of zero
+  const unsigned s = std::signbit(x) ? 32u : 0u;
+  const float a = fabsf(x);
+  if (!(a == a)) return s | 31u;
+  unsigned c;
+  if (a < 2.0f) c = (unsigned)nearbyintf(a * 8.0f);
+  else if (a < 4.0f) c = 8u + (unsigned)nearbyintf(a * 4.0f);
+  else if (a < 7.75f) c = 16u + (unsigned)nearbyintf(a * 2.0f);
+  else c = 31u;
+  return s | (c > 31u ? 31u : c);
+}
+inline unsigned fp6_get(const unsigned* w, int e) {
+  const int bit = 6 * e;
+  const uint64_t two = w[bit >> 5] | ((uint64_t)((bit >> 5) + 1 < 6 ? w[(bit >> 5) + 1] : 0u) << 32);
+  return (unsigned)(two >> (bit & 31)) & 63u;
+}
+// v_cvt_scalef32_2xpk16_fp6_f32: element 2 i <- src0[i] / 2^floor(log2 scale), element 2 i + 1 <- src1[i] / the same
+inline u6 cvt_scalef32_2xpk16_fp6_f32(f16v s0, f16v s1, float scale) {
+  int ex;
+  frexpf(scale, &ex);
+  const float inv = ldexpf(1.0f, -(ex - 1));
+  unsigned w[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 32; ++i) {
+    const unsigned c = fp6_encode(((i & 1) ? s1[i >> 1] : s0[i >> 1]) * inv);
+    const int bit = 6 * i;
+    const uint64_t v = (uint64_t)c << (bit & 31);
+    w[bit >> 5] |= (unsigned)v;
+    w[(bit >> 5) + 1] |= (unsigned)(v >> 32);
+  }
+  u6 r;
+  for (int i = 0; i < 6; ++i) r[i] = w[i];
+  return r;
+}
+// v_mfma_scale_f32_32x32x64_f8f6f4 with cbsz = blgp = 2 (both operands e2m3): lane l of src0 holds A[i = l % 32][k = 32 (l / 32) + e],
+// registers 6 and 7 of the 8-register operand are ignored; the per-lane scale is byte 0 of the scale register, 2^(b - 127)
+inline f16v mfma_scale_32x32x64_fp6(i8v a, i8v b, f16v c, int cbsz, int blgp, int, int sa, int, int sb) {
+  if (cbsz != 2 || blgp != 2) { fprintf(stderr, "hipemu: only e2m3 x e2m3 is emulated\n"); abort(); }
+  WaveCtx& w = wv();
+  const int lane = blk->cur->lane;
+  unsigned ua[6], ub[6];
+  for (int i = 0; i < 6; ++i) { ua[i] = (unsigned)a[i]; ub[i] = (unsigned)b[i]; }
+  const float fa = ldexpf(1.0f, (sa & 255) - 127), fb = ldexpf(1.0f, (sb & 255) - 127);
+  for (int e = 0; e < 32; ++e) { w.qa[lane][e] = fp6_decode(fp6_get(ua, e)) * fa; w.qb[lane][e] = fp6_decode(fp6_get(ub, e)) * fb; }
+  barrier_wait(w.bar);
+  const int j = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += w.qa[i + 32 * (k >> 5)][k & 31] * w.qb[j + 32 * (k >> 5)][k & 31];
+    c[r] += s;
   }
   barrier_wait(w.bar);
   return c;
@@ -489,6 +554,8 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
 #define __builtin_amdgcn_raw_buffer_load_b128 hipemu::raw_buffer_load_b128
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu::mfma_32x32x16_f16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2_f32
+#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4 hipemu::mfma_scale_32x32x64_fp6
+#define __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32 hipemu::cvt_scalef32_2xpk16_fp6_f32
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

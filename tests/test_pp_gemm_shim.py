@@ -63,6 +63,63 @@ def test_pp_variant_equals_generic_kernel_fp16(emu_engine, capfd, variant, M, N,
         assert bad == 0 and v > 0, (bad, nb, d, v)
 
 
+# ---- fp16m: 2 fp16 MFMAs + 1 MX-fp6 MFMA per 32 k (common.h) ---------------------------------------------------------------------------
+# The correction terms are rounded to ~4 bits per factor, so the results are close to — not bytes of — the three-term product: the bound
+# is the scheme's own error (2^-16 per operand relative to the block maximum, summed over K), the check that it is non-zero shows the MX
+# instruction ran.  Every tile instantiated for MX lines (gemm.hip F5_MX_TILES), ragged shapes, the k-split tile with >= 3 k-tiles per group.
+MX_CASES = [(50, 300, 288), (54, 250, 160), (55, 250, 160), (56, 250, 224), (59, 130, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (66, 130, 160)]
+
+
+def run_mx(make_engine, capfd, variant, epi, M, N, K):
+    from f5_tts_amd import binding, config
+
+    eng = make_engine(config.DIT_TINY)
+    os.environ["KB_CHECK"] = "1"
+    try:
+        ms = C.c_double()
+        st = eng.lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16m"], variant, epi, M, N, K, 1, C.byref(ms))
+    finally:
+        os.environ.pop("KB_CHECK", None)
+    err = capfd.readouterr().err
+    assert st == 0, err
+    return err
+
+
+@pytest.mark.parametrize("variant,M,N", MX_CASES)
+def test_pp_mx_lines_product_close_to_the_three_term_product(emu_engine, capfd, variant, M, N):  # noqa: F811
+    err = run_mx(emu_engine, capfd, variant, 2, M, N, 256)
+    m = re.search(r"KB_CHECK fp16m variant \d+: max \|diff\| (\S+) mean (\S+) of max \|value\| (\S+)", err)
+    assert m, err
+    d, mean, v = (float(x) for x in m.groups())
+    assert v > 0 and 0 < d <= 1e-4 * v and mean <= 1e-5 * v, err
+
+
+@pytest.mark.parametrize("variant,M,N", [(50, 300, 288), (56, 250, 224), (66, 130, 160)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_pp_mx_output_rows_decode_to_the_fp16x3_rows(emu_engine, capfd, variant, M, N, epi):  # noqa: F811
+    """The FF1-type epilogue writes the NEXT GEMM's MX lines: hi halves equal the fp16x3 rows', coarse values and remainders within their steps."""
+    err = run_mx(emu_engine, capfd, variant, epi, M, N, 256)
+    m = re.search(r"KB_CHECK fp16m variant \d+ epi \d: (\d+) lines, (\d+) hi halves differ .* errors (\S+) / (\S+) block steps, (\d+) out of bounds", err)
+    assert m, err
+    lines, hidiff, ec, el, bad = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5))
+    # (hi halves: the two GEMMs' results differ by a few 1e-5 relative, which crosses an fp16 rounding boundary in a few % of the values)
+    assert lines == M * N // 32 and bad == 0 and hidiff <= lines * 32 // 8 and 0 < ec <= 0.51 and 0 < el <= 1.5, err
+
+
+@pytest.mark.parametrize("rows,K", [(37, 256), (5, 1024), (9, 768), (3, 2048)])
+def test_mx_pack_and_layernorm_rows_against_the_format(emu_engine, rows, K):  # noqa: F811
+    """pack_mx_rows_kernel (both operand sides) and the LayerNorm producer: every line decoded on the host against the fp32 values, with the
+    format's own bounds (coarse value within half a block step, remainder within a quarter step, hi = fp16(value), zero padding words)."""
+    from f5_tts_amd import config
+
+    eng = emu_engine(config.DIT_TINY)
+    out = (C.c_double * 9)()
+    assert eng.lib.f5hip_bench_mx_pack(eng._ctx, rows, K, out) == 0
+    for which in range(3):
+        wc, wl, bad = out[3 * which], out[3 * which + 1], out[3 * which + 2]
+        assert bad == 0 and 0.2 < wc <= 0.5001 and 0.1 < wl <= 0.27, (which, wc, wl, bad)  # (remainders stay below 4 block steps: their top binade rounds to 0.125)
+
+
 def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
     from f5_tts_amd import binding, config
 
@@ -81,3 +138,11 @@ def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
 def test_pp_qkv_epilogue_equals_generic_kernel(emu_engine, capfd, variant, seqs, nseq):  # noqa: F811
     diff, err = run_qkv(emu_engine, capfd, "fp16x3", variant, seqs, nseq, K=256 if variant in KSPLIT else 128)
     assert diff == 0, err[-2000:]
+
+
+@pytest.mark.parametrize("variant", [c[0] for c in MX_CASES])
+def test_pp_qkv_epilogue_on_mx_lines(emu_engine, capfd, variant):  # noqa: F811
+    """The fused q|k|v epilogue behind the MX k-loop: every q / k / V^T value within 1e-4 of the fp16x3 generic kernel's (another product
+    form, so values — the index scheme itself is the byte-for-byte test above)."""
+    diff, err = run_qkv(emu_engine, capfd, "fp16m", variant, 3, 150, K=256)
+    assert diff == 0, err
