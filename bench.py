@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
                     help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
     ap.add_argument("--schedule", default="default", choices=["default"], help="kept for command-line compatibility: there is one schedule")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default single-GPU run (BASELINE.json configs[1]) also times configs[2] (batch 32, NFE 32) and configs[4] (E2-TTS + BigVGAN, "
+                         "batch 8) in child processes and reports them in the line's `other_configs`; this switch leaves them out")
     ap.add_argument("--tiny", action="store_true",
                     help="NOT a benchmark: the tiny model / Vocos at 120 frames (what smoke() runs), so that this file's own logic — self-launch, "
                          "rank protocol, JSON assembly — can be executed end to end, including on the CPU shim (tests/test_bench_on_shim.py)")
@@ -149,9 +152,37 @@ def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen, bigvgan=No
                 break
     except Exception:
         pass
-    return {"value": t_gen / total, "unit": "frames/s", "cores": cores, "kind": kind, "cpu": cpu_name,
+    ref_note = {}
+    try:  # what the REFERENCE's own classes took for this workload where they can run (the build container; oracle/make_golden.py records it)
+        pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pins.json")))
+        ref_note = {"reference_classes_seconds_in_build_container": round(pins["base_v1_cfg1"]["reference_seconds"], 1),
+                    "reference_classes_note": "the reference's own CFM.sample (imported from /root/reference through oracle/ref_shims.py) on configs[0]'s inputs, "
+                                              "8 cores of the build container, sampler only (no vocoder) — tests/golden/pins.json; /root/reference does not exist on the GPU box"}
+    except Exception:
+        pass
+    return {"value": t_gen / total, "unit": "frames/s", "cores": cores, "kind": kind, "cpu": cpu_name, **ref_note,
             "rtf": total / (HOP * (t_gen - 1) / SR), "seconds_per_utterance": total, "extrapolated": not full, "seconds_per_ode_step": per_step,
             "sample": how + ("; vocoder = the Vocos restatement (vocos package absent)" if bigvgan is None else "")}
+
+
+def other_configs(a):
+    """BASELINE.json's other single-GPU configurations, each in a child process of this file (its own context, memory and failure domain),
+    summarised for the headline line: configs[2] = batch 32, NFE 32; configs[4] = E2-TTS Base + BigVGAN, batch 8, NFE 16."""
+    runs = [("configs[2]", ["--batch", "32", "--nfe", "32", "--steps", "2", "--warmup", "1"]),
+            ("configs[4]", ["--model", "E2TTS_Base", "--vocoder", "bigvgan", "--batch", "8", "--nfe", "16", "--steps", "3", "--warmup", "1"])]
+    out = []
+    for name, args in runs:
+        cmd = LAUNCH_CMD + args + ["--precision", a.precision, "--no-cpu-baseline", "--no-other-configs"] + (["--no-graph"] if a.no_graph else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out.append({"baseline_config": name, "workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                        "rtf": d["rtf"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
+                        "roofline": {k: d.get("roofline", {}).get(k) for k in ("achieved", "peak", "frac", "avg_launch_us")},
+                        "kernel_classes_ms": d.get("kernel_classes_ms"), "notes": d["config"].get("notes")})
+        except Exception as e:  # the headline line must not depend on these
+            out.append({"baseline_config": name, "error": repr(e)[:300]})
+    return out
 
 
 def kernel_source_hash():
@@ -366,6 +397,13 @@ def main():
             res["cpu_baseline"] = cpu_baseline(cfg, sd, vsd, vcfg, wav.cpu(), text, duration, a.nfe, t_gen, (bcfg, bsd) if big else None)
         except Exception as e:  # pragma: no cover
             res["cpu_baseline"] = {"error": repr(e)}
+    if world == 1 and not a.no_other_configs and not a.tiny and a.batch == 1 and a.model == "F5TTS_v1_Base" and a.vocoder == "vocos":
+        try:  # free the headline's context before the children allocate theirs
+            eng.close()
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        res["other_configs"] = other_configs(a)
     print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.barrier()

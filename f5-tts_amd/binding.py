@@ -13,8 +13,9 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # F5HIP_LIB=/path/to/libf5hip.so: another build of the same ABI (A/B measurements of two builds on one box; tools/gpu_run.sh)
 LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "csrc", "libf5hip.so")
+BENCH_LIB_PATH = os.environ.get("F5HIP_BENCH_LIB") or os.path.join(_HERE, "csrc", "libf5hip_bench.so")
 
-ABI_VERSION = 7  # F5HIP_ABI_VERSION in include/f5hip.h
+ABI_VERSION = 8  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16, PREC_FP16M = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16m": PREC_FP16M}
 
@@ -65,8 +66,6 @@ SYMBOLS = {
     "f5hip_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "f5hip_reset_kernel_stats": (C.c_int, [_P]),
-    "f5hip_bench_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
-    "f5hip_bench_mx_pack": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "f5hip_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfigC), C.c_int, C.POINTER(_P)]),
     "f5hip_bigvgan_destroy": (C.c_int, [_P]),
     "f5hip_bigvgan_last_error": (C.c_char_p, [_P]),
@@ -80,12 +79,19 @@ SYMBOLS = {
     "f5hip_bigvgan_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "f5hip_bigvgan_reset_kernel_stats": (C.c_int, [_P]),
+}
+
+# include/f5hip_bench.h (libf5hip_bench.so: microbenchmarks, format checks, fault reproducers — tools and tests only)
+BENCH_SYMBOLS = {
+    "f5hip_bench_gemm": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "f5hip_bench_mx_pack": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "f5hip_bench_qkv": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "f5hip_bench_attention": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "f5hip_bench_qkv_probe": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_char_p]),
 }
 
 _lib: Optional[C.CDLL] = None
+_bench_lib: Optional[C.CDLL] = None
 
 
 class F5HipError(RuntimeError):
@@ -109,6 +115,29 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         raise F5HipError("libf5hip ABI version mismatch")
     if path == LIB_PATH:
         _lib = lib
+    return lib
+
+
+def type_symbols(lib: C.CDLL, symbols) -> C.CDLL:
+    for name, (res, args) in symbols.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_bench_library(path: str = None) -> C.CDLL:
+    """dlopen libf5hip_bench.so (after libf5hip.so, whose internal launchers it calls) and type the f5hip_bench_* entry points."""
+    global _bench_lib
+    if _bench_lib is not None and path is None:
+        return _bench_lib
+    load_library()
+    p = path or BENCH_LIB_PATH
+    if not os.path.isfile(p):
+        raise F5HipError(f"{p} not found — build it with `make -C f5-tts_amd/csrc` (tools and tests only; the product does not need it)")
+    lib = type_symbols(C.CDLL(p, mode=C.RTLD_GLOBAL), BENCH_SYMBOLS)
+    if path is None:
+        _bench_lib = lib
     return lib
 
 

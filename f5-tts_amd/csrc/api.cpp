@@ -42,7 +42,9 @@ template <typename T>
 T* stage(f5hip_ctx* ctx, size_t n) { return reinterpret_cast<T*>(ctx->stage.alloc(n * sizeof(T))); }
 #define STAGE(T, var, n)                                                    \
   T* var = stage<T>(ctx, (n));                                              \
-  if (!var) FAIL(F5HIP_ERR_HIP, "pinned staging allocation of %zu bytes failed", (size_t)(n) * sizeof(T))
+  if (!var) FAIL(F5HIP_ERR_HIP, "pinned staging allocation of %zu bytes failed%s%s", (size_t)(n) * sizeof(T),                                   \
+                 ctx->stage.last_error != hipSuccess ? ": waiting for the staging slot's previous call: " : "",                                  \
+                 ctx->stage.last_error != hipSuccess ? hipGetErrorString(ctx->stage.last_error) : "")
 
 // Every entry point that enqueues work calls this first: device, the staging slot of this call, and — the workspace being one per context —
 // a GPU-side wait for the previous call's work when this call arrives on a different stream (no host wait in either case).
@@ -414,9 +416,9 @@ int finalize_impl(f5hip_ctx* ctx) {
   const int64_t skip_elems = skip_concat ? (int64_t)(c.depth / 2) * D * 2 * D : (!unett && c.long_skip_connection) ? D * 2 * D : 0;
   const bool mmdit = c.backbone == 2;
   const int64_t cstream_elems = mmdit ? per_block * (c.depth - 1) + 3 * inner * D : 0;  // text stream; the last block only projects q/k/v
-  // fp16m (fp16 + MX-fp6 correction lines, common.h): the four block GEMMs of the DiT backbone when every one of them is a launch the
+  // fp16m (fp16 + MX-fp6 correction lines, common.h): the four block GEMMs of the DiT / UNetT backbones when every one of them is a launch the
   // pipelined kernel takes (rows of whole 128-byte lines, at least a 3-stage ring of them) and the fused q|k|v epilogue applies
-  ctx->mx_ok = c.backbone == 0 && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
+  ctx->mx_ok = (c.backbone == 0 || c.backbone == 1) && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
   const int64_t mx_elems = ctx->mx_ok ? per_block * c.depth * 2 : 0;
   HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3 + mx_elems) * sizeof(f16)));  // plain hi + packed hi/lo (+ MX lines)
   f16* hp = ctx->half_pool.as<f16>();
@@ -426,7 +428,7 @@ int finalize_impl(f5hip_ctx* ctx) {
   HIPCHK(ctx->cond_pool.ensure((size_t)cond_rows * 2 * sizeof(float)));
   float* cp = ctx->cond_pool.as<float>();
   ctx->walpha.clear();
-  static const bool no_cond = getenv("F5HIP_NO_WEIGHT_CONDITIONING") != nullptr;  // A/B switch (tests, tools/): round 2's plain split
+  const bool no_cond = getenv("F5HIP_NO_WEIGHT_CONDITIONING") != nullptr;  // A/B switch (tests, tools/): round 2's plain split; read at every finalize
   ctx->blocks.assign(c.depth, BlockW{});
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = p + (unett ? "layers." : "transformer_blocks.") + std::to_string(i) + ".";
@@ -1221,6 +1223,8 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
   const float* cconst = ctx->cconst.as<float>() + r0n * D;
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int pk = op == OP_F16X3 ? 1 : 0;
+  const bool mx = ctx->mx_call;  // fp16m: q|k|v, out, FF1, FF2 read MX lines (same row strides); the skip projection and proj_out stay fp16x3
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t pl = pk ? 2 : 1;
   const int64_t ldA = D * pl, ldO = inner * pl, ldF = F * pl, ldC = 2 * D * pl;  // operand row strides (elements)
   float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
@@ -1289,34 +1293,34 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     }
     {  // attn_norm: x_transformers RMSNorm
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_attn, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
+      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_attn, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pkb, ldA, 1));
     }
-    CHK(run_qkv(ctx, bw, A, ldA, M, ns, s0, op, exact_attn, wbytes, st));
-    CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pk, ldO, st));
+    CHK(run_qkv(ctx, bw, A, ldA, M, ns, s0, opb, exact_attn, wbytes, st));
+    CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldO, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, op, bw.wo, bw.wo_hi, bw.wo_pk), ldO, M, D, inner);
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldO, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldO, M, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
-      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_ff, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pk, ldA, 1));
+      HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_ff, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pkb, ldA, 1));
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
-      GemmCore g = core(A, ldA, wsel(ctx, op, bw.w1, bw.w1_hi, bw.w1_pk), ldA, M, F, D);
+      GemmCore g = core(A, ldA, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldA, M, F, D);
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
-      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pk; e.ldo16 = ldF;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldF;
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {  // x = ff(...) + x (unett.py:301)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, op, bw.w2, bw.w2_hi, bw.w2_pk), ldF, M, D, F);
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldF, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldF, M, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.res = x; e.ldres = D;
-      HIPCHK(launch_gemm_store(op, g, e, 1, st));
+      HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
   }
   {  // norm_out(x)[:, 1:, :] -> proj_out (unett.py:305-307): one GEMM per sequence over rows 1..n of the normalised operand
@@ -1547,7 +1551,7 @@ int enqueue_steps(f5hip_ctx* ctx, int B, int n, int nt, int steps, int method, i
   // Round 3, with the two-workgroups-per-CU tiles at 4k .. 40k rows (NFE 8, same box, profiles/r03g_chains.log; one chain / two chains):
   //   B = 2: 71.1 / 70.8   B = 3: 108.6 / 96.4   B = 4: 130.4 / 125.5   B = 6: 194.9 / 182.4   B = 8: 249.6 / 243.8   B = 12: 370.4 / 369.3
   //   B = 16: 488.7 / 489.8   B = 24: 740.5 / 729.8 — two chains are never worse any more, so: two chains from B = 2 on.
-  const int64_t rows1 = (int64_t)B * n;  // rows of one chain
+  const int64_t rows1 = ctx->pk_rows > 0 ? ctx->pk_rows / ctx->nb : (int64_t)B * n;  // rows of one chain (packed rows: the valid ones)
   const bool auto_split = rows1 >= 2048;
   const bool split = !mmdit && ctx->nb == 2 && !ctx->profile && (ctx->branch_streams == 1 || (ctx->branch_streams < 0 && auto_split));
   if (split && !ctx->side_stream) {
@@ -1822,7 +1826,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   // fp16m: MX lines for the block GEMMs where they are built (finalize: mx_ok) and the call is one the pipelined kernel and the flash
   // epilogue take; anything else runs the call in fp16x3 — never less accurate, so the mode needs no error path
   ctx->mx_call = precision == F5HIP_PREC_FP16M && ctx->mx_ok && !exact_attn && ctx->attn_kv_split <= 1 &&
-                 (2 * BN + 512) * 4 * std::max<int64_t>(std::max<int64_t>(D, c.ff_inner), (int64_t)c.heads * c.dim_head) < (int64_t)0x7ff00000;
+                 (2 * (BN + B) + 512) * 4 * std::max<int64_t>(std::max<int64_t>(D, c.ff_inner), (int64_t)c.heads * c.dim_head) < (int64_t)0x7ff00000;
 
   // cfg_strength < 1e-5: the reference evaluates only the conditional branch (cfm.py:166-177); otherwise cond + uncond rows are packed
   const int nb = cfg_strength < 1e-5f ? 1 : 2;
@@ -1902,6 +1906,12 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
       HIPCHK(hipMemcpyAsync(ctx->rowmap.p, rm, (size_t)Mp * 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->rowinfo.p, ri, (size_t)Mp * 4, hipMemcpyHostToDevice, st));
       HIPCHK(hipMemcpyAsync(ctx->cu_rows.p, cu, (size_t)(nb * B + 1) * 4, hipMemcpyHostToDevice, st));
+      // The packed q|k|v epilogue writes tokens below duration[b] only, and the flash kernel multiplies the V^T columns of masked keys by
+      // P = 0: whatever an earlier call (another n, the padded layout) left in [duration[b], ldv) must be finite — cleared once per call
+      // (2 B inner ldv halves: microseconds)
+      const int64_t ldv = (n + 7) & ~7;
+      HIPCHK(hipMemsetAsync(ctx->vt16.p, 0, (size_t)((int64_t)2 * B * c.heads * c.dim_head * ldv * 2), st));
+      if (ctx->vt16_lo.p && ctx->attn_impl == 2) HIPCHK(hipMemsetAsync(ctx->vt16_lo.p, 0, (size_t)((int64_t)2 * B * c.heads * c.dim_head * ldv * 2), st));
     }
   }
   {

@@ -51,7 +51,8 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   // per B = 1 sample); with two workgroups per CU it ties or loses (B' = 16: 197.9 against 192.0 us, B' = 64: 829 against 825), so the
   // 128-row launches keep the phase-by-phase kernel.  F5HIP_ATTN_PIPE=0 / 1: never / also for the 128-row blocks (A/B).
   static const int pipe_env = [] { const char* v = getenv("F5HIP_ATTN_PIPE"); return v ? atoi(v) : -1; }();
-  // ping-pong form (attention_kernel.h flash_pp_kernel): 8 waves, 256 query rows, the two halves one phase apart.  F5HIP_ATTN_PP=0: off (A/B)
+  // ping-pong form (attention_kernel.h flash_pp_kernel): 8 waves, 256 query rows, the two halves one phase apart.  OFF by default (it measured
+  // 9 % slower); F5HIP_ATTN_PP=1 turns it on (A/B runs, tests/test_gpu_parity.py::test_ping_pong_attention_kernel_opt_in)
   static const bool pp_off = [] { const char* v = getenv("F5HIP_ATTN_PP"); return !v || atoi(v) == 0; }();
   if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
     if (lazy && !pp_off) {

@@ -175,7 +175,22 @@ __device__ __forceinline__ void mx_pack16(const float (&v)[16], uint32_t (&hi)[8
   p[7] = 0u;
 }
 
-// acc += (the two correction terms of one 32-k block): W's P words in (w0, w1), the activation's in (a0, a1), 16 bytes each
+// A fragment that an inline-asm ds_read delivered, re-defined BEHIND the wait for it.  The compiler takes an asm read's destination as
+// written when the read is issued; what it derives from it on its own — the copies that assemble an MX operand's register tuple, which
+// loop-invariant code motion hoists to the read itself; the reuse of a destination dword nobody reads (the zero word) — then happens
+// before the data has landed (round 4: NaNs on the GPU only, both forms; tests/test_isa_hazards.py walks the disassembly for them).  An
+// empty volatile asm with the fragment as an in/out operand stays behind the (volatile) wait, and everything downstream hangs off its result.
+__device__ __forceinline__ void pin_after_wait(uint4& f) {
+#ifndef F5_HIPEMU
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = {f.x, f.y, f.z, f.w};
+  asm volatile("" : "+v"(v));
+  f = make_uint4(v[0], v[1], v[2], v[3]);
+#endif
+}
+
+// acc += (the two correction terms of one 32-k block): W's P words in (w0, w1), the activation's in (a0, a1), 16 bytes each (pinned behind
+// their wait by the caller: pin_after_wait)
 __device__ __forceinline__ void mx_mma(f32x16& acc, const uint4& w0, const uint4& w1, const uint4& a0, const uint4& a1) {
   const i32x8 wv = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
   const i32x8 av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};

@@ -118,17 +118,23 @@ __device__ __forceinline__ void mx_store_half(char* line, int h, const uint32_t 
   *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[4], p[5], p[6], p[7]);
 }
 
-// LayerNorm / RMSNorm / copy (+ affine | AdaLN modulation) -> MX operand rows.  One wave per row; in pass b lane L owns the 16 channels
-// 32 (32 b + L / 2) + 8 q + 4 (L % 2) + e — exactly one P_h of common.h, so the pack needs no lane exchange (the loads are 16-byte pieces
-// at a 32-byte stride; a lane pair covers a 128-byte line over the four q).
+// LayerNorm / RMSNorm / copy (+ affine | AdaLN modulation) -> MX operand rows.  One wave per row.  The row is loaded, reduced and normalised
+// in the coalesced layout of layernorm_kernel (lane L, piece i: the float4 group G = 64 i + L of a 1024-channel pass), then transposed
+// through the wave's own 4 KB of LDS so that lane L = 2 blk + h owns the 16 channels 32 blk + 8 q + 4 h + e — exactly one P_h of common.h —
+// and the pack needs no lane exchange.  (First form of round 4: the P_h pieces loaded directly, 16 bytes at a 32-byte stride — every
+// instruction touched all 32 lines of the row; 332 against 188 ms of LayerNorm per B = 32 step.  profiles/r04c_*.)  LDS image: group G at
+// slot (G & ~7) | ((G & 7) ^ 2 ((G >> 3) & 3)): the natural writes (8 lanes = one 128-byte line) and the transposed reads (a lane pair per
+// line, four lines per 8 lanes) are both bank-conflict free.
 template <int NB>  // passes: D <= 1024 NB
 __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, f16* out16,
                                                             int64_t ldo16, int mode) {
-  const int lane = threadIdx.x & 63, h = lane & 1;
-  const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= M) return;
+  __shared__ float4 xpose[WAVES_PER_BLOCK][NB * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane & 1;
+  const int row_raw = blockIdx.x * WAVES_PER_BLOCK + wave;
+  const bool live = row_raw < M;  // (no early exit: the block barrier below is executed by every wave)
+  const int row = live ? row_raw : M - 1;
   const float* xr = x + (int64_t)row * ldx;
   const float* A = weight ? weight : scale;
   const float* Bp = weight ? bias : shift;
@@ -136,27 +142,27 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 32 * (32 * b + (lane >> 1)) + 8 * q + 4 * h;
+    for (int i = 0; i < 4; ++i) {
+      const int c = (b * 256 + i * 64 + lane) * 4;
       const bool in = c < D;
-      v[b][q] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pa[b][q] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pb[b][q] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[b][i] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pa[b][i] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[b][i] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   float sum = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sum += (v[b][q].x + v[b][q].y) + (v[b][q].z + v[b][q].w);
+    for (int i = 0; i < 4; ++i) sum += (v[b][i].x + v[b][i].y) + (v[b][i].z + v[b][i].w);
   const float mean = mode == 0 ? wave_sum(sum) / (float)D : 0.f;
   float sq = 0.f;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 32 * (32 * b + (lane >> 1)) + 8 * q + 4 * h;
+    for (int i = 0; i < 4; ++i) {
+      const int c = (b * 256 + i * 64 + lane) * 4;
       if (c < D) {
-        const float a0 = v[b][q].x - mean, a1 = v[b][q].y - mean, a2 = v[b][q].z - mean, a3 = v[b][q].w - mean;
+        const float a0 = v[b][i].x - mean, a1 = v[b][i].y - mean, a2 = v[b][i].z - mean, a3 = v[b][i].w - mean;
         sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
       }
     }
@@ -164,24 +170,34 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
   if (mode == 0) rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + eps);
   else if (mode == 1) rstd = sqrtf((float)D) / fmaxf(sqrtf(wave_sum(sq)), 1e-12f);
   else rstd = 1.0f;
+  float4* tp = xpose[wave];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t[4] = {(v[b][i].x - mean) * rstd, (v[b][i].y - mean) * rstd, (v[b][i].z - mean) * rstd, (v[b][i].w - mean) * rstd};
+      if (weight) { t[0] = t[0] * pa[b][i].x + pb[b][i].x; t[1] = t[1] * pa[b][i].y + pb[b][i].y; t[2] = t[2] * pa[b][i].z + pb[b][i].z; t[3] = t[3] * pa[b][i].w + pb[b][i].w; }
+      else if (scale) { t[0] = t[0] * (1.0f + pa[b][i].x) + pb[b][i].x; t[1] = t[1] * (1.0f + pa[b][i].y) + pb[b][i].y;
+                        t[2] = t[2] * (1.0f + pa[b][i].z) + pb[b][i].z; t[3] = t[3] * (1.0f + pa[b][i].w) + pb[b][i].w; }
+      const int G = b * 256 + i * 64 + lane;
+      tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+  __syncthreads();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int blk = 32 * b + (lane >> 1);
     float y[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float t[4] = {(v[b][q].x - mean) * rstd, (v[b][q].y - mean) * rstd, (v[b][q].z - mean) * rstd, (v[b][q].w - mean) * rstd};
-      if (weight) { t[0] = t[0] * pa[b][q].x + pb[b][q].x; t[1] = t[1] * pa[b][q].y + pb[b][q].y; t[2] = t[2] * pa[b][q].z + pb[b][q].z; t[3] = t[3] * pa[b][q].w + pb[b][q].w; }
-      else if (scale) { t[0] = t[0] * (1.0f + pa[b][q].x) + pb[b][q].x; t[1] = t[1] * (1.0f + pa[b][q].y) + pb[b][q].y;
-                        t[2] = t[2] * (1.0f + pa[b][q].z) + pb[b][q].z; t[3] = t[3] * (1.0f + pa[b][q].w) + pb[b][q].w; }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) y[4 * q + e] = t[e];
+      const int G = blk * 8 + 2 * q + h;
+      const float4 t = tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))];
+      y[4 * q] = t.x; y[4 * q + 1] = t.y; y[4 * q + 2] = t.z; y[4 * q + 3] = t.w;
     }
     uint32_t hi[8], p[8];
     mx_pack16<false>(y, hi, p);
-    // (whole waves run the exchange inside mx_store_half; blocks past D of the last pass are dropped here — D % 32 == 0, so both lanes of a pair agree)
+    // (whole waves run the exchange inside mx_store_half; rows past M and blocks past D are dropped here — D % 32 == 0, so both lanes of a pair agree)
     char* line = reinterpret_cast<char*>(out16 + (int64_t)row * ldo16) + (int64_t)blk * 128;
-    if (32 * blk < D) mx_store_half(line, h, hi, p);
+    if (live && 32 * blk < D) mx_store_half(line, h, hi, p);
     else { uint32_t sink[4]; for (int i = 0; i < 4; ++i) sink[i] = (uint32_t)__shfl_xor((int)hi[i], 1, 64); (void)sink; }
   }
 }

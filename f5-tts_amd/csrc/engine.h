@@ -73,13 +73,15 @@ struct HostStage {
     taken = false;
     return hipSuccess;
   }
+  hipError_t last_error = hipSuccess;  // why the last claim() failed (alloc() can only say "no memory": the caller formats this)
   hipError_t claim() {
-    cur = (cur + 1) % RING;
-    SlotS& s = slot[cur];
+    const int next = (cur + 1) % RING;
+    SlotS& s = slot[next];
     hipError_t e = hipSuccess;
     if (s.open) e = hipDeviceSynchronize();
     else if (s.recorded) e = hipEventSynchronize(s.done);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { last_error = e; return e; }  // the ring does not advance: the next alloc() retries this slot
+    cur = next;
     s.recorded = false;
     s.open = true;
     for (auto& c : s.chunks) c.used = 0;

@@ -215,9 +215,9 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   return hipGetLastError();
 }
 
-// the tiles instantiated for MX lines (NSPLIT 2): no k-step split (the fp6 correction of a line belongs to one wave), and only the tiles
-// pick_pp_variant can choose in that mode plus their microbenchmark alternatives — every instantiation is a minute of build time
-#define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66)
+// the tiles instantiated for MX lines (NSPLIT 2): the tiles pick_pp_variant can choose in that mode plus their microbenchmark
+// alternatives — every instantiation is a minute of build time
+#define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66) X(68) X(69)
 template <int NSPLIT, typename Epi>
 hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s) {
   if constexpr (NSPLIT == 2) {
@@ -258,7 +258,7 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
 // Tile choice.  A launch costs rounds x (time of one workgroup), so prefer the tile whose workgroup count fills whole rounds of the CUs
 // with the largest wave tiles; measured tables: DESIGN.md section 4 (tools/kernel_bench.py, profiles/r02*).
 inline int64_t ktiles_of(const GemmCore& g, int nsplit_planes) { return (int64_t)g.K * 2 * nsplit_planes / GEMM_KTB; }
-int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool mx = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
+int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool mx = false, bool act16 = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
   static const int forced = [] { const char* e = getenv("F5HIP_PP_VARIANT"); return e ? atoi(e) : -1; }();  // tuning knob; 0 = never use the pipelined kernel
   if (forced >= 0) return forced;
   static const int f3072 = [] { const char* e = getenv("F5HIP_PP_VARIANT_N3072"); return e ? atoi(e) : -1; }();  // per-shape tuning knobs (tools/)
@@ -273,12 +273,18 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
   //   2k .. 4k   (B = 1, one chain of 2 x 1406 rows): one round of 240 workgroups — 192x192 for N = 3072 (62 us against 84 for the
   //              128x64 tiles of gemm.h), 192x128 / 8 waves for N = 2048 (41 against 53), 96x128 for N = 1024 (26 / 45 against 32 / 52)
   //   < 2k       (B = 1, one CFG chain of 1406 rows): 192x128 / 8 waves for N = 3072, 96x128 otherwise
-  if (mx) {  // MX lines (fp16m): the same regimes without the k-step-split tiles; small launches stay on the pipelined kernel (no fallback)
+  if (mx) {  // MX lines (fp16m), measured (profiles/r04c_kernel_bench_fp16m_vs_fp16x3.log; us, fp16x3's choice first): small launches
+             // stay on the pipelined kernel (the mode has no generic-kernel fallback)
+    //   M = 90k: 256x256 everywhere (FF1 1136 -> 776, FF2 1110 -> 812)
+    //   M = 11k .. 22k: FF1 (GELU -> MX rows epilogue) 256x256 (150 -> 118 at 11k; two-per-CU 128-130), out / FF2 192x128 two per CU
+    //   (22k: 292 -> 210; 256x256 231), q|k|v 128x192 two per CU (260 -> 177)
+    //   M = 2812: q|k|v 192x192 (59 -> 48), FF1 192x128 / 8 waves (41 -> 32), out / FF2 96x128 / 4 waves (24 / 40 -> 21 / 34; its k-split 21 / 35)
     if (g.M >= 40000) return 50;
-    if (g.M >= 4096) return qkv ? 61 : g.N >= 2048 ? 62 : g.M >= 8192 ? 62 : 63;
-    const bool ksp_ok = ktiles_of(g, 2) % 2 == 0 && ktiles_of(g, 2) / 2 >= 3;
-    if (g.M >= 2048) return g.N >= 3072 ? 56 : g.N >= 2048 ? 55 : ksp_ok ? 66 : 59;
-    return g.N >= 3072 ? 55 : ksp_ok ? 66 : 59;
+    if (g.M >= 4096) return qkv ? 61 : (act16 && g.M >= 8192) ? 50 : (g.N >= 2048 || g.M >= 8192) ? 62 : 63;
+    static const int kss = [] { const char* e = getenv("F5HIP_MX_KSS"); return e ? atoi(e) : 1; }();  // A/B switch: the k-step-split tiles for the one-round launches
+    const bool even_kt = ktiles_of(g, 2) % 2 == 0 && ktiles_of(g, 2) >= 4;
+    if (g.M >= 2048) return g.N >= 3072 ? (kss && even_kt ? 68 : 56) : g.N >= 2048 ? (kss && even_kt ? 69 : 55) : 59;
+    return g.N >= 3072 ? 55 : 59;
   }
   if (g.M < 512) return 0;  // a handful of row tiles: the generic small tiles
   if (g.M >= 40000) return 50;
@@ -309,7 +315,7 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
 template <int NSPLIT>
 hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   if (!pp_applies<NSPLIT>(g, batch)) return PP_NOT_APPLICABLE;
-  if (variant < 0) variant = pick_pp_variant(g, pp_planes(NSPLIT), false, NSPLIT == 2);
+  if (variant < 0) variant = pick_pp_variant(g, pp_planes(NSPLIT), false, NSPLIT == 2, e.out16 != nullptr);
   if (variant < 50) return PP_NOT_APPLICABLE;
   constexpr bool PK = NSPLIT != 1;
   constexpr int FMT = NSPLIT == 3 ? 1 : NSPLIT == 2 ? 2 : 0;  // the operand format the consumer of out16 reads = this launch's own

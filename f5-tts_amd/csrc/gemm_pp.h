@@ -411,7 +411,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   static_assert(TM % JG == 0 && NS >= 2 && NS <= 5 && (NS - 1) * LPT <= 63 && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2,
                 "slot / ring shape (the counted waits are 6-bit immediates)");
   static_assert(sizeof(T) == 2, "fp16 operands (plain or hi/lo packed)");
-  static_assert(!MX || KSS == 1, "the fp6 correction needs both k-steps' owner: no k-step split of MX lines");
+  // MX lines under the k-step split: group g multiplies hi k-step g of every line, and the line's fp6 correction belongs to group 1 on even
+  // k-tiles and to group 0 on odd ones (the tiles run as even / odd pairs anyway): 2 fp16 + 1 fp6 MFMA per group per pair of k-tiles
   F5_DYN_LDS(char, smem_all);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -486,107 +487,127 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
       fa_addr[p][ksl] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
       fw_addr[p][ksl] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
     }
-  Frag fa[2][NFR][JG], fw[2][NFR][TN];
+  // The k-loop as a function of the GROUP when MX lines meet the k-step split (whose turn a k-tile's fp6 correction is depends on the
+  // group): two copies with the roles resolved at compile time — a run-time test put a scalar branch in front of every fp6 MFMA (round 4).
+  auto k_loop = [&](auto GC) {
+  constexpr int G = decltype(GC)::value;  // this wave's group (meaningful for MX && KSS == 2 only)
+    Frag fa[2][NFR][JG], fw[2][NFR][TN];
 
-  // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot.
-  // Slots are numbered v = parity * SLOTS + s over a PAIR of k-tiles: the fragment buffers alternate with v, so tiles with an odd number
-  // of slots or k-steps (the k-step split) run as even / odd tiles; with even counts the parity is always 0.
-  constexpr int SLOTS = KSL * NSLOT;
-  constexpr bool PAIRED = (SLOTS % 2 != 0) || (KSL % 2 != 0);
-  auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, v>
-    constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
-    static_for<NFR>([&](auto P) {
-      constexpr int p = decltype(P)::value;
-      if constexpr (!MX || p == 0 || ks == KSL - 1) {
-        if constexpr (jg == 0) {
-          const uint32_t wb = fw_addr[p][ks] + soff;
-          static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * 4096>(wb); });
-        }
-        const uint32_t ab = fa_addr[p][ks] + soff;
-        static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * 4096>(ab); });
+    // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot.
+    // Slots are numbered v = parity * SLOTS + s over a PAIR of k-tiles: the fragment buffers alternate with v, so tiles with an odd number
+    // of slots or k-steps (the k-step split) run as even / odd tiles; with even counts the parity is always 0.
+    constexpr int SLOTS = KSL * NSLOT;
+    constexpr bool PAIRED = (SLOTS % 2 != 0) || (KSL % 2 != 0);
+    auto read_slot = [&](auto SC, uint32_t soff) {  // SC = integral_constant<int, v>
+      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
+      static_for<NFR>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        auto reads = [&] {
+          if constexpr (jg == 0) {
+            const uint32_t wb = fw_addr[p][ks] + soff;
+            static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * 4096>(wb); });
+          }
+          const uint32_t ab = fa_addr[p][ks] + soff;
+          static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * 4096>(ab); });
+        };
+        if constexpr (!MX || p == 0) reads();
+        else if constexpr (KSS == 1) { if constexpr (ks == KSL - 1) reads(); }  // the lane's MX words: with the line's last k-step
+        else { if constexpr (G != v / SLOTS) reads(); }                          // k-step split: the group whose turn this k-tile is
+      });
+      // (no scheduling fence here: pinning the reads ahead of the slot's MFMAs measured -20 % on the 8-wave tiles and 0 on the 4-wave ones —
+      // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
+    };
+    auto mma_slot = [&](auto SC) {
+      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
+      if constexpr (MX && (KSS == 1 ? ks == KSL - 1 : G != v / SLOTS)) {  // this slot multiplies MX words: re-define them behind the wait that preceded this call
+        static_for<JG>([&](auto J) { pin_after_wait(fa[buf][1][decltype(J)::value].u); pin_after_wait(fa[buf][2][decltype(J)::value].u); });
+        if constexpr (jg == 0) static_for<TN>([&](auto I) { pin_after_wait(fw[wbuf][1][decltype(I)::value].u); pin_after_wait(fw[wbuf][2][decltype(I)::value].u); });
       }
-    });
-    // (no scheduling fence here: pinning the reads ahead of the slot's MFMAs measured -20 % on the 8-wave tiles and 0 on the 4-wave ones —
-    // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
-  };
-  auto mma_slot = [&](auto SC) {
-    constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
-#pragma unroll
-    for (int jj = 0; jj < JG; ++jj)
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        if constexpr (ABL & 8) {  // keep the fragments alive without the MFMAs
-#ifndef F5_HIPEMU
-          asm volatile("" ::"v"(fw[wbuf][0][i].u.x), "v"(fw[wbuf][MX ? 0 : NPL - 1][i].u.w), "v"(fa[buf][0][jj].u.x), "v"(fa[buf][MX ? 0 : NPL - 1][jj].u.w));
-#endif
-          continue;
+  #pragma unroll
+      for (int jj = 0; jj < JG; ++jj)
+  #pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          if constexpr (ABL & 8) {  // keep the fragments alive without the MFMAs
+  #ifndef F5_HIPEMU
+            asm volatile("" ::"v"(fw[wbuf][0][i].u.x), "v"(fw[wbuf][MX ? 0 : NPL - 1][i].u.w), "v"(fa[buf][0][jj].u.x), "v"(fa[buf][MX ? 0 : NPL - 1][jj].u.w));
+  #endif
+            continue;
+          }
+          Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][0][jj]);
+          if constexpr (MX && KSS == 1) {
+            if constexpr (ks == KSL - 1) mx_mma(acc[jg * JG + jj][i], fw[wbuf][1][i].u, fw[wbuf][2][i].u, fa[buf][1][jj].u, fa[buf][2][jj].u);  // both correction terms of the line
+          } else if constexpr (MX) {
+            if constexpr (G != v / SLOTS) mx_mma(acc[jg * JG + jj][i], fw[wbuf][1][i].u, fw[wbuf][2][i].u, fa[buf][1][jj].u, fa[buf][2][jj].u);
+          } else if constexpr (NPL == 2) {
+            Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][1][jj]);  // W_hi . A_lo
+            Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][1][i], fa[buf][0][jj]);  // W_lo . A_hi
+          }
         }
-        Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][0][jj]);
-        if constexpr (MX) {
-          if constexpr (ks == KSL - 1) mx_mma(acc[jg * JG + jj][i], fw[wbuf][1][i].u, fw[wbuf][2][i].u, fa[buf][1][jj].u, fa[buf][2][jj].u);  // both correction terms of the line
-        } else if constexpr (NPL == 2) {
-          Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][1][jj]);  // W_hi . A_lo
-          Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][1][i], fa[buf][0][jj]);  // W_lo . A_hi
-        }
-      }
-  };
+    };
 
-  // One k-tile.  On entry: slot 0's reads are in flight (or landed); tiles t+1 .. t+NS-1 are issued.  MODE 0: steady state (refill tile
-  // t+NS when it exists), 1: next-to-last tile (nothing left to issue, everything outstanding is waited for), 2: last tile.
-  auto ktile = [&](auto MODE, auto PAR, int t, uint32_t soff, uint32_t soff_next, int stage) {
-    constexpr int mode = decltype(MODE)::value, v0 = decltype(PAR)::value * SLOTS, v0_next = PAIRED ? (1 - decltype(PAR)::value) * SLOTS : 0;
-    // slots 0 .. SLOTS-2: wait for this slot's fragments, read the next slot's, multiply
-    static_for<SLOTS - 1>([&](auto S) {
-      pp::lds_wait();
-      read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff);
-      mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
-    });
-    pp::lds_wait();  // the last slot's fragments: every read of this tile by this wave has landed
-    if constexpr (mode != 2) {
-      if constexpr (mode == 0) pp::wait_vmcnt<(NS - 2) * LPT>();  // tile t+1 landed (this wave's pieces); NS-2 tiles stay in flight
-      else pp::wait_vmcnt<0>();
-      pp::wg_barrier();  // tile t+1 visible to all; nobody reads this tile's stage any more
-      if constexpr (mode == 0) {
-        if constexpr (!(ABL & 4)) {
-          if (t + NS < nkt) issue(t + NS, stage);
+    // One k-tile.  On entry: slot 0's reads are in flight (or landed); tiles t+1 .. t+NS-1 are issued.  MODE 0: steady state (refill tile
+    // t+NS when it exists), 1: next-to-last tile (nothing left to issue, everything outstanding is waited for), 2: last tile.
+    auto ktile = [&](auto MODE, auto PAR, int t, uint32_t soff, uint32_t soff_next, int stage) {
+      constexpr int mode = decltype(MODE)::value, v0 = decltype(PAR)::value * SLOTS, v0_next = PAIRED ? (1 - decltype(PAR)::value) * SLOTS : 0;
+      // slots 0 .. SLOTS-2: wait for this slot's fragments, read the next slot's, multiply
+      static_for<SLOTS - 1>([&](auto S) {
+        pp::lds_wait();
+        read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff);
+        mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
+      });
+      pp::lds_wait();  // the last slot's fragments: every read of this tile by this wave has landed
+      if constexpr (mode != 2) {
+        if constexpr (mode == 0) pp::wait_vmcnt<(NS - 2) * LPT>();  // tile t+1 landed (this wave's pieces); NS-2 tiles stay in flight
+        else pp::wait_vmcnt<0>();
+        pp::wg_barrier();  // tile t+1 visible to all; nobody reads this tile's stage any more
+        if constexpr (mode == 0) {
+          if constexpr (!(ABL & 4)) {
+            if (t + NS < nkt) issue(t + NS, stage);
+          }
         }
+        read_slot(std::integral_constant<int, v0_next>{}, soff_next);
       }
-      read_slot(std::integral_constant<int, v0_next>{}, soff_next);
+      mma_slot(std::integral_constant<int, v0 + SLOTS - 1>{});
+    };
+
+    // prologue: tiles 0 .. NS-1 in flight, tile 0 landed and visible, its first fragments requested
+  #pragma unroll
+    for (int s = 0; s < NS; ++s) issue(s, s);
+    pp::wait_vmcnt<(NS - 1) * LPT>();
+    pp::wg_barrier();
+    read_slot(std::integral_constant<int, 0>{}, 0u);
+    int stage = 0;
+    uint32_t soff = 0;
+    auto next_soff = [&](uint32_t so) { return so + STAGE == (uint32_t)(NS * STAGE) ? 0u : so + STAGE; };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, PAIRED ? 1 : 0>;  // parity of the odd tiles (an even number of k-tiles: launcher)
+    int t = 0;
+    auto steady = [&](auto PAR) {
+      const uint32_t sn = next_soff(soff);
+      ktile(std::integral_constant<int, 0>{}, PAR, t, soff, sn, stage);
+      soff = sn;
+      stage = stage == NS - 1 ? 0 : stage + 1;
+      ++t;
+    };
+    if constexpr (PAIRED) {
+      while (t < nkt - 2) { steady(P0{}); steady(P1{}); }
+    } else {
+      while (t < nkt - 2) steady(P0{});
     }
-    mma_slot(std::integral_constant<int, v0 + SLOTS - 1>{});
+    {
+      const uint32_t sn = next_soff(soff);
+      ktile(std::integral_constant<int, 1>{}, P0{}, t, soff, sn, stage);
+      soff = sn;
+      ++t;
+    }
+    ktile(std::integral_constant<int, 2>{}, P1{}, t, soff, 0u, 0);
   };
-
-  // prologue: tiles 0 .. NS-1 in flight, tile 0 landed and visible, its first fragments requested
-#pragma unroll
-  for (int s = 0; s < NS; ++s) issue(s, s);
-  pp::wait_vmcnt<(NS - 1) * LPT>();
-  pp::wg_barrier();
-  read_slot(std::integral_constant<int, 0>{}, 0u);
-  int stage = 0;
-  uint32_t soff = 0;
-  auto next_soff = [&](uint32_t so) { return so + STAGE == (uint32_t)(NS * STAGE) ? 0u : so + STAGE; };
-  using P0 = std::integral_constant<int, 0>;
-  using P1 = std::integral_constant<int, PAIRED ? 1 : 0>;  // parity of the odd tiles (an even number of k-tiles: launcher)
-  int t = 0;
-  auto steady = [&](auto PAR) {
-    const uint32_t sn = next_soff(soff);
-    ktile(std::integral_constant<int, 0>{}, PAR, t, soff, sn, stage);
-    soff = sn;
-    stage = stage == NS - 1 ? 0 : stage + 1;
-    ++t;
-  };
-  if constexpr (PAIRED) {
-    while (t < nkt - 2) { steady(P0{}); steady(P1{}); }
+  if constexpr (MX && KSS == 2) {
+    if (grp == 0) k_loop(std::integral_constant<int, 0>{});
+    else k_loop(std::integral_constant<int, 1>{});
   } else {
-    while (t < nkt - 2) steady(P0{});
+    k_loop(std::integral_constant<int, 0>{});
   }
-  {
-    const uint32_t sn = next_soff(soff);
-    ktile(std::integral_constant<int, 1>{}, P0{}, t, soff, sn, stage);
-    soff = sn;
-    ++t;
-  }
-  ktile(std::integral_constant<int, 2>{}, P1{}, t, soff, 0u, 0);
 
   if constexpr (ABL & 1) {
 #ifndef F5_HIPEMU

@@ -1,11 +1,13 @@
-// microbench.cpp — kernel-level measurement entry points of the C ABI (f5hip_bench_*): time ONE kernel of the hot path on
-// synthetic operands with HIP events on the launch stream.  Used by tools/kernel_bench.py to tune tile variants; no model state.
+// microbench.cpp — kernel-level measurement entry points (include/f5hip_bench.h, libf5hip_bench.so — NOT part of libf5hip.so): time ONE
+// kernel of the hot path on synthetic operands with HIP events on the launch stream, check operand formats and tiles against each other.
+// Used by tools/kernel_bench.py and the tile / format tests; reaches the engine's internal launchers through libf5hip.so; no model state.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
 
+#include "../../include/f5hip_bench.h"
 #include "engine.h"
 
 namespace {

@@ -20,7 +20,7 @@ from typing import Callable, Dict, Iterable, List, Optional, Sequence, Union
 import torch
 
 from . import binding
-from .binding import PRECISIONS, DitConfigC, VocosConfigC, check, load_library
+from .binding import PRECISIONS, DitConfigC, VocosConfigC, check, load_bench_library, load_library
 from .config import DiTConfig, VocosConfig
 
 # reference src/f5_tts/model/utils.py:205-218
@@ -97,6 +97,11 @@ class F5HipEngine:
         self.finalized = False
 
     # -- lifetime ------------------------------------------------------------------------------
+    @property
+    def bench_lib(self):
+        """libf5hip_bench.so (include/f5hip_bench.h): microbenchmarks and format checks over this context — tools and tests only."""
+        return load_bench_library()
+
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
             self.lib.f5hip_destroy(self._ctx)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 7
+#define F5HIP_ABI_VERSION 8
 
 /* status codes */
 enum {
@@ -245,7 +245,8 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
  * loop over the VALID rows only: the reference's varlen attention path, model/modules.py:522-543, extended to the row-wise layers.  Rows past a
  * sequence's duration then keep the prompt / zero state instead of the values the padded layout would compute for them; the reference's
  * callers slice every utterance to its own length, utils_infer.py:507, eval_infer_batch.py:199.  Ignored where it cannot apply: key mask
- * off, qk_norm, long skip, UNetT / MMDiT, the materialised fp32 attention),
+ * off, qk_norm, long skip, UNetT / MMDiT, the materialised fp32 attention, "attn_kv_split" > 1, n >= 65536 or 2 * batch >= 65536 (the
+ * row table packs (sequence, token) into 16 + 16 bits)),
  * "attn_kv_split" (1 off (default) / 2..8: flash attention with every query block cut into that many key ranges + a merge kernel —
  * shorter workgroups for small batches, csrc/attention_kernel.h). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
@@ -256,21 +257,8 @@ int f5hip_kernel_stat(const f5hip_ctx* ctx, int index, const char** name, int64_
                       double* flops, double* bytes);
 int f5hip_reset_kernel_stats(f5hip_ctx* ctx);
 
-/* Kernel microbenchmarks (tools/kernel_bench.py; no reference counterpart): average milliseconds of ONE launch of a
- * hot-path kernel on full-range random synthetic operands, HIP events on the launch stream, 2 warm-up launches.
- *   gemm:      a DiT block GEMM A[M,K] W[N,K]^T; epilogue 0 = +bias -> operand planes, 1 = FF1 (tanh-GELU -> operand planes),
- *              2 = out-proj/FF2 (fp32 residual += gate * (acc + bias)); variant -1 = launch heuristic, 0..5 = 64x128, 128x64,
- *              128x128, 256x128, 128x256, 256x256 tiles (rows x output channels)
- *   attention: the flash kernel over [batch2*heads, n, 64] (precision FP16 or FP16X3) */
-int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, int M, int N, int K, int iters, double* avg_ms);
-int f5hip_bench_mx_pack(f5hip_ctx* ctx, int rows, int K, double* out9);
-int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff);
-int f5hip_bench_attention(f5hip_ctx* ctx, int precision, int batch2, int heads, int n, int iters, double* avg_ms);
-/* Reproducer of a co-residency fault found in round 2 (csrc/race_probe.hip; no reference counterpart): `reps`
- * launches of the fused q|k|v GEMM on tile `variant` with epilogue form `expt`, each checked against the generic kernel; bad[r] = wrong
- * outputs of launch r; dump_path (or NULL) receives the wrong outputs as binary records. */
-int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int lds_pad, int noise, int seqs, int nseq, int reps, int64_t* bad,
-                          const char* dump_path);
+/* (The kernel microbenchmarks and fault reproducers — f5hip_bench_* — are not part of the product: include/f5hip_bench.h,
+ * libf5hip_bench.so.) */
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,14 @@ FULL_CASES = {
     # fp16 hi/lo split survive weights and activations whose scales span three decades?
     "base_v1_stress": dict(preset="F5TTS_v1_Base", wseed=0, stress=True, loud=True, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                            kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # BASELINE.json configs[4] at its own NFE and as a BATCH (VERDICT r03 "missing" 4): E2-TTS Base, two distinct fixed-length prompts, NFE 16 —
+    # rows of the B = 8 schedule bench.py --model E2TTS_Base --batch 8 times (the GPU test repeats them to 8: fixed-length batches have no
+    # cross-row coupling, as with base_v1_cfg3_b4 for configs[2])
+    "e2_base_cfg5_b2": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=20, batch=2, nt=220, tseed=5, duration=1406, lens=None,
+                            kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # the v0 yaml at full size (src/f5_tts/configs/F5TTS_Base.yaml:20-46: pe_attn_head 1, text_mask_padding False) — the configs[1] case on it
+    "base_v0_cfg1": dict(preset="F5TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
+                         kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[0]/[1]: F5-TTS Base, 5 s ref + 10 s gen, NFE 16, sway, CFG 2
     "base_v1_cfg1": dict(preset="F5TTS_v1_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),

@@ -31,10 +31,25 @@ def test_library_exports_every_declared_symbol():
     lib = binding.load_library()
     for name in header_symbols():
         assert hasattr(lib, name)
-    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 7
+    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 8
     out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (f5hip_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported
+    # the microbenchmarks, format checks and the fault reproducer are a library of their own (include/f5hip_bench.h): not in the product
+    assert not [s for s in exported if s.startswith("f5hip_bench_")]
+
+
+def test_bench_library_exports_its_header():
+    bench_header = os.path.join(ROOT, "include", "f5hip_bench.h")
+    src = re.sub(r"/\*.*?\*/", "", open(bench_header).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(f5hip_bench_[a-z_0-9]+)\s*\(", src)))
+    assert declared == sorted(binding.BENCH_SYMBOLS)
+    assert os.path.isfile(binding.BENCH_LIB_PATH), "build first: python __graft_entry__.py"
+    out = subprocess.run(["nm", "-D", "--defined-only", binding.BENCH_LIB_PATH], capture_output=True, text=True).stdout
+    assert set(declared) <= set(re.findall(r"\bT (f5hip_[a-z_0-9]+)", out))
+    lib = binding.load_bench_library()
+    for name in declared:
+        assert hasattr(lib, name)
 
 
 def test_header_cites_reference_interfaces():

@@ -279,6 +279,42 @@ def test_flash_attention_equals_materialised_attention(engines):
     assert maxerr(plain, exact.cpu()) < 3e-4
 
 
+def test_ping_pong_attention_kernel_opt_in():
+    """flash_pp_kernel (8 waves, 256 query rows, the two halves a phase apart) is OFF by default — it measured 9 % slower — and kept as the
+    record of that experiment behind F5HIP_ATTN_PP=1 (read once per process: a child process).  It carries its own cu_rows / lazy-maximum /
+    key-mask logic, so it is run here against reference-minted goldens: a fixed-length case and the ragged key-mask case, padded and with
+    packed rows."""
+    import subprocess
+
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import f5_tts_amd
+from f5_tts_amd import config, synth
+from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+from oracle import make_golden as MG
+worst = 0.0
+for name, packed in (("tiny_v1_nfe16", 0), ("tiny_mask_ragged_b3", 0), ("tiny_mask_ragged_b3", 1)):
+    c = MG.CASES[name]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    eng.set_option("packed_rows", packed)
+    out, _ = F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+    g = np.load(%r + "/" + name + ".npz")["out"]
+    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * out.shape[0]
+    for b, d in enumerate(durs):
+        worst = max(worst, float((out[b, :d].cpu() - torch.as_tensor(g[b, :d])).abs().max()))
+    eng.close()
+print("PP_WORST", worst)
+""" % (ROOT, GOLD)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F5HIP_ATTN_PP="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float(r.stdout.split("PP_WORST")[1].split()[0])
+    print(f"ping-pong attention kernel (F5HIP_ATTN_PP=1): worst max-abs over three goldens {worst:.2e}")
+    assert worst < X3TOL
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL)])
 def test_key_padding_mask_ragged_batch(prec, tol):
     """attn_mask_enabled=True (reference modules.py:513-516): keys beyond each utterance's duration are masked —
@@ -410,12 +446,59 @@ def test_full_size_e2_unett_golden():
     eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
     g = gold("e2_base_cfg5")
     try:
-        for prec in ("fp16x3", "fp32"):
+        for prec, tol in (("fp16m", FULL_TOL), ("fp16x3", FULL_TOL), ("fp32", TIGHT)):
             out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
             e = maxerr(out[:, 468:], g["out"][:, 468:])
             print(f"full-size E2 {prec}: generated-mel max-abs {e:.2e}")
-            assert e < MEL_TOL
-            assert maxerr(traj[1], g["traj_1"]) < MEL_TOL
+            assert e < tol
+            assert maxerr(traj[1], g["traj_1"]) < tol
+    finally:
+        eng.close()
+
+
+def test_full_size_v0_yaml_golden():
+    """The v0 configuration at full size (src/f5_tts/configs/F5TTS_Base.yaml:20-46: pe_attn_head 1 — rope on the first head only —,
+    text_mask_padding False) on the configs[1] inputs, against the golden minted by the reference's own DiT (VERDICT r03 "missing" 4)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["base_v0_cfg1"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    assert cfg.pe_attn_head == 1 and not cfg.text_mask_padding
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    g = gold("base_v0_cfg1")
+    try:
+        for prec, tol in (("fp16m", FULL_TOL), ("fp16x3", FULL_TOL), ("fp32", TIGHT)):
+            out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
+            e = maxerr(out[:, 468:], g["out"][:, 468:])
+            print(f"full-size v0 yaml {prec}: generated-mel max-abs {e:.2e}")
+            assert e < tol and maxerr(traj[1], g["traj_1"]) < tol
+    finally:
+        eng.close()
+
+
+def test_configs4_shaped_batch_golden():
+    """BASELINE.json configs[4] in its own shape (E2-TTS Base, batch 8, NFE 16): two distinct utterances against the golden minted by the
+    reference's own UNetT through CFM.sample (e2_base_cfg5_b2), then the same two as rows 0..1 and 6..7 of the B = 8 batch that
+    bench.py --model E2TTS_Base --batch 8 times (fixed-length batches have no cross-row coupling)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["e2_base_cfg5_b2"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
+    g = gold("e2_base_cfg5_b2")
+    try:
+        for prec in ("fp16m", "fp16x3"):
+            model = F5HipCFM(eng, precision=prec)
+            out, traj = model.sample(wav.cuda(), text, duration, **c["kw"])
+            e = maxerr(out[:, 468:], g["out"][:, 468:])
+            print(f"configs[4]-shaped E2 B=2 NFE=16 {prec}: generated-mel max-abs {e:.2e}")
+            assert e < FULL_TOL and maxerr(traj[1], g["traj_1"]) < FULL_TOL
+            out8, _ = model.sample(wav.repeat(4, 1).cuda(), text.repeat(4, 1), duration, **c["kw"])
+            e8 = max(maxerr(out8[:2, 468:], g["out"][:, 468:]), maxerr(out8[6:, 468:], g["out"][:, 468:]))
+            print(f"the same utterances as rows 0..1 and 6..7 of B=8 ({prec}): {e8:.2e}")
+            assert e8 < FULL_TOL
     finally:
         eng.close()
 
@@ -432,7 +515,7 @@ def test_small_models_golden(name):
     eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
     g = gold(name)
     try:
-        for prec, tol in (("fp32", TIGHT), ("fp16x3", X3TOL), ("fp16m", 4e-4)):  # (fp16m on the UNetT model = fp16x3: the MX lines are the DiT's)
+        for prec, tol in (("fp32", TIGHT), ("fp16x3", X3TOL), ("fp16m", 4e-4)):
             out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
             e = maxerr(out, g["out"])
             print(f"{name} {prec}: max-abs {e:.2e}")
@@ -973,7 +1056,7 @@ def test_pp_qkv_epilogue_equals_generic_kernel_on_the_gpu(engines, variant, seqs
     eng = engines("tiny", 1)
     ms, diff = C.c_double(), C.c_int64()
     for _ in range(3):
-        st = eng.lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS["fp16x3"], variant, seqs, 1406, 1024, 2, 1, C.byref(ms), C.byref(diff))
+        st = eng.bench_lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS["fp16x3"], variant, seqs, 1406, 1024, 2, 1, C.byref(ms), C.byref(diff))
         assert st == 0 and diff.value == 0, (variant, seqs, st, diff.value)
 
 
@@ -992,7 +1075,7 @@ def test_pp_store_epilogues_equal_generic_kernel_on_the_gpu(engines, capfd, vari
     os.environ["KB_CHECK"] = "1"
     try:
         ms = C.c_double()
-        st = eng.lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16x3"], variant, epi, M, N, K, 1, C.byref(ms))
+        st = eng.bench_lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16x3"], variant, epi, M, N, K, 1, C.byref(ms))
     finally:
         os.environ.pop("KB_CHECK", None)
     err = capfd.readouterr().err

@@ -33,7 +33,7 @@ def probe():
 
     def run(tile, expt, lds_pad=0):
         bad = (C.c_int64 * LAUNCHES)()
-        st = eng.lib.f5hip_bench_qkv_probe(eng._ctx, tile, expt, 0, lds_pad, 0, 2, 1406, LAUNCHES, bad, None)
+        st = eng.bench_lib.f5hip_bench_qkv_probe(eng._ctx, tile, expt, 0, lds_pad, 0, 2, 1406, LAUNCHES, bad, None)
         assert st == 0, st
         return list(bad)
 

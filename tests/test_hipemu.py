@@ -595,8 +595,8 @@ def engine_emu_lib():
         r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", path] + objs, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
     lib = C.CDLL(path, mode=C.RTLD_LOCAL)
-    for name, (res, args) in binding.SYMBOLS.items():
-        if hasattr(lib, name):  # the microbenchmark / BigVGAN entry points are not part of this build
+    for name, (res, args) in {**binding.SYMBOLS, **binding.BENCH_SYMBOLS}.items():  # (one library here: engine + microbench.cpp)
+        if hasattr(lib, name):  # the BigVGAN / fault-reproducer entry points are not part of this build
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
     return lib
@@ -618,6 +618,7 @@ def emu_engine(engine_emu_lib, monkeypatch):
     from f5_tts_amd import engine as E
 
     monkeypatch.setattr(E, "load_library", lambda *a, **k: engine_emu_lib)
+    monkeypatch.setattr(E, "load_bench_library", lambda *a, **k: engine_emu_lib)
     monkeypatch.setattr(E, "_as_tensor", host_alias)
     monkeypatch.setattr(torch.cuda, "device", lambda *_a, **_k: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *_a, **_k: types.SimpleNamespace(cuda_stream=0))

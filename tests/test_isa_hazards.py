@@ -10,7 +10,7 @@ compiler can vouch for:
   issues MFMAs and LDS reads (op_sel: src0 low half from the low register, src1 low half from the HIGH register — found in round 3 as
   the cause of round 2's "co-residency race"; reproducer tools/probes/pk_opsel_probe.hip, sweep tools/probes/pk_opsel_sweep.hip).  The
   library is built with -packed-fp32-ops, so hipcc emits no v_pk_{add,mul,fma}_f32 at all; only the reproducer (csrc/race_probe.hip)
-  keeps them.
+  keeps them — in libf5hip_bench.so (tools and tests), not in the engine's library.
 """
 import os
 import re
@@ -95,7 +95,7 @@ def test_pipelined_gemm_keeps_its_dma_ring_in_flight(code_objects):
             targs = re.search(r"gemm_pp_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)  # NSPLIT TM TN WGM WGN NS JG
             assert targs, name
             kss = int(re.search(r"Li0ELi[12]ELi([12])EEv8GemmCore", name).group(1))
-            ksl = (2 if int(targs.group(1)) == 3 else 4) // kss  # k-steps per group per k-tile
+            ksl = (2 if int(targs.group(1)) in (2, 3) else 4) // kss  # k-steps per group per k-tile (hi | lo and hi | MX lines hold 32 k)
             slots = ksl * (int(targs.group(2)) // int(targs.group(7)))
             paired = slots % 2 == 1 or ksl % 2 == 1  # gemm_pp.h PAIRED: an even and an odd k-tile per loop iteration
             assert nbar == (2 if paired else 1), (name, nbar)  # one barrier per k-tile
@@ -152,7 +152,7 @@ def test_no_packed_fp32_in_the_form_that_loses_an_operand(code_objects):
                 kernels += 1
                 continue
             ins = ln.split("//")[0].strip()
-            if not name or "Probe" in name or not PK_F32.match(ins):
+            if not name or not PK_F32.match(ins):  # (the reproducer, csrc/race_probe.hip, lives in libf5hip_bench.so since round 4: no exception here)
                 continue
             packed += 1
             if PK_LOSES_SRC1.search(ins):
@@ -160,3 +160,80 @@ def test_no_packed_fp32_in_the_form_that_loses_an_operand(code_objects):
     assert kernels > 100, kernels
     assert not bad, bad[:5]
     assert packed == 0, f"{packed} packed-fp32 instructions outside the reproducer: was the library built without -packed-fp32-ops?"
+
+
+def _regs(tok):
+    """('v' | 'a', {numbers}) of an operand like v12, v[10:13], a[0:15]; None for anything else."""
+    m = re.match(r"^([va])(\d+)$", tok) or re.match(r"^([va])\[(\d+):(\d+)\]$", tok)
+    if not m:
+        return None
+    lo = int(m.group(2))
+    hi = int(m.group(3)) if m.lastindex == 3 else lo
+    return m.group(1), set(range(lo, hi + 1))
+
+
+def test_no_register_of_an_inflight_lds_read_is_reused_before_its_wait(code_objects):
+    """The fragment reads of gemm_pp.h are inline asm, so the compiler believes their destination registers are written when the read is
+    ISSUED.  A destination dword nobody uses (round 4: the zero word of an MX operand, of which the matrix instruction reads six of eight
+    registers) is then free for reuse at once — hipcc put an LDS address there, and the read's late write-back turned the following reads
+    into garbage: NaNs on the GPU, nothing on the host shim.  The second form of the same assumption: the copies that assemble an MX
+    operand's register tuple, hoisted (loop-invariant code motion) to the read itself — they READ the destination before the data is there.
+    Walk every pipelined-GEMM kernel along its control flow: between a ds_read and the s_waitcnt that retires it (LDS operations of a wave
+    complete in order) no instruction may mention one of its destination registers (csrc/common.h pin_after_wait is the fix for both)."""
+    checked, bad = 0, []
+    for co in code_objects:
+        dis = subprocess.run([TOOLS[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        for name, body in pp_kernels(dis).items():
+            addr = {}
+            for idx, (ln, _) in enumerate(body):
+                m = re.search(r"//\s*([0-9A-Fa-f]+):", ln)
+                if m:
+                    addr[int(m.group(1), 16)] = idx
+            base = min(addr)
+
+            def target(ln):
+                m = re.search(r"<[^>]*\+0x([0-9a-f]+)>", ln)
+                return addr.get(base + int(m.group(1), 16)) if m else None
+
+            seen, work = set(), [(0, ())]
+            while work:
+                idx, pending = work.pop()
+                while idx < len(body):
+                    if (idx, pending) in seen:
+                        break
+                    seen.add((idx, pending))
+                    ln, ins = body[idx]
+                    op, _, rest = ins.partition(" ")
+                    ops = [t.strip() for t in rest.split(",")] if rest else []
+                    if op == "s_endpgm":
+                        break
+                    if op.startswith("s_cbranch") or op == "s_branch":
+                        t = target(ln)
+                        if t is not None:
+                            work.append((t, pending))
+                        if op == "s_branch":
+                            break
+                        idx += 1
+                        continue
+                    if op == "s_waitcnt":
+                        m = re.search(r"lgkmcnt\((\d+)\)", ins)
+                        if m:
+                            n = int(m.group(1))
+                            pending = pending[len(pending) - n:] if n else ()
+                        idx += 1
+                        continue
+                    # any mention of a register whose LDS read is still in flight: written (the read's late write-back lands in the new value)
+                    # or read (the data is not there yet) — operands like v[10:13], v7, a[0:15]; modifiers / immediates do not parse
+                    for tok in ops:
+                        r = _regs(tok.split(" ")[0])
+                        if r and any(kind == r[0] and set(regs) & r[1] for kind, regs in pending):
+                            bad.append((name[:90], ins))
+                            break
+                    if op.startswith("ds_read"):
+                        r = _regs(ops[0])
+                        if r:
+                            pending = pending + ((r[0], tuple(sorted(r[1]))),)
+                    idx += 1
+            checked += 1
+    assert checked >= 20, checked
+    assert not bad, bad[:6]

@@ -22,7 +22,7 @@ def run(make_engine, capfd, prec, variant, epi, M, N, K):
     os.environ["KB_CHECK"] = "1"
     try:
         ms = C.c_double()
-        st = eng.lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS[prec], variant, epi, M, N, K, 1, C.byref(ms))
+        st = eng.bench_lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS[prec], variant, epi, M, N, K, 1, C.byref(ms))
     finally:
         os.environ.pop("KB_CHECK", None)
     err = capfd.readouterr().err
@@ -67,7 +67,8 @@ def test_pp_variant_equals_generic_kernel_fp16(emu_engine, capfd, variant, M, N,
 # The correction terms are rounded to ~4 bits per factor, so the results are close to — not bytes of — the three-term product: the bound
 # is the scheme's own error (2^-16 per operand relative to the block maximum, summed over K), the check that it is non-zero shows the MX
 # instruction ran.  Every tile instantiated for MX lines (gemm.hip F5_MX_TILES), ragged shapes, the k-split tile with >= 3 k-tiles per group.
-MX_CASES = [(50, 300, 288), (54, 250, 160), (55, 250, 160), (56, 250, 224), (59, 130, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (66, 130, 160)]
+MX_CASES = [(50, 300, 288), (54, 250, 160), (55, 250, 160), (56, 250, 224), (59, 130, 160), (61, 200, 224), (62, 250, 160), (63, 130, 160), (66, 130, 160),
+            (68, 250, 224), (69, 250, 160)]  # 68 / 69: the k-step split (the groups take the fp6 correction of alternate k-tiles)
 
 
 def run_mx(make_engine, capfd, variant, epi, M, N, K):
@@ -77,7 +78,7 @@ def run_mx(make_engine, capfd, variant, epi, M, N, K):
     os.environ["KB_CHECK"] = "1"
     try:
         ms = C.c_double()
-        st = eng.lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16m"], variant, epi, M, N, K, 1, C.byref(ms))
+        st = eng.bench_lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16m"], variant, epi, M, N, K, 1, C.byref(ms))
     finally:
         os.environ.pop("KB_CHECK", None)
     err = capfd.readouterr().err
@@ -114,7 +115,7 @@ def test_mx_pack_and_layernorm_rows_against_the_format(emu_engine, rows, K):  # 
 
     eng = emu_engine(config.DIT_TINY)
     out = (C.c_double * 9)()
-    assert eng.lib.f5hip_bench_mx_pack(eng._ctx, rows, K, out) == 0
+    assert eng.bench_lib.f5hip_bench_mx_pack(eng._ctx, rows, K, out) == 0
     for which in range(3):
         wc, wl, bad = out[3 * which], out[3 * which + 1], out[3 * which + 2]
         assert bad == 0 and 0.2 < wc <= 0.5001 and 0.1 < wl <= 0.27, (which, wc, wl, bad)  # (remainders stay below 4 block steps: their top binade rounds to 0.125)
@@ -125,7 +126,7 @@ def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
 
     eng = make_engine(config.DIT_TINY)
     ms, diff = C.c_double(), C.c_int64()
-    st = eng.lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS[prec], variant, seqs, nseq, K, 1, 1, C.byref(ms), C.byref(diff))
+    st = eng.bench_lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS[prec], variant, seqs, nseq, K, 1, 1, C.byref(ms), C.byref(diff))
     err = capfd.readouterr().err
     assert st == 0, err
     return diff.value, err

@@ -30,7 +30,7 @@ def main():
     EPI = int(os.environ.get("KB_EPI", "1"))
     VSET = tuple(int(x) for x in os.environ.get("KB_VARIANTS", "1,2,3,4,5").split(","))
     eng = F5HipEngine(config.DIT_TINY, None, device=0)
-    lib, ctx = eng.lib, eng._ctx
+    lib, ctx = eng.bench_lib, eng._ctx  # include/f5hip_bench.h (libf5hip_bench.so)
     ms = C.c_double()
     if what == "one":  # one gemm config: one <prec> <variant> M N K [iters]   (for rocprofv3 --pmc runs)
         prec, v, M, N, K = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
