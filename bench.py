@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU per step (configs[2] uses 32)")
     ap.add_argument("--nfe", type=int, default=16)
-    ap.add_argument("--precision", default="fp16x3", choices=["fp32", "fp16x3", "fp16m", "fp16"])
+    ap.add_argument("--precision", default="fp16m", choices=["fp32", "fp16x3", "fp16m", "fp16"],
+                    help="fp16m (default): the parity mode — fp16 hi/lo split operands whose two correction products per 32 k of the block GEMMs are one MX-fp6 MFMA; "
+                         "fp16x3: the three-fp16-MFMA split of rounds 1-3; fp16: what the reference runs on a GPU (misses the 1e-3 tolerance); fp32: exact")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="F5TTS_v1_Base")

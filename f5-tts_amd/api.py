@@ -61,7 +61,7 @@ def save_spectrogram(spectrogram, path: str) -> str:
 
 class F5TTS:
     def __init__(self, model: str = "F5TTS_v1_Base", ckpt_file: str = "", vocab_file: str = "", ode_method: str = "euler", use_ema: bool = True,
-                 vocoder_local_path: Optional[str] = None, device=None, hf_cache_dir=None, *, precision: str = "fp16x3",
+                 vocoder_local_path: Optional[str] = None, device=None, hf_cache_dir=None, *, precision: str = "fp16m",
                  mel_spec_type: str = "vocos", vocos_cfg: VocosConfig = VOCOS_MEL_24K,
                  state_dict: Optional[Dict[str, torch.Tensor]] = None, vocoder_state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  transcribe: Optional[Callable[[str], str]] = None, bigvgan_cfg=None):

@@ -570,7 +570,8 @@ int f5hip_bigvgan_forward(f5hip_bigvgan* v, const float* mel, int batch, int fra
   std::lock_guard<std::mutex> lk(v->mu);
   if (!v->finalized) FAIL(F5HIP_ERR_STATE, "weights not finalised (f5hip_bigvgan_finalize)");
   if (!mel || !out || batch <= 0 || frames <= 0) FAIL(F5HIP_ERR_INVALID, "bad argument: mel/out null or batch/frames <= 0");
-  if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
+  if (precision < F5HIP_PREC_FP32 || precision > F5HIP_PREC_FP16M) FAIL(F5HIP_ERR_INVALID, "bad precision %d", precision);
+  if (precision == F5HIP_PREC_FP16M) precision = F5HIP_PREC_FP16X3;  // the MX lines are the DiT / UNetT block GEMMs': the conv GEMMs run the three-term product
   HIPCHK(hipSetDevice(v->device));
   const int rc = forward_impl(v, mel, batch, frames, channel_major, precision, out, reinterpret_cast<hipStream_t>(stream));
   bv_collect(v, reinterpret_cast<hipStream_t>(stream));

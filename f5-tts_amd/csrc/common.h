@@ -197,6 +197,19 @@ __device__ __forceinline__ void mx_mma(f32x16& acc, const uint4& w0, const uint4
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc, 2, 2, 0, (int)w1.z, 0, (int)a1.z);
 }
 
+// A wave's own LDS writes become readable by its own lanes: LDS operations of one wave are processed in order, so nothing has to be
+// waited for — the compiler only must not move the reads above the writes.  (The host shim runs the lanes of a wave as fibers that switch
+// at barriers: there it is a real wave rendezvous.)
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef F5_HIPEMU
+  hipemu::barrier_wait(hipemu::wv().bar);
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // wave-uniform: does any lane hold the predicate?
 __device__ __forceinline__ bool f5_wave_any(bool pred) {
 #ifdef F5_HIPEMU

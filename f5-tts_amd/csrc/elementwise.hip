@@ -125,16 +125,17 @@ __device__ __forceinline__ void mx_store_half(char* line, int h, const uint32_t 
 // instruction touched all 32 lines of the row; 332 against 188 ms of LayerNorm per B = 32 step.  profiles/r04c_*.)  LDS image: group G at
 // slot (G & ~7) | ((G & 7) ^ 2 ((G >> 3) & 3)): the natural writes (8 lanes = one 128-byte line) and the transposed reads (a lane pair per
 // line, four lines per 8 lanes) are both bank-conflict free.
-template <int NB>  // passes: D <= 1024 NB
+template <int NB, bool EARLY>  // passes: D <= 1024 NB; EARLY: per-channel parameters requested before the row reduction (few rows: latency; many
+                              // rows: the registers cost occupancy and with it bandwidth — as layernorm_kernel, profiles/r04d_*: 4.0 against 5.7 TB/s)
 __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, f16* out16,
                                                             int64_t ldo16, int mode) {
   __shared__ float4 xpose[WAVES_PER_BLOCK][NB * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane & 1;
-  const int row_raw = blockIdx.x * WAVES_PER_BLOCK + wave;
-  const bool live = row_raw < M;  // (no early exit: the block barrier below is executed by every wave)
-  const int row = live ? row_raw : M - 1;
+  const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
+  if (row >= M) return;  // (whole waves: the transpose below synchronises the wave only)
+  constexpr bool live = true;
   const float* xr = x + (int64_t)row * ldx;
   const float* A = weight ? weight : scale;
   const float* Bp = weight ? bias : shift;
@@ -146,8 +147,10 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
       const int c = (b * 256 + i * 64 + lane) * 4;
       const bool in = c < D;
       v[b][i] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pa[b][i] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pb[b][i] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (EARLY) {
+        pa[b][i] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pb[b][i] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   float sum = 0.f;
 #pragma unroll
@@ -176,13 +179,19 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float t[4] = {(v[b][i].x - mean) * rstd, (v[b][i].y - mean) * rstd, (v[b][i].z - mean) * rstd, (v[b][i].w - mean) * rstd};
+      if constexpr (!EARLY) {
+        const int c = (b * 256 + i * 64 + lane) * 4;
+        const bool in = c < D;
+        pa[b][i] = (A && in) ? *reinterpret_cast<const float4*>(A + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pb[b][i] = (Bp && in) ? *reinterpret_cast<const float4*>(Bp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       if (weight) { t[0] = t[0] * pa[b][i].x + pb[b][i].x; t[1] = t[1] * pa[b][i].y + pb[b][i].y; t[2] = t[2] * pa[b][i].z + pb[b][i].z; t[3] = t[3] * pa[b][i].w + pb[b][i].w; }
       else if (scale) { t[0] = t[0] * (1.0f + pa[b][i].x) + pb[b][i].x; t[1] = t[1] * (1.0f + pa[b][i].y) + pb[b][i].y;
                         t[2] = t[2] * (1.0f + pa[b][i].z) + pb[b][i].z; t[3] = t[3] * (1.0f + pa[b][i].w) + pb[b][i].w; }
       const int G = b * 256 + i * 64 + lane;
       tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))] = make_float4(t[0], t[1], t[2], t[3]);
     }
-  __syncthreads();
+  wave_lds_sync();  // the wave's own 4 KB: no block barrier (a block-wide one cost bandwidth at many rows: 4.0 against 5.7 TB/s, profiles/r04d_*)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int blk = 32 * b + (lane >> 1);
@@ -575,8 +584,11 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps
   if (pk16 == 2) {  // MX operand rows (fp16m): a kernel of its own lane layout
     if (D % 32 || out32 || !out16 || ldo16 % 8 || (reinterpret_cast<uintptr_t>(out16) & 15) || (weight && scale)) return hipErrorInvalidValue;
     dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    if (D <= 1024) hipLaunchKernelGGL(layernorm_mx_kernel<1>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode);
-    else hipLaunchKernelGGL(layernorm_mx_kernel<2>, grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode);
+    const bool early = M < 8192;
+#define F5_LNMX(NB, E) hipLaunchKernelGGL((layernorm_mx_kernel<NB, E>), grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode)
+    if (D <= 1024) { if (early) F5_LNMX(1, true); else F5_LNMX(1, false); }
+    else { if (early) F5_LNMX(2, true); else F5_LNMX(2, false); }
+#undef F5_LNMX
     return hipGetLastError();
   }
   // paired 16-byte half stores: whole pairs of 4-channel groups per row, 16-byte aligned rows

@@ -155,7 +155,7 @@ def load_checkpoint(engine: F5HipEngine, ckpt_path: str, use_ema: bool = True, f
 
 
 def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos", vocab_file: str = "", ode_method: str = ode_method,
-               use_ema: bool = True, device=0, precision: str = "fp16x3", vocos_cfg: Optional[VocosConfig] = VOCOS_MEL_24K,
+               use_ema: bool = True, device=0, precision: str = "fp16m", vocos_cfg: Optional[VocosConfig] = VOCOS_MEL_24K,
                state_dict: Optional[Dict[str, torch.Tensor]] = None, model_cls=None) -> F5HipCFM:
     """reference utils_infer.py:238-276 — ``load_model(model_cls, model_cfg, ckpt_path, ...)``.  The reference's leading ``model_cls``
     argument (the backbone CLASS: DiT / UNetT / MMDiT) is the keyword ``model_cls`` here — a class or its name; it is REQUIRED when
@@ -203,7 +203,7 @@ def load_model(model_cfg, ckpt_path: Optional[str], mel_spec_type: str = "vocos"
 
 
 def load_vocoder(vocoder_name: str = "vocos", is_local: bool = True, local_path: str = "", engine: Optional[F5HipEngine] = None,
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, device=0, precision: str = "fp16x3", bigvgan_cfg=None, **_ignored):
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, device=0, precision: str = "fp16m", bigvgan_cfg=None, **_ignored):
     """reference utils_infer.py:106-145.
 
     ``"vocos"`` (:107-129): ``<local_path>/pytorch_model.bin`` (config.yaml is the fixed charactr/vocos-mel-24khz architecture =

@@ -8,7 +8,7 @@ compiler can vouch for:
 * no kernel of the library spills to scratch.
 * no kernel of the library holds a packed-fp32 instruction in the operand form that loses src1 on gfx950 while another wave on the SIMD
   issues MFMAs and LDS reads (op_sel: src0 low half from the low register, src1 low half from the HIGH register — found in round 3 as
-  the cause of round 2's "co-residency race"; reproducer tools/probes/pk_opsel_probe.hip, sweep tools/probes/pk_opsel_sweep.hip).  The
+  the cause of round 2's "co-residency race"; reproducer tools/probes/pk_opsel_probe.hip, sweep tools/probes/gen_pk_opsel_sweep.py).  The
   library is built with -packed-fp32-ops, so hipcc emits no v_pk_{add,mul,fma}_f32 at all; only the reproducer (csrc/race_probe.hip)
   keeps them — in libf5hip_bench.so (tools and tests), not in the engine's library.
 """

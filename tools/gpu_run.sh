@@ -105,34 +105,38 @@ evidence)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
   timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $out/gpu_tests.log; cat $out/gpu_tests.log
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/smoke.log
-  timeout 900 python bench.py --steps 10 --warmup 3 > $out/bench_b1.json 2> $out/bench_b1.err
-  timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16 --no-cpu-baseline > $out/bench_b1_fp16.json 2> /dev/null
-  timeout 600 python bench.py --steps 3 --warmup 1 --batch 4 --nfe 32 --no-cpu-baseline > $out/bench_b4_nfe32.json 2> /dev/null
-  timeout 600 python bench.py --steps 3 --warmup 1 --batch 8 --no-cpu-baseline > $out/bench_b8.json 2> /dev/null
-  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --no-cpu-baseline > $out/bench_b32_nfe32.json 2> /dev/null
-  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --precision fp16 --no-cpu-baseline > $out/bench_b32_nfe32_fp16.json 2> /dev/null
-  timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_e2_b8_bigvgan.json 2> /dev/null
+  # the headline line exactly as the driver runs it (default precision fp16m; carries cpu_baseline and other_configs = configs[2], configs[4])
+  timeout 1500 python bench.py --steps 10 --warmup 3 > $out/bench_b1.json 2> $out/bench_b1.err
+  Q="--no-cpu-baseline --no-other-configs"
+  timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16x3 $Q > $out/bench_b1_fp16x3.json 2> /dev/null
+  timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16 $Q > $out/bench_b1_fp16.json 2> /dev/null
+  timeout 600 python bench.py --steps 3 --warmup 1 --batch 4 --nfe 32 $Q > $out/bench_b4_nfe32.json 2> /dev/null
+  timeout 600 python bench.py --steps 3 --warmup 1 --batch 8 $Q > $out/bench_b8.json 2> /dev/null
+  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/bench_b32_nfe32.json 2> /dev/null
+  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --precision fp16x3 $Q > $out/bench_b32_nfe32_fp16x3.json 2> /dev/null
+  timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 $Q > $out/bench_e2_b8_bigvgan.json 2> /dev/null
   for f in $out/bench_*.json; do line $f $(basename $f .json); done
-  trace $out b1 --steps 3 --warmup 1
-  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32
-  pmc $out fp16x3_b1 --batch 1 --nfe 16
-  pmc $out fp16x3_b32 --batch 32 --nfe 2
-  B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048;1406,2048,1024;1406,1024,2048"
-  MID="5624,2048,1024;11248,2048,1024;11248,1024,2048;22496,1024,1024;89984,2048,1024;89984,1024,2048"
-  { for epi in 1 2; do KB_SHAPES=$B1 KB_PRECS=fp16x3 KB_EPI=$epi KB_VARIANTS=-1,1,55,56,59,66,68,69 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-330; done
-    for epi in 1 2; do KB_SHAPES=$MID KB_PRECS=fp16x3,fp16 KB_EPI=$epi KB_VARIANTS=-1,50,51,58,61,62,63 timeout 400 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-330; done
-    for sq in "2 1406" "8 1406" "64 1406"; do timeout 300 python tools/kernel_bench.py qkv fp16x3 $sq -1,50,55,61,62,68 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done
-    timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn
+  trace $out b1 --steps 3 --warmup 1 --no-other-configs
+  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32 --no-other-configs
+  pmc $out fp16m_b1 --batch 1 --nfe 16 --no-other-configs
+  pmc $out fp16m_b32 --batch 32 --nfe 2 --no-other-configs
+  B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048"
+  MID="11248,2048,1024;22496,1024,2048;89984,2048,1024;89984,1024,2048"
+  { for epi in 1 2; do
+      KB_SHAPES=$B1 KB_PRECS=fp16x3,fp16m,fp16 KB_EPI=$epi KB_VARIANTS=-1 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-200
+      KB_SHAPES=$MID KB_PRECS=fp16x3,fp16m,fp16 KB_EPI=$epi KB_VARIANTS=-1 timeout 400 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-200
+    done
+    for sq in "2 1406" "8 1406" "64 1406"; do for prec in fp16x3 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec $sq -1 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done; done
     KB_ATTN_LOG2Q=1 timeout 300 python tools/kernel_bench.py attn 2>&1 | grep ^attn | sed "s/^/lazy /"; } > $out/kernel_bench.log 2>&1
   tail -12 $out/kernel_bench.log | cut -c1-200
   [ -x tools/probes/hipblaslt_ref ] && timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1
   timeout 900 python tools/attn_precision_check.py > $out/attn_precision.log 2>&1; tail -6 $out/attn_precision.log ;;
 counters)  # the rocprofv3 half of `evidence` alone (kernel-trace summaries + PMC passes)
   tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
-  trace $out b1 --steps 3 --warmup 1
-  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32
-  pmc $out fp16x3_b1 --batch 1 --nfe 16
-  pmc $out fp16x3_b32 --batch 32 --nfe 2 ;;
+  trace $out b1 --steps 3 --warmup 1 --no-other-configs
+  trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32 --no-other-configs
+  pmc $out fp16m_b1 --batch 1 --nfe 16 --no-other-configs
+  pmc $out fp16m_b32 --batch 32 --nfe 2 --no-other-configs ;;
 tiles)
   tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
   KB_SHAPES=${2:?shapes} KB_VARIANTS=${3:?variants} KB_EPI=${4:-1} KB_PRECS=${5:-fp16x3} timeout 900 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | cut -c1-340 | tee $out/tiles.log ;;
@@ -150,6 +154,7 @@ race)
   rm -f $out/*.bin; head -c 2500 $(ls $out/dump.*.txt 2>/dev/null | head -1) 2>/dev/null ;;
 pkprobe)
   tag=${1:?tag}; out=$R/gpurun_out/$tag; mkdir -p $out; cd tools/probes
+  [ -f pk_opsel_sweep.hip ] || python gen_pk_opsel_sweep.py  # the sweep's source is generated (1 300 lines): only the generator is in the tree
   for b in pk_opsel_probe pk_opsel_sweep; do [ -x $b ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $b $b.hip 2> /dev/null; done
   { for m in 0 1 4 5 13; do timeout 120 ./pk_opsel_probe 2 $m 20000 | tail -1; done; } > $out/pk_probe.log 2>&1
   timeout 600 ./pk_opsel_sweep 4000 1 > $out/sweep_partners.log 2>&1; timeout 600 ./pk_opsel_sweep 4000 0 > $out/sweep_alone.log 2>&1

@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--list"); ap.add_argument("--out", default="infer_out")
     ap.add_argument("--model", default="F5TTS_v1_Base"); ap.add_argument("--ckpt"); ap.add_argument("--vocab"); ap.add_argument("--vocos")
     ap.add_argument("--synthetic", type=int, default=0); ap.add_argument("--nfe", type=int, default=16)
-    ap.add_argument("--precision", default="fp16x3"); ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--precision", default="fp16m"); ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--testset", choices=["seedtts", "ls_pc_test_clean"], default=None,
                     help="read --list with the reference's test-list parsers (eval/utils_eval.py:19-52) instead of the utt|wav|ref|gen layout")
     ap.add_argument("--librispeech-path", default="", help="root of LibriSpeech test-clean for --testset ls_pc_test_clean")

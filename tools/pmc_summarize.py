@@ -16,6 +16,8 @@ def klass(name):
     if "gemm_pp_kernel" in name or ("gemm_kernel" in name and ("EpiQKV" in name or "EpiStore" in name)):
         if "DF16_Li3" in name or "_Float16, 3" in name:
             return "gemm_fp16x3"
+        if "DF16_Li2" in name or "_Float16, 2" in name:  # MX lines (fp16m): 2 fp16 MFMAs + 1 MX-fp6 MFMA per 32 k
+            return "gemm_fp16m"
         if "DF16_Li1" in name or "_Float16, 1" in name:
             return "gemm_fp16"
         return "gemm_fp32"
@@ -63,7 +65,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--nfe", type=int, default=16)
-    ap.add_argument("--precision", default="fp16x3")
+    ap.add_argument("--precision", default="fp16m")  # bench.py's default
     ap.add_argument("--model", default="F5TTS_v1_Base")
     a, _ = ap.parse_known_args(sys.argv[2:])
     fetch, write = load(os.path.join(out, "fetch"), "FETCH_SIZE"), load(os.path.join(out, "write"), "WRITE_SIZE")
