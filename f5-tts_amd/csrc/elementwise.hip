@@ -101,23 +101,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 // fp16m operand rows (common.h "fp16 + MX-fp6 corrections"): LayerNorm producer and one-time / test packing
 // ---------------------------------------------------------------------------------------------
-// store one half-line: the 16 hi halves of channels 8 q + 4 h + e (two lanes of a pair fill the 64-byte hi region) and the lane's P words
-__device__ __forceinline__ void mx_store_half(char* line, int h, const uint32_t (&hi)[8], const uint32_t (&p)[8]) {
-  // neighbouring lanes (h = 0, 1) hold the two 8-byte halves of every 16-byte chunk q: lane 0 collects chunks 0 and 1, lane 1 chunks 2 and 3
-  uint32_t r[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = (uint32_t)__shfl_xor((int)(h ? hi[i] : hi[4 + i]), 1, 64);
-  if (h == 0) {
-    *reinterpret_cast<uint4*>(line) = make_uint4(hi[0], hi[1], r[0], r[1]);
-    *reinterpret_cast<uint4*>(line + 16) = make_uint4(hi[2], hi[3], r[2], r[3]);
-  } else {
-    *reinterpret_cast<uint4*>(line + 32) = make_uint4(r[0], r[1], hi[4], hi[5]);
-    *reinterpret_cast<uint4*>(line + 48) = make_uint4(r[2], r[3], hi[6], hi[7]);
-  }
-  *reinterpret_cast<uint4*>(line + 64 + 32 * h) = make_uint4(p[0], p[1], p[2], p[3]);
-  *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[4], p[5], p[6], p[7]);
-}
-
 // LayerNorm / RMSNorm / copy (+ affine | AdaLN modulation) -> MX operand rows.  One wave per row.  The row is loaded, reduced and normalised
 // in the coalesced layout of layernorm_kernel (lane L, piece i: the float4 group G = 64 i + L of a 1024-channel pass), then transposed
 // through the wave's own 4 KB of LDS so that lane L = 2 blk + h owns the 16 channels 32 blk + 8 q + 4 h + e — exactly one P_h of common.h —
@@ -131,11 +114,10 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, f16* out16,
                                                             int64_t ldo16, int mode) {
-  __shared__ float4 xpose[WAVES_PER_BLOCK][NB * 256];
+  __shared__ float4 xpose[WAVES_PER_BLOCK][NB * 288];  // 4 KB of values per 1024 channels, re-used as the 32 x 144-byte image of the packed lines
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane & 1;
   const int row = blockIdx.x * WAVES_PER_BLOCK + wave;
-  if (row >= M) return;  // (whole waves: the transpose below synchronises the wave only)
-  constexpr bool live = true;
+  if (row >= M) return;  // (whole waves: the transposes below synchronise the wave only)
   const float* xr = x + (int64_t)row * ldx;
   const float* A = weight ? weight : scale;
   const float* Bp = weight ? bias : shift;
@@ -192,6 +174,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
       tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))] = make_float4(t[0], t[1], t[2], t[3]);
     }
   wave_lds_sync();  // the wave's own 4 KB: no block barrier (a block-wide one cost bandwidth at many rows: 4.0 against 5.7 TB/s, profiles/r04d_*)
+  uint32_t hi[NB][8], p[NB][8];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int blk = 32 * b + (lane >> 1);
@@ -202,13 +185,31 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
       const float4 t = tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))];
       y[4 * q] = t.x; y[4 * q + 1] = t.y; y[4 * q + 2] = t.z; y[4 * q + 3] = t.w;
     }
-    uint32_t hi[8], p[8];
-    mx_pack16<false>(y, hi, p);
-    // (whole waves run the exchange inside mx_store_half; rows past M and blocks past D are dropped here — D % 32 == 0, so both lanes of a pair agree)
-    char* line = reinterpret_cast<char*>(out16 + (int64_t)row * ldo16) + (int64_t)blk * 128;
-    if (live && 32 * blk < D) mx_store_half(line, h, hi, p);
-    else { uint32_t sink[4]; for (int i = 0; i < 4; ++i) sink[i] = (uint32_t)__shfl_xor((int)hi[i], 1, 64); (void)sink; }
+    mx_pack16<false>(y, hi[b], p[b]);
   }
+  // The packed lines leave through LDS as well: a lane holds 64 scattered bytes of its line (8-byte hi pieces, its 32-byte P words), and
+  // stores of 16 bytes at a 64-byte stride reach 4.0 TB/s where the fp16x3 kernel's contiguous ones reach 5.7 (profiles/r04d_*).  Image of
+  // line blk at 144 blk (the 16 bytes of padding walk the banks), then every lane stores consecutive 16-byte pieces of the row.
+  wave_lds_sync();  // every lane has taken its values out of tp
+  char* img = reinterpret_cast<char*>(tp);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int blk = 32 * b + (lane >> 1);
+    char* line = img + blk * 144;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(line + 16 * q + 8 * h) = make_uint2(hi[b][2 * q], hi[b][2 * q + 1]);
+    *reinterpret_cast<uint4*>(line + 64 + 32 * h) = make_uint4(p[b][0], p[b][1], p[b][2], p[b][3]);
+    *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[b][4], p[b][5], p[b][6], p[b][7]);
+  }
+  wave_lds_sync();
+  char* orow = reinterpret_cast<char*>(out16 + (int64_t)row * ldo16);
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = (b * 4 + i) * 64 + lane, ln = g >> 3, pc = g & 7;  // 16-byte piece pc of line ln
+      if (32 * ln < D) *reinterpret_cast<uint4*>(orow + (int64_t)ln * 128 + pc * 16) = *reinterpret_cast<const uint4*>(img + ln * 144 + pc * 16);
+    }
 }
 
 // [rows, K] fp32 (row stride ld) x rowscale[r] -> MX operand rows [rows, 2K halves]; WEIGHT selects which of (coarse, remainder) leads in P

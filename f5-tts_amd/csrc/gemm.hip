@@ -171,11 +171,9 @@ F5_PPV(67, 3, 1, 2, 2, 2, 3, +1);  // 192x64,  2 x 4 waves of 96x32 = 128 KB
 F5_PPV(68, 3, 3, 2, 2, 3, 1, +2);  // 192x192, 2 x 4 waves of 96x96, 3 stages = 144 KB
 F5_PPV(69, 3, 2, 2, 2, 3, 3, +2);  // 192x128, 2 x 4 waves of 96x64, 3 stages = 120 KB
 F5_PPV(70, 3, 1, 2, 2, 3, 3, +2);  // 192x64,  2 x 4 waves of 96x32, 3 stages =  96 KB
-// round 4 (MX lines only): 256x256 as FOUR waves of 128x128 — one wave per SIMD, the 16 accumulator tiles in AGPRs.  With the MFMA work per
-// product halved the 8-wave 256x256 tile is bound by LDS bandwidth (48 fragment reads per wave-k-block x 8 waves + the DMA = 133 % of the
-// MFMA time); the 128x128 wave tile reads 32 per wave x 4 waves = 2/3 of that.
-F5_PPV(71, 4, 4, 2, 2, 2, 1);
-F5_PPV(72, 4, 4, 2, 2, 2, 2);
+// (round 4, measured and removed: 256x256 as FOUR waves of 128x128 — one wave per SIMD, 16 accumulator tiles in AGPRs, 2/3 of the 8-wave tile's
+// fragment reads — for MX lines, where LDS bandwidth bounds the 8-wave tile: 8-10 % SLOWER at M = 11k .. 90k (881 against 816 us on FF1 at
+// 90k rows; profiles/r04e_tiles_4wave.log): with one wave per SIMD nothing hides the fragment waits and the barrier)
 // (deeper rings — 192x64 k-step split x 5 stages, 192x128 x 4, 96x128 / 4 waves x 5, 192x128 / 8 waves x 4 — measured the same or 1-3 % slower
 // than the 3-stage tiles: the one-round k-loops are not waiting for their DMA; profiles/r02e_deep_rings.log)
 #undef F5_PPV
@@ -222,7 +220,7 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
 
 // the tiles instantiated for MX lines (NSPLIT 2): the tiles pick_pp_variant can choose in that mode plus their microbenchmark
 // alternatives — every instantiation is a minute of build time
-#define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66) X(68) X(69) X(71) X(72)
+#define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66) X(68) X(69)
 template <int NSPLIT, typename Epi>
 hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s) {
   if constexpr (NSPLIT == 2) {
