@@ -150,7 +150,7 @@ hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f1
   a.log2q = log2q;
   a.cu_rows = cu_rows;
   if (cu_rows && (kv_split > 1 || !kvlen)) return hipErrorInvalidValue;  // packed rows: the unsplit kernel, lengths required
-  if (o_packed == 2 && (kv_split > 1 || (reinterpret_cast<uintptr_t>(o16) & 15))) return hipErrorInvalidValue;  // MX lines: the kernels' own epilogue only (not the merge kernel)
+  if (o_packed >= 2 && (kv_split > 1 || (reinterpret_cast<uintptr_t>(o16) & 15))) return hipErrorInvalidValue;  // MX lines: the kernels' own epilogue only (not the merge kernel)
   a.kv_split = kv_split < 1 ? 1 : kv_split; a.part_o = part_o; a.part_ml = part_ml;
   a.o_packed = o_packed;
   a.kvlen2 = kvlen2; a.seg2_off = seg2_off;

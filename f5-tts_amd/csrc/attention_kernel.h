@@ -41,9 +41,28 @@ struct FlashArgs {
 // The operand row of the out-projection from a lane's share of a normalised output row: lane (row, hi) owns O[32 db + 8 c + 4 hi + e] =
 // o[db][4 c + e].  o_packed 0: plain fp16 rows, 1: packed hi | lo lines (fp16x3), 2: MX lines (fp16m, common.h) — the lane's 16 features of
 // a 32-block are exactly the k-set of P_hi, so the pack needs no lane exchange.
-__device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16 (&o)[2], float inv, int64_t row, int hh, int hi) {
+__device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16 (&o)[2], float inv, int64_t row, int hh, int hi, bool live) {
+  if (a.o_packed == 3) {  // fp16m2 rows [inner hi halves | units]: the lane pair (l, l ^ 32) trades halves first (whole waves: `live` only gates the stores)
+    char* orow3 = reinterpret_cast<char*>(a.o) + row * ((int64_t)a.heads * 64 * 3);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float x[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) x[t] = o[db][t] * inv;
+      mx2_unit_order(x);
+      uint32_t hv[8], xw[4];
+      mx2_pack16<false>(x, hv, xw);
+      if (live) {
+        char* hp = orow3 + (hh * 64 + 32 * db + 8 * hi) * 2;
+        *reinterpret_cast<uint4*>(hp) = make_uint4(hv[0], hv[1], hv[2], hv[3]);
+        *reinterpret_cast<uint4*>(hp + 32) = make_uint4(hv[4], hv[5], hv[6], hv[7]);
+        *reinterpret_cast<uint4*>(orow3 + (int64_t)a.heads * 128 + (hh * 2 + db) * 32 + 16 * hi) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+      }
+    }
+    return;
+  }
   const int64_t orow = row * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
-  if (a.o_packed == 2) {
+  if (a.o_packed == 2) {  // MX lines: the P word is the lane's own; the hi halves trade quads with the partner lane (l ^ 32) for 16-byte stores (whole waves)
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       float x[16];
@@ -51,14 +70,19 @@ __device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16
       for (int t = 0; t < 16; ++t) x[t] = o[db][t] * inv;
       uint32_t hv[8], pw[8];
       mx_pack16<false>(x, hv, pw);
-      char* line = reinterpret_cast<char*>(a.o + orow) + (int64_t)(hh * 2 + db) * 128;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) *reinterpret_cast<uint2*>(line + (8 * c + 4 * hi) * 2) = make_uint2(hv[2 * c], hv[2 * c + 1]);
-      *reinterpret_cast<uint4*>(line + 64 + 32 * hi) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-      *reinterpret_cast<uint4*>(line + 80 + 32 * hi) = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+      for (int j = 0; j < 4; ++j) f5_swap32(hv[j], hv[4 + j]);  // half-wave 0: channels 0-15 (own quads 0, 1 + the partner's), half-wave 1: 16-31
+      if (live) {
+        char* line = reinterpret_cast<char*>(a.o + orow) + (int64_t)(hh * 2 + db) * 128;
+        *reinterpret_cast<uint4*>(line + 32 * hi) = make_uint4(hv[0], hv[1], hv[4], hv[5]);
+        *reinterpret_cast<uint4*>(line + 32 * hi + 16) = make_uint4(hv[2], hv[3], hv[6], hv[7]);
+        *reinterpret_cast<uint4*>(line + 64 + 32 * hi) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+        *reinterpret_cast<uint4*>(line + 80 + 32 * hi) = make_uint4(pw[4], pw[5], pw[6], pw[7]);
+      }
     }
     return;
   }
+  if (!live) return;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -365,9 +389,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     }
     return;
   }
-  if (qrow < q_end) {
-    flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
-  }
+  flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi, qrow < q_end);
 }
 
 // ---- LDS fragment reads with hand-placed waits (flash_pipe_kernel) -------------------------------------------------------------------
@@ -627,9 +649,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
   if (t < ntile) step(t, 0, sa, sb);
 
   const float l_tot = VSUM ? l_run + __shfl_xor(l_run, 32, 64) : l_run;
-  if (qrow < q_end) {
-    flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
-  }
+  flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi, qrow < q_end);
 }
 
 // Ping-pong form (round 3) of the production configuration (plain fp16 q, k, P, V; base-2 scores; lazy reference maximum; unsplit keys; row
@@ -864,9 +884,7 @@ __global__ __launch_bounds__(512, 1) void flash_pp_kernel(FlashArgs a) {
   }
   if (!half) phase_end();
 
-  if (qrow < q_end) {
-    flash_store_row(a, o, 1.0f / l_run, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi);
-  }
+  flash_store_row(a, o, 1.0f / l_run, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi, qrow < q_end);
 }
 
 // merge the kv_split partial results of every query row: O = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s with m = max_s m_s (the

@@ -4,7 +4,7 @@
 
 #include "gemm.h"  // common.h pulls in the HIP runtime (or the host shim under F5_HIPEMU)
 
-enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3 };  // GEMM operand kind; OP_F16M: fp16 + MX-fp6 correction lines (common.h), the
+enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3, OP_F16M2 = 4 };  // OP_F16M2: fp16m rows without the coarse values (common.h "fp16m2"): 96 bytes per 32 k  // GEMM operand kind; OP_F16M: fp16 + MX-fp6 correction lines (common.h), the
                                                              // pipelined block-GEMM kernel only (no generic-kernel fallback: launches fail)
 
 // ---- gemm.hip ---------------------------------------------------------------------------------
@@ -74,6 +74,8 @@ hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s);
 // [rows, K] fp32 (row stride ld floats) x rowscale[r] (or null) -> MX operand rows of OP_F16M (common.h): weight != 0 packs the W side
 hipError_t launch_pack_mx_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s);
+// the same -> fp16m2 rows of OP_F16M2 ([K hi halves | units], 1.5 K halves per row; K % 64 == 0)
+hipError_t launch_pack_mx2_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s);
 // W [rows, K] fp32 -> per-row power-of-two scale (largest entry to [2^12, 2^13)) and its inverse, the plain fp16 copy hi [rows, K] and the
 // packed hi | lo copy pk [rows, 2K] of the scaled rows (GemmCore::w_alpha takes `alpha`)
 // dst[r, :] = src[rowmap[r], :] (gather) / dst[rowmap[r], :] = src[r, :] (scatter) over `rows` rows of C floats (C % 4 == 0)

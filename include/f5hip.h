@@ -52,8 +52,10 @@ enum {
  *   FP16    fp16 operands, fp32 accumulate (what the reference runs on GPU: utils_infer.py:191-199)
  *   FP16M   FP16X3 with the two correction terms of every product of the DiT block GEMMs (q|k|v, out, FF1, FF2) taken as ONE MX-fp6
  *           matrix instruction per 32 k instead of two fp16 ones (1.5 MFMA-equivalents per product instead of 3; same accuracy class:
- *           DESIGN.md section 2).  Backbones / shapes / options the MX path is not built for run as FP16X3 (never less accurate). */
-enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2, F5HIP_PREC_FP16M = 3 };
+ *           DESIGN.md section 2).  Backbones / shapes / options the MX path is not built for run as FP16X3 (never less accurate).
+ *   FP16M2  not a mode of f5hip_sample (rejected there): names the 96-byte-row operand form of FP16M in the microbenchmarks of
+ *           libf5hip_bench.so (f5hip_bench.h).  The engine uses that form inside FP16M only when F5HIP_MX2=1 is set at finalize. */
+enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2, F5HIP_PREC_FP16M = 3, F5HIP_PREC_FP16M2 = 4 };
 
 /* Architecture of the backbone: the keyword arguments of reference src/f5_tts/model/backbones/dit.py:171-192 (DiT) /
  * unett.py:109-128 (UNetT) that change inference arithmetic. */

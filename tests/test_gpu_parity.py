@@ -315,6 +315,38 @@ print("PP_WORST", worst)
     assert worst < X3TOL
 
 
+@pytest.mark.parametrize("name,tol", [("tiny_v1_ragged_b2", MXTOL), ("tiny_mask_ragged_b3", MXTOL), ("small_v1", MXTOL), ("base_v1_cfg1", FULL_TOL)])
+def test_fp16m2_rows_opt_in(monkeypatch, name, tol):
+    """F5HIP_MX2=1 (read per finalize): fp16m with 96-byte operand rows for calls below 4096 rows — the coarse values of the correction
+    product derived in the k-loop from the `hi` fragments instead of being stored (csrc/common.h mx2_*, gemm_pp.h NSPLIT 4).  OFF by default:
+    13-20 % slower per GEMM than the 128-byte lines on the GPU (profiles/r04h_*).  Kept correct: the same goldens, a
+    tiny ragged one with packed rows too, the full-size configs[1] case; and different in the last bits from the default form (it ran)."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    full = name in MG.FULL_CASES
+    c = (MG.FULL_CASES if full else MG.CASES)[name]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
+    outs = {}
+    for env, packed in (("0", 0), ("1", 0)) + ((("1", 1),) if name == "tiny_mask_ragged_b3" else ()):
+        monkeypatch.setenv("F5HIP_MX2", env)
+        eng = F5HipEngine(cfg, None, device=0)
+        eng.load_state_dict(sd)
+        eng.set_option("packed_rows", packed)
+        out, _ = F5HipCFM(eng, precision="fp16m", ode_method=c.get("method", "euler")).sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+        outs[(env, packed)] = out.cpu()
+        eng.close()
+    g = torch.as_tensor(gold(name)["out"])
+    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * g.shape[0]
+    worst = 0.0
+    for (env, packed), out in outs.items():
+        if env == "1":
+            worst = max(worst, max(float((out[b, :d] - g[b, :d]).abs().max()) for b, d in enumerate(durs)))
+    print(f"fp16m2 rows (F5HIP_MX2=1) {name}: generated-mel max-abs {worst:.2e}")
+    assert worst < tol
+    assert not torch.equal(outs[("0", 0)], outs[("1", 0)])
+
+
 @pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL)])
 def test_key_padding_mask_ragged_batch(prec, tol):
     """attn_mask_enabled=True (reference modules.py:513-516): keys beyond each utterance's duration are masked —

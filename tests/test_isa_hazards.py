@@ -224,8 +224,12 @@ def test_no_register_of_an_inflight_lds_read_is_reused_before_its_wait(code_obje
                         continue
                     # any mention of a register whose LDS read is still in flight: written (the read's late write-back lands in the new value)
                     # or read (the data is not there yet) — operands like v[10:13], v7, a[0:15]; modifiers / immediates do not parse
-                    for tok in ops:
+                    for pos, tok in enumerate(ops):
                         r = _regs(tok.split(" ")[0])
+                        if r and op == "v_cvt_scalef32_pk32_fp6_f16" and pos == 1 and len(r[1]) == 16:
+                            # fp16m2 (common.h mx2_coarse): the lane has 16 halves for a 32-half conversion; source dwords 8-15 are left
+                            # undefined on purpose and their six result codes are dropped — whatever those registers hold, in flight or not
+                            r = (r[0], set(sorted(r[1])[:8]))
                         if r and any(kind == r[0] and set(regs) & r[1] for kind, regs in pending):
                             bad.append((name[:90], ins))
                             break

@@ -73,6 +73,31 @@ def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
     G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
 
 
+@pytest.mark.parametrize("name", ["tiny_v1_ragged_b2", "tiny_inner512"])
+def test_fp16m2_rows_opt_in_on_the_shim(shim_engines, monkeypatch, name):
+    """F5HIP_MX2=1 (read per finalize): fp16m with 96-byte operand rows — the LayerNorm / flash / GELU producers in that form, the
+    conversions in the k-loop (csrc/common.h mx2_*, gemm_pp.h NSPLIT 4).  Off by default (slower on the GPU: DESIGN.md section 4); here
+    it has to match the same goldens, and differ in the last bits from the 128-byte lines — i.e. it did run."""
+    from f5_tts_amd import config, synth
+    from f5_tts_amd import engine as E
+
+    c = G.MG.CASES[name]
+    cfg, wav, text, duration, lens = G.MG.case_inputs(c)
+    outs = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("F5HIP_MX2", env)
+        eng = E.F5HipEngine(config.PRESETS[c["preset"]], None, device=0)
+        eng.load_state_dict(synth.synth_dit_state_dict(config.PRESETS[c["preset"]], seed=c["wseed"]))
+        out, _ = E.F5HipCFM(eng, precision="fp16m").sample(wav, text, duration, lens=lens, **c["kw"])
+        outs.append(out.clone())
+        eng.close()
+    g = torch.as_tensor(G.gold(name)["out"])
+    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * g.shape[0]
+    for b, d in enumerate(durs):
+        assert float((outs[1][b, :d] - g[b, :d]).abs().max()) < G.MXTOL
+    assert not torch.equal(outs[0], outs[1])
+
+
 def test_mel_front_ends_on_the_shim(shim_engines):
     G.test_mel_matches_reference_golden(shim_engines)
 

@@ -45,6 +45,16 @@ static unsigned get6(const unsigned* w, int e) {  // contiguous little-endian 6-
   return (unsigned)(two >> (bit & 31)) & 63u;
 }
 
+// ---- E (round 4, second half): v_cvt_scalef32_pk32_fp6_f16 — 32 halves -> 32 e2m3 codes; is element i the code of source i? ---------------
+typedef _Float16 v32h __attribute__((ext_vector_type(32)));
+__global__ void cvt32_kernel(const float* in, float scale, unsigned* out) {
+  v32h a;
+  for (int i = 0; i < 32; ++i) a[i] = (_Float16)in[i];
+  const v6u r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(a, scale);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 6; ++i) out[i] = r[i];
+}
+
 // ---- B ------------------------------------------------------------------------------------------------------------------------------
 __global__ void mfma_kernel(const unsigned* A, const unsigned* B, const int* sa, const int* sb, float* D) {
   const int l = threadIdx.x;
@@ -183,6 +193,26 @@ int main() {
       printf("\n");
     }
   }
+  // ---- E
+  {
+    float h[32];
+    for (int i = 0; i < 32; ++i) h[i] = (i & 1 ? -1.f : 1.f) * 0.25f * (i % 30);  // 0 .. 7.25 in quarter steps, alternating sign
+    float* din;
+    unsigned* dout;
+    CHECK(hipMalloc(&din, sizeof(h)));
+    CHECK(hipMalloc(&dout, 32));
+    CHECK(hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice));
+    for (float sc : {1.0f, 4.0f}) {
+      hipLaunchKernelGGL(cvt32_kernel, dim3(1), dim3(64), 0, 0, din, sc, dout);
+      unsigned w[8] = {0};
+      CHECK(hipMemcpy(w, dout, 24, hipMemcpyDeviceToHost));
+      printf("cvt_pk32_f16 scale %.2f raw %08x %08x %08x %08x %08x %08x\n  decoded:", sc, w[0], w[1], w[2], w[3], w[4], w[5]);
+      for (int e = 0; e < 32; ++e) printf(" %g", fp6_val(get6(w, e)));
+      printf("\n  inputs :");
+      for (int e = 0; e < 32; ++e) printf(" %g", h[e]);
+      printf("\n");
+    }
+  }
   // ---- B
   {
     std::vector<unsigned> A(64 * 8, 0), B(64 * 8, 0);
@@ -233,6 +263,7 @@ int main() {
       for (int a = 0; a < 64; ++a) { printf("  src0 (%d,%2d) meets:", a >> 5, a & 31); for (int b = 0; b < 64; ++b) if (m[a * 64 + b]) printf(" (%d,%d)", b >> 5, b & 31); printf("\n"); }
   }
   // ---- C / D
+  if (getenv("MX6_PROBE_NO_PACE")) return 0;
   for (int waves : {4, 8}) {
     pace<0>("6 fp16 MFMA (x3 product, 2 k-steps, 2 tiles /2)", waves, 12);
     pace<1>("2 x (2 fp16 + 1 fp6), dependent", waves, 6);
