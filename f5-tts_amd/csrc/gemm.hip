@@ -380,12 +380,24 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
   return PP_NOT_APPLICABLE;
 }
 
+// Tile rasterisation (GemmCore::group_m = row tiles per group, row tile fastest inside a group).  An XCD takes a contiguous run of the tile
+// order (block b runs on XCD b % 8; gemm_pp.h), and what its L2 has to pull is the row panels + the weight panels its run touches:
+//  * many rounds (M >= 8192): groups of 4 row tiles (+2-5 % at M >= 22k, L2-miss traffic / 2);
+//  * the one-round launches of a single utterance with a WIDE output (q|k|v, FF1: N >= 2048): channel tiles fastest gave every XCD 2 row
+//    panels and ALL of the weights — groups of 5 make the run of 30 tiles a 5 x 6 block: 118 -> 77 MB fetched per q|k|v launch, 85 -> 64 MB
+//    per FF1 launch (FETCH_SIZE, profiles/r04l_groupm_fetch.log), 1-2 % of the launch;
+//  * narrow outputs (N = 1024: 8 channel tiles): measured the same at every group size (71-76 MB), plain order.
+// F5HIP_GEMM_GROUPM overrides (tuning knob).
+int default_group_m(const GemmCore& g) {
+  static const int gm_env = [] { const char* v = getenv("F5HIP_GEMM_GROUPM"); return v ? atoi(v) : -1; }();
+  if (gm_env >= 0) return gm_env;
+  return g.M >= 8192 ? 4 : (g.N >= 2048 ? 5 : 1);
+}
+
 template <typename Epi>
 hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int variant, hipStream_t s) {
   GemmCore g = g0;
-  static const int gm_env = [] { const char* v = getenv("F5HIP_GEMM_GROUPM"); return v ? atoi(v) : -1; }();  // tuning knob
-  // default: groups of 4 row-tiles once the grid is many waves deep (+2-5 % at M >= 22k, L2-miss traffic / 2), plain order otherwise
-  if (g.group_m == 0) g.group_m = gm_env >= 0 ? gm_env : (g.M >= 8192 ? 4 : 1);
+  if (g.group_m == 0) g.group_m = default_group_m(g);
   if constexpr (std::is_same<Epi, EpiStore>::value) {
     if (op == OP_F16M || op == OP_F16M2) {  // MX lines / rows: the pipelined kernel or nothing (the engine checks the shapes before it chooses the mode)
       const hipError_t r = (variant >= 0 && variant < 50) ? PP_NOT_APPLICABLE : op == OP_F16M ? try_pp_store<2>(g, e, batch, variant, s) : try_pp_store<4>(g, e, batch, variant, s);
@@ -424,7 +436,7 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
   if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M || op == OP_F16M2) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
       ((op == OP_F16 || op == OP_F16M2) ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
     GemmCore g = g0;
-    if (g.group_m == 0) g.group_m = g.M >= 8192 ? 4 : 1;
+    if (g.group_m == 0) g.group_m = default_group_m(g);
     const int variant = want >= 50 ? want : pick_pp_variant(g, (op == OP_F16 || op == OP_F16M2) ? 1 : 2, true, op == OP_F16M || op == OP_F16M2, false, op == OP_F16M2);
     // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
     const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;

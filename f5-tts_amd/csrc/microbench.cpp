@@ -401,7 +401,7 @@ int f5hip_bench_qkv_probe(f5hip_ctx* ctx, int variant, int expt, int abl, int ld
   if (noise && hipMemsetAsync(nbuf, 1, noise_bytes, s) != hipSuccess) return F5HIP_ERR_HIP;
   if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
   GemmCore g{};
-  g.A = ah; g.W = wh; g.lda = (int64_t)K * 2; g.ldw = (int64_t)K * 2; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N; g.group_m = 1;
+  g.A = ah; g.W = wh; g.lda = (int64_t)K * 2; g.ldw = (int64_t)K * 2; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;  // (group_m 0: the launcher's default rasterisation)
   auto epi = [&](int which) {
     EpiQKV e{};
     e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = -1; e.qscale = 0.125f; e.ldvt = ldv;
