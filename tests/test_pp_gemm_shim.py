@@ -170,3 +170,20 @@ def test_pp_mx2_rows_product_close_to_the_three_term_product(emu_engine, capfd, 
     assert m, err
     d, mean, v = (float(x) for x in m.groups())
     assert v > 0 and 0 < d <= 1e-4 * v and mean <= 1e-5 * v, err
+
+
+def test_tile_grouping_covers_every_tile_with_a_ragged_last_group():
+    """GemmCore::group_m (row tiles per group, row tile fastest inside a group: gemm.hip default_group_m picks 5 for the wide one-round
+    launches since round 4, 4 from 8192 rows) is read from F5HIP_GEMM_GROUPM once per process, so a child process runs a few of the
+    byte-for-byte cases above under group sizes that do NOT divide the row-tile count (M = 250 / 300 rows: 3 row tiles of 96, 2 of 192 or
+    256): every tile must still be computed exactly once — a tile skipped or done twice by the index arithmetic of gemm_pp.h / gemm.h
+    shows as differing bytes against the generic kernel, which these runs group the same way but walk with its own 128x64 tiles."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gm in ("2", "5"):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_pp_gemm_shim.py"), "-k",
+                            "(test_pp_variant_equals_generic_kernel_fp16x3 and (59-130 or 55-250 or 50-300)) or (test_pp_mx_lines_product and 59)"],
+                           capture_output=True, text=True, env=dict(os.environ, F5HIP_GEMM_GROUPM=gm), cwd=root, timeout=1800)
+        assert r.returncode == 0 and " passed" in r.stdout and "no tests ran" not in r.stdout, (gm, r.stdout[-1500:], r.stderr[-500:])
