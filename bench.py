@@ -180,7 +180,7 @@ def other_configs(a):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out.append({"baseline_config": name, "workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
                         "rtf": d["rtf"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
-                        "roofline": {k: d.get("roofline", {}).get(k) for k in ("achieved", "peak", "frac", "avg_launch_us")},
+                        "roofline": {k: d.get("roofline", {}).get(k) for k in ("achieved", "peak", "frac", "avg_launch_us", "traffic", "traffic_source")},
                         "kernel_classes_ms": d.get("kernel_classes_ms"), "notes": d["config"].get("notes")})
         except Exception as e:  # the headline line must not depend on these
             out.append({"baseline_config": name, "error": repr(e)[:300]})
