@@ -38,6 +38,24 @@ struct FlashArgs {
   int pp_prio;  // flash_pp_kernel: raise the wave priority during the softmax phase (A/B switch F5HIP_ATTN_PP_PRIO, default on)
 };
 
+// Scores of keys that do not exist (>= kv_end) or lie in the masked hole [hole_lo, hole_hi) -> -inf, for the tile of keys t KT .. t KT + 63:
+// register r of block kb of a lane (row, hi) is key t KT + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi.  Branch-free — one compare and one select per
+// score against the lane's own limits; the `if (...) s = -inf` form compiled to an exec-mask save / restore per element (~430 instructions
+// for the one tail tile of a launch with n % 64 != 0).
+__device__ __forceinline__ void flash_mask_tile(f32x16 (&s)[2], int t, int hi, int kv_end, int hole_lo, int hole_hi) {
+  const int base = t * KT + 4 * hi, lim = kv_end - base, hlo = hole_lo - base, hhi = hole_hi - base;
+  const bool hole = hole_hi > hole_lo;  // wave-uniform
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = kb * 32 + (r & 3) + 8 * (r >> 2);
+      bool dead = off >= lim;
+      if (hole) dead = dead | ((off >= hlo) & (off < hhi));
+      s[kb][r] = dead ? -INFINITY : s[kb][r];
+    }
+}
+
 // The operand row of the out-projection from a lane's share of a normalised output row: lane (row, hi) owns O[32 db + 8 c + 4 hi + e] =
 // o[db][4 c + e].  o_packed 0: plain fp16 rows, 1: packed hi | lo lines (fp16x3), 2: MX lines (fp16m, common.h) — the lane's 16 features of
 // a 32-block are exactly the k-set of P_hi, so the pack needs no lane exchange.
@@ -262,13 +280,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     // ---- online softmax (fp32), lane-local per query row ----------------------------------------------
     if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {  // tail tile (keys >= kv_end do not exist / are
                                                                                       // masked) or a tile touching the masked hole
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) s[kb][r] = -INFINITY;
-        }
+      flash_mask_tile(s, t, hi, kv_end, hole_lo, hole_hi);
     }
     float mx = s[0][0];
 #pragma unroll
@@ -544,13 +556,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
       fa::read_b128<(i >> 2) * 32 * K_ROWB + (i & 3) * 32>(fk[i], aK);
     });
     if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) cur[kb][r] = -INFINITY;
-        }
+      flash_mask_tile(cur, t, hi, kv_end, hole_lo, hole_hi);
     }
     float mx = cur[0][0];
     if constexpr (ABL != 6 && ABL != 7) {
@@ -587,8 +593,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float p = (ABL == 1 || ABL == 7) ? cur[i >> 2][4 * (i & 3) + e] : __builtin_amdgcn_exp2f(cur[i >> 2][4 * (i & 3) + e]);
-        if constexpr (VSUM) rs += p;
         fp[i >> 1].h[4 * (i & 1) + e] = (f16)p;
+      }
+      if constexpr (VSUM) {  // row sum over the rounded values the P.V product multiplies: one v_dot2_f32_f16 per packed pair
+        rs = f5_sum2_f16((i & 1) ? fp[i >> 1].u.z : fp[i >> 1].u.x, rs);
+        rs = f5_sum2_f16((i & 1) ? fp[i >> 1].u.w : fp[i >> 1].u.y, rs);
       }
     }
     // O^T += V^T . P^T (+ the row sums on the matrix pipe unless VSUM)
@@ -744,13 +753,7 @@ __global__ __launch_bounds__(512, 1) void flash_pp_kernel(FlashArgs a) {
       return;
     }
     if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= kv_end || (key >= hole_lo && key < hole_hi)) sc[kb][r] = -INFINITY;
-        }
+      flash_mask_tile(sc, t, hi, kv_end, hole_lo, hole_hi);
     }
     float mx = sc[0][0];
 #pragma unroll

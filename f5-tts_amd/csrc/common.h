@@ -41,6 +41,22 @@ union Frag {
   f32x4 f;
 };
 
+// acc + lo + hi of a packed pair of halves in ONE instruction (v_dot2_f32_f16 against (1, 1), fp32 accumulate): the row sums of the flash
+// kernels' P, taken over the values the P.V product multiplies (the fp16-rounded ones) at half the adds
+__device__ __forceinline__ float f5_sum2_f16(uint32_t pair, float acc) {
+#ifdef F5_HIPEMU
+  union { uint32_t u; f16 h[2]; } v;
+  v.u = pair;
+  return acc + ((float)v.h[0] + (float)v.h[1]);
+#else
+  typedef _Float16 f5_half2 __attribute__((ext_vector_type(2)));
+  union { uint32_t u; f5_half2 v; } a;
+  a.u = pair;
+  const f5_half2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+  return __builtin_amdgcn_fdot2(a.v, ones, acc, false);
+#endif
+}
+
 template <typename T>
 struct Mma32;
 template <>

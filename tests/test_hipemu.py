@@ -395,205 +395,9 @@ def engine_emu_lib():
     import f5_tts_amd  # noqa: F401
     from f5_tts_amd import binding
 
-    import hipemu_build
+    import hipemu_build  # tests/hipemu_build.py: conftest.py starts the stale translation units in the background at collection; this waits and links
 
     path = hipemu_build.ensure()
-    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
-    for name, (res, args) in binding.SYMBOLS.items():
-        if name.startswith("f5hip_bigvgan_"):
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-    return lib
-
-
-class EmuBigVGAN:
-    """The C ABI driven directly with host pointers (the emulated library's "device" memory is host memory)."""
-
-    def __init__(self, lib, cfg, sd):
-        import ctypes as C
-
-        from f5_tts_amd.bigvgan import _config_c
-
-        self.lib, self.cfg, self.C = lib, cfg, C
-        self.ctx = C.c_void_p()
-        c = _config_c(cfg)
-        assert lib.f5hip_bigvgan_create(C.byref(c), 0, C.byref(self.ctx)) == 0, lib.f5hip_bigvgan_last_error(None)
-        name, numel = C.c_char_p(), C.c_int64()
-        for i in range(lib.f5hip_bigvgan_num_tensors(self.ctx)):
-            assert lib.f5hip_bigvgan_tensor_info(self.ctx, i, C.byref(name), C.byref(numel)) == 0
-            t = sd[name.value.decode()].detach().float().contiguous()
-            assert t.numel() == numel.value, name.value
-            assert lib.f5hip_bigvgan_load_tensor(self.ctx, name.value, C.c_void_p(t.data_ptr()), t.numel()) == 0
-        assert lib.f5hip_bigvgan_finalize(self.ctx) == 0, lib.f5hip_bigvgan_last_error(self.ctx)
-
-    def option(self, key, value):
-        assert self.lib.f5hip_bigvgan_set_option(self.ctx, key.encode(), value) == 0, self.lib.f5hip_bigvgan_last_error(self.ctx)
-
-    def forward(self, mel, precision=0, channel_major=True, out_shape=None):
-        C = self.C
-        b, t = mel.shape[0], (mel.shape[2] if channel_major else mel.shape[1])
-        mel = mel.contiguous().float()
-        out = torch.full(out_shape or (b, t * self.cfg.hop), float("nan"))
-        st = self.lib.f5hip_bigvgan_forward(self.ctx, C.c_void_p(mel.data_ptr()), b, t, int(channel_major), precision, C.c_void_p(out.data_ptr()), None)
-        assert st == 0, self.lib.f5hip_bigvgan_last_error(self.ctx)
-        return out
-
-    def close(self):
-        self.lib.f5hip_bigvgan_destroy(self.ctx)
-
-
-@pytest.mark.parametrize("name", ["BIGVGAN_TINY", "BIGVGAN_TINY2"])
-def test_whole_generator_through_the_product_orchestration_code(emu_lib, name):
-    """bigvgan_api.cpp end to end on the CPU: weight matrices, buffer ping-pong, strides, every launch — stage by stage against the
-    oracle, in fp32, then the waveform in the two fp16 operand modes, all three conv implementations, both input layouts."""
-    from f5_tts_amd import config, synth
-    from oracle import bigvgan_oracle as BO
-
-    cfg = getattr(config, name)
-    sd = synth.synth_bigvgan_state_dict(cfg, seed=2)
-    voc = EmuBigVGAN(emu_lib, cfg, sd)
-    T = 7
-    mel = torch.randn(2, cfg.num_mels, T, generator=torch.Generator().manual_seed(11))
-    want, stages = BO.bigvgan_forward(sd, cfg, mel, return_stages=True)
-    for k, ref in enumerate(stages):
-        voc.option("stop_after_stage", k)
-        got = voc.forward(mel, out_shape=(2, ref.shape[2], ref.shape[1])).transpose(1, 2)
-        assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), f"stage {k}"
-    voc.option("stop_after_stage", -1)
-    voc.option("conv_impl", 0)  # the launch counts below are those of the materialised-operand path (the library default is 2)
-    voc.option("profile", 1)
-    base = voc.forward(mel)
-    voc.option("profile", 0)
-    import ctypes as C
-
-    name, calls, ms, fl, by = C.c_char_p(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-    stats = {}
-    for i in range(emu_lib.f5hip_bigvgan_num_kernel_stats(voc.ctx)):
-        assert emu_lib.f5hip_bigvgan_kernel_stat(voc.ctx, i, C.byref(name), C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by)) == 0
-        stats[name.value.decode()] = (calls.value, fl.value, by.value)
-    nconv = 1 + len(cfg.upsample_rates) + sum((2 if cfg.resblock == "1" else 1) * len(d) for d in cfg.resblock_dilation_sizes) * len(cfg.upsample_rates)
-    assert stats["conv_gemm"][0] == nconv == stats["operand"][0] and stats["conv_gemm"][1] > 0  # one GEMM + one operand emission per conv
-    assert stats["activation1d"][0] == nconv - 1 - len(cfg.upsample_rates) + 1 and stats["other"][0] == len(cfg.upsample_rates) + 1
-    assert (base - want[:, 0]).abs().max().item() < 3e-5
-    assert (voc.forward(mel.transpose(1, 2).contiguous(), channel_major=False) - base).abs().max().item() == 0.0
-    for impl in (1, 2):
-        voc.option("conv_impl", impl)
-        assert (voc.forward(mel) - base).abs().max().item() < 1e-5, impl
-    for prec, tol in ((1, 2e-4), (2, 3e-2)):  # F5HIP_PREC_FP16X3, F5HIP_PREC_FP16
-        for impl in (0, 1, 2):
-            voc.option("conv_impl", impl)
-            assert (voc.forward(mel, precision=prec) - want[:, 0]).abs().max().item() < tol, (prec, impl)
-    voc.close()
-
-
-def test_emulated_library_rejects_what_the_real_one_rejects(emu_lib):
-    import ctypes as C
-
-    from f5_tts_amd import config, synth
-    from f5_tts_amd.bigvgan import _config_c
-
-    cfg = config.BIGVGAN_TINY
-    ctx = C.c_void_p()
-    assert emu_lib.f5hip_bigvgan_create(C.byref(_config_c(cfg)), 0, C.byref(ctx)) == 0
-    assert emu_lib.f5hip_bigvgan_finalize(ctx) == 3 and b"never loaded" in emu_lib.f5hip_bigvgan_last_error(ctx)  # F5HIP_ERR_STATE
-    x = torch.zeros(4)
-    assert emu_lib.f5hip_bigvgan_load_tensor(ctx, b"conv_pre.bias", C.c_void_p(x.data_ptr()), 4) == 1  # wrong size
-    assert emu_lib.f5hip_bigvgan_load_tensor(ctx, b"nope", C.c_void_p(x.data_ptr()), 4) == 1
-    assert emu_lib.f5hip_bigvgan_forward(ctx, C.c_void_p(x.data_ptr()), 1, 1, 1, 0, C.c_void_p(x.data_ptr()), None) == 3  # not finalised
-    assert emu_lib.f5hip_bigvgan_set_option(ctx, b"conv_impl", 7) == 1
-    emu_lib.f5hip_bigvgan_destroy(ctx)
-
-
-# ---- flash attention (csrc/attention_kernel.h): the GPU-proven kernel through the shim, then its key-split variant ---------------------
-def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None, log2q=False):
-    bh = Bp * heads
-    q = (rng.standard_normal((bh, n, 64)) * 0.5 / 8.0).astype(np.float32)  # pre-scaled by 1/sqrt(64), as the QKV epilogue leaves it
-    if log2q:
-        q *= np.float32(np.log2(np.e))  # ... and by log2(e): the kernel's scores are base-2 logarithms
-    k = (rng.standard_normal((bh, n, 64)) * 1.5).astype(np.float32)
-    v = rng.standard_normal((bh, n, 64)).astype(np.float32)
-    ldv = (n + 7) & ~7
-    vt = np.zeros((bh, 64, ldv), dtype=np.float32)
-    vt[:, :, :n] = v.transpose(0, 2, 1)
-    hi = lambda x: x.astype(np.float16)  # noqa: E731
-    lo = lambda x: (x - x.astype(np.float16).astype(np.float32)).astype(np.float16)  # noqa: E731
-    files = dict(q=hi(q), k=hi(k), vt=hi(vt))
-    if nsplit >= 2:
-        files.update(q_lo=lo(q), k_lo=lo(k))
-    if nsplit == 3:
-        files.update(vt_lo=lo(vt))
-    if kvlen is not None:
-        files["kvlen"] = np.asarray(kvlen, dtype=np.int32)
-    val = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit >= 2 else (lambda x: hi(x).astype(np.float64))
-    vval = (lambda x: hi(x).astype(np.float64) + lo(x).astype(np.float64)) if nsplit == 3 else (lambda x: hi(x).astype(np.float64))
-    s = val(q) @ val(k).transpose(0, 2, 1) * (np.log(2.0) if log2q else 1.0)
-    if kvlen is not None:
-        for b in range(Bp):
-            s[b * heads:(b + 1) * heads, :, kvlen[b]:] = -np.inf
-    p = np.exp(s - s.max(-1, keepdims=True))
-    want = (p / p.sum(-1, keepdims=True)) @ vval(v)  # [bh, n, 64]
-    want = want.reshape(Bp, heads, n, 64).transpose(0, 2, 1, 3).reshape(Bp, n, heads * 64)
-    return files, want
-
-
-@pytest.mark.parametrize("nsplit,kvs,n,kvlen", [(2, 1, 200, None), (1, 1, 70, None), (3, 1, 130, [130, 77]),
-                                                (2, 2, 200, None), (2, 3, 333, None), (1, 4, 70, None), (3, 2, 130, [130, 77]), (2, 8, 64, None)])
-def test_flash_attention_kernel_and_its_key_split_variant(exe, tmp_path, nsplit, kvs, n, kvlen):
-    """kvs == 1: the kernel the DiT parity suite has proven on the GPU, run through the shim (validates the shim on __shfl_xor, V^T
-    tiles, online softmax).  kvs > 1: the key-split variant + merge kernel written without a GPU, against the same softmax."""
-    rng = np.random.default_rng(n + kvs)
-    Bp, heads = 2, 2
-    files, want = _attn_case(rng, Bp, heads, n, nsplit, kvlen)
-    run(exe, tmp_path, "attn", nsplit, Bp, heads, n, kvs, 1, int(kvlen is not None), **files)
-    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
-    tol = 3e-3 if nsplit < 3 else 2e-5  # P (and V) rounded to fp16 in the PV product unless everything is split
-    assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
-
-
-@pytest.mark.parametrize("pipe,n,kvlen", [(4, 200, None), (14, 70, None), (6, 450, [450, 301]), (16, 130, [130, 77]), (4, 64, None), (4, 333, [1, 333]),
-                                          (8, 200, None), (8, 600, [600, 301]), (8, 64, None), (8, 333, [1, 333]), (8, 257, [129, 257])])
-def test_software_pipelined_flash_attention(exe, tmp_path, pipe, n, kvlen):
-    """flash_pipe_kernel (scores of tile t + 1 issued inside the softmax of tile t; skewed K / V^T ring): 4- and 6-wave blocks, row sums on
-    either pipe, one tile, odd and even tile counts, masked tails down to a single valid key.  pipe 8: flash_pp_kernel (8 waves, the two
-    halves one phase apart on a shared K / V^T ring)."""
-    rng = np.random.default_rng(n + pipe)
-    Bp, heads = 2, 2
-    files, want = _attn_case(rng, Bp, heads, n, 1, kvlen, log2q=True)
-    run(exe, tmp_path, "attn", 1, Bp, heads, n, 1, 1, int(kvlen is not None), pipe, **files)
-    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
-    assert np.abs(got - want).max() < 3e-3 * max(1.0, np.abs(want).max())
-
-
-# ---- the DiT engine itself (api.cpp + every kernel translation unit) on the CPU: the product's own host classes over the shim ------------
-@pytest.fixture(scope="module")
-def engine_emu_lib():
-    import ctypes as C
-
-    import f5_tts_amd  # noqa: F401
-    from f5_tts_amd import binding
-
-    out_dir = os.path.join(ROOT, "tests", "c_abi", "_build", "engine_emu")
-    os.makedirs(out_dir, exist_ok=True)
-    csrc, emu = os.path.join(ROOT, "f5-tts_amd", "csrc"), os.path.join(ROOT, "tests", "hipemu")
-    deps = [os.path.join(emu, "hipemu.h"), os.path.join(ROOT, "include", "f5hip.h")] + [os.path.join(csrc, h) for h in os.listdir(csrc) if h.endswith(".h")]
-    objs, stale = [], []
-    for src in ("gemm.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp", "microbench.cpp"):
-        obj = os.path.join(out_dir, src + ".o")
-        objs.append(obj)
-        sp = os.path.join(csrc, src)
-        if not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in deps + [sp]):
-            stale.append([CLANG, "-x", "c++", "-std=c++20", "-O1", "-pthread", "-fPIC", "-DF5_HIPEMU", "-I", emu, "-I", csrc, "-Wno-unknown-pragmas",
-                          "-Wno-pass-failed", "-Wno-psabi", "-c", sp, "-o", obj])
-    if stale:  # the translation units side by side (gemm.hip alone is two thirds of the serial time)
-        from concurrent.futures import ThreadPoolExecutor
-
-        with ThreadPoolExecutor(max_workers=len(stale)) as pool:
-            for r in pool.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), stale):
-                assert r.returncode == 0, r.stderr[-3000:]
-    path = os.path.join(out_dir, "libf5hip_engine_emu.so")
-    if not os.path.exists(path) or any(os.path.getmtime(o) > os.path.getmtime(path) for o in objs):
-        r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", path] + objs, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-3000:]
     lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, (res, args) in {**binding.SYMBOLS, **binding.BENCH_SYMBOLS}.items():  # (one library here: engine + microbench.cpp)
         if hasattr(lib, name):  # the BigVGAN / fault-reproducer entry points are not part of this build
