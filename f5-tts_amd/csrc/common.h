@@ -331,13 +331,42 @@ __device__ __forceinline__ bool f5_wave_any(bool pred) {
 #endif
 }
 
+// Wave-wide reductions, the result in every lane.  On the GPU: data-parallel-primitive moves inside the VALU (quad swaps, the two mirrors of a
+// 16-lane row, then the row totals handed down the rows with row_bcast 15 / 31 and read from lane 63) instead of six `ds_bpermute` round
+// trips through the LDS pipe (what __shfl_xor compiles to): the reductions sit on the critical path of the latency-bound LayerNorm launches.
+#ifndef F5_HIPEMU
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float f5_dpp(float v, float identity) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef F5_HIPEMU
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#else
+  v += f5_dpp<0xB1>(v, 0.f);        // quad_perm [1, 0, 3, 2]
+  v += f5_dpp<0x4E>(v, 0.f);        // quad_perm [2, 3, 0, 1]: every lane holds its quad's sum
+  v += f5_dpp<0x141>(v, 0.f);       // row_half_mirror: 8 lanes
+  v += f5_dpp<0x140>(v, 0.f);       // row_mirror: the 16-lane row
+  v += f5_dpp<0x142, 0xa>(v, 0.f);  // row_bcast 15 into rows 1 and 3: rows 0 + 1, rows 2 + 3
+  v += f5_dpp<0x143, 0xc>(v, 0.f);  // row_bcast 31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#ifdef F5_HIPEMU
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+#else
+  v = fmaxf(v, f5_dpp<0xB1>(v, v));
+  v = fmaxf(v, f5_dpp<0x4E>(v, v));
+  v = fmaxf(v, f5_dpp<0x141>(v, v));
+  v = fmaxf(v, f5_dpp<0x140>(v, v));
+  v = fmaxf(v, f5_dpp<0x142, 0xa>(v, v));  // (rows outside the mask keep their own value: max(v, v))
+  v = fmaxf(v, f5_dpp<0x143, 0xc>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
