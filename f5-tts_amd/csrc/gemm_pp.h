@@ -72,7 +72,8 @@ __device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
   a = r[0];
   b = r[1];
 }
-__device__ __forceinline__ uint32_t xchg1(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }  // neighbour lane (a DPP quad_perm move)
+// neighbour lane (lane ^ 1) as ONE DPP move, quad_perm [1, 0, 3, 2] (__shfl_xor(v, 1) compiled to a ds_bpermute round trip: 72 of them in the q|k|v kernel)
+__device__ __forceinline__ uint32_t xchg1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); }
 __device__ __forceinline__ void store_b128(BufRsrc r, uint32_t off, uint4 v) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 d = {v.x, v.y, v.z, v.w};

@@ -45,7 +45,10 @@ def ensure():
         proc, obj = _running.pop()
         _, err = proc.communicate()
         assert proc.returncode == 0, err[-3000:]
-        os.replace(obj + ".part", obj)  # an interrupted compile never leaves a fresh-looking object behind
+        if os.path.exists(obj + ".part"):
+            os.replace(obj + ".part", obj)  # an interrupted compile never leaves a fresh-looking object behind
+        else:  # another process building the same tree got there first (both compiled the same sources)
+            assert os.path.exists(obj), obj
     objs = _objects()
     if not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         r = subprocess.run([CLANG, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-Wl,--no-undefined", "-o", LIB] + objs, capture_output=True, text=True)
