@@ -8,6 +8,12 @@
 #include "kernels.h"
 #include "gemm_pp.h"
 
+// gemm_p8.hip: the ping-pong 256x256 kernel of the many-round launches (variant id 80; gemm_p8.h)
+template <int NSPLIT, typename Epi>
+hipError_t launch_p8(const GemmCore& g, const Epi& e, int abl, hipStream_t s);
+bool p8_applies(int nsplit, const GemmCore& g);
+hipError_t init_p8_kernels();
+
 namespace {
 
 // One tile variant: TM x TN 32x32 tiles per wave, WGM x WGN waves.
@@ -235,6 +241,10 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
 #define F5_MX2_TILES(X) X(55) X(56) X(59)  // (the 8-wave 256x256 tile does not fit fp16m2's conversion temporaries into 256 registers: rows >= 4096 stay on fp16m lines)
 template <int NSPLIT, typename Epi>
 hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s) {
+  if (variant == 80) {  // the ping-pong kernel (gemm_p8.h): plain fp16 rows and MX lines
+    if constexpr (NSPLIT == 1 || NSPLIT == 2) return launch_p8<NSPLIT, Epi>(g, e, 0, s);
+    else return PP_NOT_APPLICABLE;
+  }
   if constexpr (NSPLIT == 4) {
     switch (variant) {
 #define F5_CASE(ID) case ID: return launch_pp_one<4, ID, Epi>(g, e, s);
@@ -368,6 +378,9 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
           default: return PP_NOT_APPLICABLE;
         }
       }
+    }
+    if constexpr (NSPLIT == 1 || NSPLIT == 2) {  // ablations of the ping-pong kernel: 1000 * code + 80 (code 1 no epilogue, 4 no LDS-DMA, 8 no MFMAs, 9 neither epilogue nor MFMAs)
+      if (variant >= 1000 && variant % 1000 == 80 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant / 1000, s);
     }
     if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
     return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
@@ -532,6 +545,7 @@ hipError_t init_gemm_kernels() {
 #ifndef F5_HIPEMU
   if ((e = set_glds_attrs<EpiStore>()) != hipSuccess || (e = set_glds_attrs<EpiQKV>()) != hipSuccess || (e = set_glds_attrs<EpiQKVFast>()) != hipSuccess) return e;
 #endif
+  if ((e = init_p8_kernels()) != hipSuccess) return e;
   e = set_pp_attrs<1>();
   if (e != hipSuccess) return e;
   e = set_pp_attrs<2>();

@@ -63,6 +63,42 @@ def test_pp_variant_equals_generic_kernel_fp16(emu_engine, capfd, variant, M, N,
         assert bad == 0 and v > 0, (bad, nb, d, v)
 
 
+# ---- the ping-pong kernel of the many-round launches (csrc/gemm_p8.h, variant id 80) ---------------------------------------------------------
+# Two groups of four waves half a phase apart, the LDS refilled by quarters two phases behind the reads: on the shim (LDS-DMA synchronous,
+# fibers switched at barriers) a quarter refilled a phase too early, a fragment read from the wrong buffer or a quadrant paired with the
+# wrong weight tile all show as differing bytes.  K = 256 .. 640: two pairs of k-tiles (one steady body + the last-pair body), three, and five pairs.
+@pytest.mark.parametrize("M,N,K", [(300, 288, 256), (300, 288, 384), (520, 544, 640)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_p8_equals_generic_kernel_fp16(emu_engine, capfd, M, N, K, epi):  # noqa: F811
+    for bad, nb, d, v in run(emu_engine, capfd, "fp16", 80, epi, M, N, K):
+        assert bad == 0 and v > 0, (bad, nb, d, v)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 288, 128), (300, 288, 192), (520, 544, 320)])
+def test_p8_mx_lines_product_close_to_the_three_term_product(emu_engine, capfd, M, N, K):  # noqa: F811
+    err = run_mx(emu_engine, capfd, 80, 2, M, N, K)
+    m = re.search(r"KB_CHECK fp16m variant \d+: max \|diff\| (\S+) mean (\S+) of max \|value\| (\S+)", err)
+    assert m, err
+    d, mean, v = (float(x) for x in m.groups())
+    assert v > 0 and 0 < d <= 1e-4 * v and mean <= 1e-5 * v, err
+
+
+@pytest.mark.parametrize("epi", [0, 1])
+def test_p8_mx_output_rows_decode_to_the_fp16x3_rows(emu_engine, capfd, epi):  # noqa: F811
+    M, N = 300, 288
+    err = run_mx(emu_engine, capfd, 80, epi, M, N, 256)
+    m = re.search(r"KB_CHECK fp16m variant \d+ epi \d: (\d+) lines, (\d+) hi halves differ .* errors (\S+) / (\S+) block steps, (\d+) out of bounds", err)
+    assert m, err
+    lines, hidiff, ec, el, bad = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5))
+    assert lines == M * N // 32 and bad == 0 and hidiff <= lines * 32 // 8 and 0 < ec <= 0.51 and 0 < el <= 1.5, err
+
+
+@pytest.mark.parametrize("prec,K", [("fp16", 256), ("fp16m", 128)])
+def test_p8_qkv_epilogue(emu_engine, capfd, prec, K):  # noqa: F811
+    diff, err = run_qkv(emu_engine, capfd, prec, 80, 3, 150, K=K)
+    assert diff == 0, err[-2000:]
+
+
 # ---- fp16m: 2 fp16 MFMAs + 1 MX-fp6 MFMA per 32 k (common.h) ---------------------------------------------------------------------------
 # The correction terms are rounded to ~4 bits per factor, so the results are close to — not bytes of — the three-term product: the bound
 # is the scheme's own error (2^-16 per operand relative to the block maximum, summed over K), the check that it is non-zero shows the MX

@@ -66,6 +66,46 @@ pmc() {  # counter passes (separate runs: counters only, never with tracing) + a
 }
 
 case $recipe in
+p8)
+  # round 5: the ping-pong 256x256 kernel (csrc/gemm_p8.h, tile id 80) against the lockstep 256x256 tile (50) and the heuristic's choice:
+  # value checks on the GPU, times on the many-round shapes with ablations, hipBLASLt yardstick, counters, B = 32 / B = 8 step A/B
+  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
+  { for epi in 0 1 2; do KB_CHECK=1 KB_SHAPES="5000,2048,1024;3000,1024,2048" KB_PRECS=fp16 KB_EPI=$epi KB_VARIANTS=80 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | head -8; done
+    for epi in 1 2; do KB_CHECK=1 KB_SHAPES="5000,2048,1024;3000,1024,2048" KB_PRECS=fp16m KB_EPI=$epi KB_VARIANTS=80 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | head -8; done
+    for prec in fp16 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec 8 1406 80 5 2>&1 | grep -E "^qkv|QKV_CHECK" | tail -2; done; } > $out/check.log 2>&1
+  cat $out/check.log | cut -c1-250
+  BIG="11248,2048,1024;22496,2048,1024;44992,2048,1024;89984,2048,1024;89984,1024,2048;89984,3072,1024;89984,1024,1024"
+  { for prec in fp16 fp16m; do
+      KB_SHAPES=$BIG KB_PRECS=$prec KB_EPI=1 KB_VARIANTS=-1,50,80,1080,4080,8080,9080 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi1 /" | cut -c1-400
+      KB_SHAPES=$BIG KB_PRECS=$prec KB_EPI=2 KB_VARIANTS=-1,50,80 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi2 /" | cut -c1-400
+    done
+    for sq in "8 1406" "32 1406" "64 1406"; do for prec in fp16 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec $sq -1,50,80 10 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done; done; } > $out/kernel_bench.log 2>&1
+  cat $out/kernel_bench.log | cut -c1-330
+  [ -x tools/probes/hipblaslt_ref ] && timeout 300 tools/probes/hipblaslt_ref > $out/hipblaslt_ref.log 2>&1; tail -4 $out/hipblaslt_ref.log
+  ( cd /tmp; export TMPDIR=/tmp
+    for v in 50 80; do for prec in fp16 fp16m; do
+      timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $R/$out/pmc_a_${prec}_$v -o c -- python $R/tools/kernel_bench.py one $prec $v 89984 2048 1024 3 > /dev/null 2>&1
+      timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $R/$out/pmc_b_${prec}_$v -o c -- python $R/tools/kernel_bench.py one $prec $v 89984 2048 1024 3 > /dev/null 2>&1
+    done; done )
+  python - $out <<'PY'
+import csv, glob, sys, collections
+for d in sorted(glob.glob(sys.argv[1] + "/pmc_*")):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "gemm_p" in r.get("Kernel_Name", ""):
+                a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+    print(d.split("/")[-1], {k: round(v[0] / max(v[1], 1)) for k, v in acc.items()})
+PY
+  rm -rf $out/pmc_*
+  Q="--no-cpu-baseline --no-other-configs"
+  for v in -1 80 -1 80; do
+    F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/b32_v$v.json 2>> $out/bench.err; line $out/b32_v$v.json b32_nfe32_variant$v
+  done
+  for v in -1 80; do
+    F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 3 --warmup 1 --batch 8 $Q > $out/b8_v$v.json 2>> $out/bench.err; line $out/b8_v$v.json b8_variant$v
+  done
+  tail -3 $out/bench.err ;;
 mx)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
   timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs2 or configs4 or packed_rows or ping_pong" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m.log; tail -25 $out/gpu_tests_fp16m.log
