@@ -42,9 +42,9 @@ template <typename T>
 T* stage(f5hip_ctx* ctx, size_t n) { return reinterpret_cast<T*>(ctx->stage.alloc(n * sizeof(T))); }
 #define STAGE(T, var, n)                                                    \
   T* var = stage<T>(ctx, (n));                                              \
-  if (!var) FAIL(F5HIP_ERR_HIP, "pinned staging allocation of %zu bytes failed%s%s", (size_t)(n) * sizeof(T),                                   \
-                 ctx->stage.last_error != hipSuccess ? ": waiting for the staging slot's previous call: " : "",                                  \
-                 ctx->stage.last_error != hipSuccess ? hipGetErrorString(ctx->stage.last_error) : "")
+  if (!var) FAIL(F5HIP_ERR_HIP, "pinned staging allocation of %zu bytes failed%s%s%s%s", (size_t)(n) * sizeof(T),                               \
+                 ctx->stage.last_error != hipSuccess ? ": " : "", ctx->stage.last_error != hipSuccess ? ctx->stage.last_step : "",                 \
+                 ctx->stage.last_error != hipSuccess ? ": " : "", ctx->stage.last_error != hipSuccess ? hipGetErrorString(ctx->stage.last_error) : "")
 
 // Every entry point that enqueues work calls this first: device, the staging slot of this call, and — the workspace being one per context —
 // a GPU-side wait for the previous call's work when this call arrives on a different stream (no host wait in either case).
@@ -418,7 +418,7 @@ int finalize_impl(f5hip_ctx* ctx) {
   const int64_t cstream_elems = mmdit ? per_block * (c.depth - 1) + 3 * inner * D : 0;  // text stream; the last block only projects q/k/v
   // fp16m (fp16 + MX-fp6 correction lines, common.h): the four block GEMMs of the DiT / UNetT backbones when every one of them is a launch the
   // pipelined kernel takes (rows of whole 128-byte lines, at least a 3-stage ring of them) and the fused q|k|v epilogue applies
-  ctx->mx_ok = (c.backbone == 0 || c.backbone == 1) && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
+  ctx->mx_ok = ctx->mx_weights_opt && (c.backbone == 0 || c.backbone == 1) && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
   // fp16m2 rows (96 bytes per 32 k: the coarse values derived in the k-loop) for the one-round launches of a single utterance: 64-k tiles.
   // OFF by default: measured 13-20 % slower per GEMM than the 128-byte lines, tile for tile (the conversions in the k-loop cost more than the
   // bytes they save; profiles/r04h_*) — kept, like the ping-pong attention kernel, as the record of the experiment behind F5HIP_MX2=1
@@ -1762,6 +1762,9 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "attn_impl") { ctx->attn_impl = (int)value; ctx->ws_epoch++; }  // invalidates a captured graph
   else if (k == "branch_streams") { ctx->branch_streams = (int)value; ctx->ws_epoch++; }
   else if (k == "packed_rows") { ctx->packed_opt = value ? 1 : 0; ctx->ws_epoch++; }
+  else if (k == "mx_weights") {  // read by the NEXT f5hip_finalize_weights (the copies are carved from the pool it sizes)
+    ctx->mx_weights_opt = value ? 1 : 0;
+  }
   else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
     if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
     ctx->attn_kv_split = (int)value;
@@ -1841,7 +1844,9 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   const int64_t BN = (int64_t)B * n;
   // fp16m: MX lines for the block GEMMs where they are built (finalize: mx_ok) and the call is one the pipelined kernel and the flash
   // epilogue take; anything else runs the call in fp16x3 — never less accurate, so the mode needs no error path
-  ctx->mx_call = precision == F5HIP_PREC_FP16M && ctx->mx_ok && !exact_attn && ctx->attn_kv_split <= 1 &&
+  // (the fused q|k|v launch of the pipelined kernel needs >= 8 tokens per sequence; tuning knobs that force a tile without an MX
+  // instantiation or the general q|k|v index path take the launches away from it: gemm_mx_tiles_usable)
+  ctx->mx_call = precision == F5HIP_PREC_FP16M && ctx->mx_ok && !exact_attn && ctx->attn_kv_split <= 1 && n >= 8 && gemm_mx_tiles_usable() &&
                  (2 * (BN + B) + 512) * 4 * std::max<int64_t>(std::max<int64_t>(D, c.ff_inner), (int64_t)c.heads * c.dim_head) < (int64_t)0x7ff00000;
   // ... as fp16m2 rows where every block GEMM of the call is a one-round launch (the tiles instantiated for that form: < 4096 rows)
   ctx->mx2_call = ctx->mx_call && ctx->mx2_ok && 2 * (BN + B) < 4096;

@@ -73,14 +73,17 @@ struct HostStage {
     taken = false;
     return hipSuccess;
   }
-  hipError_t last_error = hipSuccess;  // why the last claim() failed (alloc() can only say "no memory": the caller formats this)
+  hipError_t last_error = hipSuccess;  // why the last alloc() returned null (the caller formats it) ...
+  const char* last_step = "";          // ... and which step that was
   hipError_t claim() {
     const int next = (cur + 1) % RING;
     SlotS& s = slot[next];
     hipError_t e = hipSuccess;
     if (s.open) e = hipDeviceSynchronize();
     else if (s.recorded) e = hipEventSynchronize(s.done);
-    if (e != hipSuccess) { last_error = e; return e; }  // the ring does not advance: the next alloc() retries this slot
+    if (e != hipSuccess) { last_error = e; last_step = "waiting for the staging slot's previous call"; return e; }  // the ring does not advance: the next alloc() retries this slot
+    last_error = hipSuccess;  // (a later hipHostMalloc failure in alloc() must not be reported with a stale claim() cause)
+    last_step = "";
     cur = next;
     s.recorded = false;
     s.open = true;
@@ -96,7 +99,7 @@ struct HostStage {
       if (c.cap - c.used >= bytes) { void* r = c.p + c.used; c.used += bytes; return r; }
     Chunk c;
     c.cap = bytes > (size_t(1) << 20) ? bytes : (size_t(1) << 20);
-    if (hipHostMalloc(reinterpret_cast<void**>(&c.p), c.cap, 0) != hipSuccess) return nullptr;
+    if (const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c.p), c.cap, 0); e != hipSuccess) { last_error = e; last_step = "hipHostMalloc"; return nullptr; }
     c.used = bytes;
     s.chunks.push_back(c);
     return c.p;
@@ -229,6 +232,7 @@ struct f5hip_ctx {
   // Row r of the packed order (sequence by sequence: cond 0 .. B-1, then uncond) is padded row rowmap[r] = token rowinfo[r] & 0xffff of
   // sequence rowinfo[r] >> 16; sequence s starts at packed row cu_rows[s].  pk_rows = 0: the padded layout is in use.
   int packed_opt = 0;
+  int mx_weights_opt = 1;  // option "mx_weights": build the MX-line copies of the block weights at finalize (2 more halves per element)
   int64_t pk_rows = 0;
   std::vector<int32_t> cu_host;
   DevBuf rowmap, rowinfo, cu_rows, xpk, velpk;

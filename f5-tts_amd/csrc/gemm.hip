@@ -381,6 +381,7 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
     }
     if constexpr (NSPLIT == 1 || NSPLIT == 2) {  // ablations of the ping-pong kernel: 1000 * code + 80 (code 1 no epilogue, 4 no LDS-DMA, 8 no MFMAs, 9 neither epilogue nor MFMAs)
       if (variant >= 1000 && variant % 1000 == 80 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant / 1000, s);
+      if (variant > 80 && variant < 90 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, 100 + (variant - 80), s);  // schedule experiments
     }
     if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
     return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
@@ -435,6 +436,23 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
 
 hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s) {
   return dispatch<EpiStore>(op, g, e, batch, -1, s);
+}
+// OP_F16M launches have no generic-kernel fallback, so the tuning knobs that take a launch away from the tiles instantiated for MX lines
+// (a forced tile id outside F5_MX_TILES / 0 = "never the pipelined kernel", the general q|k|v index path) make the mode unusable: the
+// engine asks here before it chooses MX lines for a call and runs the call in fp16x3 otherwise (f5hip_sample)
+bool gemm_mx_tiles_usable() {
+  auto mx_tile = [](int id) {
+    if (id == 80) return true;
+#define F5_IS(ID) if (id == ID) return true;
+    F5_MX_TILES(F5_IS)
+#undef F5_IS
+    return false;
+  };
+  for (const char* name : {"F5HIP_PP_VARIANT", "F5HIP_PP_VARIANT_N3072", "F5HIP_PP_VARIANT_N2048", "F5HIP_PP_VARIANT_N1024"}) {
+    const char* v = getenv(name);
+    if (v && atoi(v) >= 0 && !mx_tile(atoi(v))) return false;
+  }
+  return getenv("F5HIP_QKV_EPI_GENERIC") == nullptr;
 }
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   return dispatch<EpiStore>(op, g, e, batch, variant, s);

@@ -42,15 +42,27 @@ using IC = std::integral_constant<int, V>;
 constexpr int P8_OPB = 256 * GEMM_KTB;    // one operand's k-tile: 256 rows x 128 B = 32 KB
 constexpr int P8_LDS_BYTES = 4 * P8_OPB;  // A buf 0 | A buf 1 | W buf 0 | W buf 1
 
-// ABL (microbenchmark ablations): bit 0 = no epilogue, bit 3 = no MFMAs
-template <int NSPLIT, typename Epi, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
+// ABL (microbenchmark ablations): bit 0 = no epilogue, bit 2 = no LDS-DMA, bit 3 = no MFMAs
+// OPT (schedule experiments, tools/kernel_bench.py tile ids 80-84): bits 0-1 = where a phase's two LDS-DMA pieces are issued — 0 at the start
+// of its memory half, 1 behind the memory half's fragment reads, 2 inside the matrix half (behind its 2nd and 5th MFMA); bit 2 = no s_setprio.
+// stagger: first-round workgroups (blockIdx < 256) of XCD slot class (blockIdx >> 3) % stagger_n wait class * stagger_ticks x 10 ns before
+// they start, so that the rounds of the launch do not reach their store-heavy epilogues at the same moment (0 = off)
+template <int NSPLIT, typename Epi, int ABL = 0, int OPT = 0>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int stagger_n, int stagger_ticks) {
   using namespace p8;
   static_assert(NSPLIT == 1 || NSPLIT == 2, "plain fp16 rows or MX lines");
   constexpr bool MX = NSPLIT == 2;
   constexpr int NPL = MX ? 2 : 1;
   constexpr int TM = 4, TN = 2, BM = 256, BN = 256, OPB = P8_OPB;
+  constexpr int DMAPOS = OPT & 3;
+  constexpr bool PRIO = !(OPT & 4);
   F5_DYN_LDS(char, smem);
+#ifndef F5_HIPEMU
+  if (stagger_n > 1 && blockIdx.x < 256) {
+    const uint64_t until = __builtin_amdgcn_s_memrealtime() + (uint64_t)(((blockIdx.x >> 3) % stagger_n) * stagger_ticks);
+    while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = pp::uniform(tid >> 6);
@@ -96,17 +108,20 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
     }
   char* const a_dst = smem + pa * 1024;
   char* const w_dst = smem + 2 * OPB + pw * 1024;
-  auto issue_a = [&](auto H, auto BUF, int kt) {  // quarter a01 (H = 0) / a23 (1) of k-tile kt into buffer BUF
-    constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
+  // PC: which of this wave's two pieces of the quarter (-1: both)
+  auto issue_a = [&](auto H, auto BUF, int kt, auto PC) {  // quarter a01 (H = 0) / a23 (1) of k-tile kt into buffer BUF
+    constexpr int h = decltype(H)::value, buf = decltype(BUF)::value, pc = decltype(PC)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(Ar, a_dst + buf * OPB + h * 8192 + p * 1024, qa[h][p], (uint32_t)kt * GEMM_KTB);
+    for (int p = 0; p < 2; ++p)
+      if (pc < 0 || pc == p) pp::dma_b128(Ar, a_dst + buf * OPB + h * 8192 + p * 1024, qa[h][p], (uint32_t)kt * GEMM_KTB);
   };
-  auto issue_w = [&](auto H, auto BUF, int kt) {  // quarter w0 (H = 0) / w1 (1)
-    constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
+  auto issue_w = [&](auto H, auto BUF, int kt, auto PC) {  // quarter w0 (H = 0) / w1 (1)
+    constexpr int h = decltype(H)::value, buf = decltype(BUF)::value, pc = decltype(PC)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(Wr, w_dst + buf * OPB + h * 4096 + p * 1024, qw[h][p], (uint32_t)kt * GEMM_KTB);
+    for (int p = 0; p < 2; ++p)
+      if (pc < 0 || pc == p) pp::dma_b128(Wr, w_dst + buf * OPB + h * 4096 + p * 1024, qw[h][p], (uint32_t)kt * GEMM_KTB);
   };
 
   f32x16 acc[TM][TN];
@@ -144,38 +159,48 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
     constexpr int i = decltype(I)::value, buf = decltype(BUF)::value;
     static_for<4>([&](auto X) { fw[i][decltype(X)::value].u = pp::lds_read_b128<i * 4096 + buf * OPB>(fw_addr[decltype(X)::value]); });
   };
-  auto mma_q = [&](auto JP, auto I) {  // quadrant (row tiles 2 JP, 2 JP + 1) x weight tile I over the whole k-tile
+  // One phase.  ISS: the quarter this phase requests (a callable; nothing in the last pair), RD: its fragment reads, VM: the counted wait that
+  // makes the NEXT phase's operands (this wave's pieces) landed before the barrier that ends the memory half (-1: nothing left in flight),
+  // (JP, I): the quadrant its matrix half multiplies, closing: whether the matrix half ends with a barrier (group 1 skips its very last one).
+  auto phase = [&](auto LIVE, auto ISS, auto RD, auto VM, auto JP, auto I, bool closing) {
+    constexpr int vm = decltype(VM)::value;
+    constexpr bool live = decltype(LIVE)::value != 0;  // does ISS request anything?
     constexpr int jp = decltype(JP)::value, i = decltype(I)::value;
-    // every fragment re-defined behind the wait that preceded this call (common.h pin_after_wait: hipcc takes an asm read's destination as
-    // written when the read is ISSUED)
+    // memory half
+    if constexpr (DMAPOS == 0) ISS(IC<-1>{});
+    RD();
+    if constexpr (DMAPOS == 1) ISS(IC<-1>{});
+    if constexpr (vm >= 0 && !(ABL & 4)) pp::wait_vmcnt<(DMAPOS == 2 && live) ? vm - 2 : vm>();  // (DMAPOS 2: this phase's own quarter is not issued yet)
+    pp::wg_barrier();
+    // matrix half
+    pp::lds_wait();  // my fragment reads have landed; nothing is scheduled across
+    if constexpr (PRIO) prio<1>();
+    // every fragment re-defined behind the wait (common.h pin_after_wait: hipcc takes an asm read's destination as written when the read is ISSUED)
     static_for<2>([&](auto JJ) { static_for<4>([&](auto X) { pin_after_wait(fa[decltype(JJ)::value][decltype(X)::value].u); }); });
     static_for<4>([&](auto X) { pin_after_wait(fw[i][decltype(X)::value].u); });
     if constexpr (ABL & 8) {
 #ifndef F5_HIPEMU
       asm volatile("" ::"v"(fw[i][0].u.x), "v"(fw[i][3].u.w), "v"(fa[0][0].u.x), "v"(fa[1][3].u.w));
 #endif
-      return;
+      if constexpr (DMAPOS == 2) ISS(IC<-1>{});
+    } else {
+      constexpr int NH = MX ? 2 : 4;  // fp16 MFMA k-steps of the line
+      static_for<NH>([&](auto X) {
+        constexpr int x = decltype(X)::value;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) Mma32<f16>::mma(acc[2 * jp + jj][i], fw[i][x], fa[jj][x]);
+        if constexpr (DMAPOS == 2 && x < 2) {  // behind the 2nd and the 4th MFMA: one piece each, in the matrix pipe's shadow
+          pp::pin();
+          ISS(IC<x>{});
+          pp::pin();
+        }
+      });
+      if constexpr (MX) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) mx_mma(acc[2 * jp + jj][i], fw[i][2].u, fw[i][3].u, fa[jj][2].u, fa[jj][3].u);  // both correction terms of the line
+      }
     }
-    constexpr int NH = MX ? 2 : 4;  // fp16 MFMA k-steps of the line
-#pragma unroll
-    for (int x = 0; x < NH; ++x)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) Mma32<f16>::mma(acc[2 * jp + jj][i], fw[i][x], fa[jj][x]);
-    if constexpr (MX) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) mx_mma(acc[2 * jp + jj][i], fw[i][2].u, fw[i][3].u, fa[jj][2].u, fa[jj][3].u);  // both correction terms of the line
-    }
-  };
-  // end of a memory half: (this wave's pieces of) the next phase's operands have landed, then the barrier that ends the partner's matrix half
-  auto mem_end = [&](auto VM) {
-    if constexpr (decltype(VM)::value >= 0 && !(ABL & 4)) pp::wait_vmcnt<decltype(VM)::value>();
-    pp::wg_barrier();
-  };
-  auto mat_half = [&](auto JP, auto I, bool closing) {
-    pp::lds_wait();  // my fragment reads have landed; nothing is scheduled across
-    prio<1>();
-    mma_q(JP, I);
-    prio<0>();
+    if constexpr (PRIO) prio<0>();
     pp::pin();
     if (closing) pp::wg_barrier();
   };
@@ -187,58 +212,34 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   // k-tiles t (even: buffer 0) and t + 1 (buffer 1).  MODE 0: steady state (k-tiles t + 2, t + 3 exist and are requested), 1: the last pair.
   auto pair = [&](auto MODE, int t) {
     constexpr bool st = decltype(MODE)::value == 0;
+    auto iss = [&](auto f) { if constexpr (st) f(); };  // the last pair requests nothing beyond E0's quarter
+    using LV = IC<st ? 1 : 0>;
     // E0
-    issue_a(HI{}, B1{}, t + 1);
-    read_a(LO{}, B0{});
-    mem_end(IC<10>{});
-    mat_half(LO{}, LO{}, true);
+    phase(IC<1>{}, [&](auto PC) { issue_a(HI{}, B1{}, t + 1, PC); }, [&] { read_a(LO{}, B0{}); }, IC<10>{}, LO{}, LO{}, true);
     // E1
-    if constexpr (st) issue_w(LO{}, B0{}, t + 2);
-    read_w(HI{}, B0{});
-    mem_end(IC<st ? 10 : 8>{});
-    mat_half(LO{}, HI{}, true);
+    phase(LV{}, [&](auto PC) { iss([&] { issue_w(LO{}, B0{}, t + 2, PC); }); }, [&] { read_w(HI{}, B0{}); }, IC<st ? 10 : 8>{}, LO{}, HI{}, true);
     // E2
-    if constexpr (st) issue_a(LO{}, B0{}, t + 2);
-    read_a(HI{}, B0{});
-    mem_end(IC<st ? 10 : 6>{});
-    mat_half(HI{}, HI{}, true);
+    phase(LV{}, [&](auto PC) { iss([&] { issue_a(LO{}, B0{}, t + 2, PC); }); }, [&] { read_a(HI{}, B0{}); }, IC<st ? 10 : 6>{}, HI{}, HI{}, true);
     // E3: weight tile 1 is free (its last MFMAs were E2's): k-tile t + 1's is read now
-    if constexpr (st) issue_w(HI{}, B0{}, t + 2);
-    read_w(HI{}, B1{});
-    mem_end(IC<st ? 10 : 4>{});
-    mat_half(HI{}, LO{}, true);
+    phase(LV{}, [&](auto PC) { iss([&] { issue_w(HI{}, B0{}, t + 2, PC); }); }, [&] { read_w(HI{}, B1{}); }, IC<st ? 10 : 4>{}, HI{}, LO{}, true);
     // O0
-    if constexpr (st) issue_a(HI{}, B0{}, t + 2);
-    read_a(LO{}, B1{});
-    mem_end(IC<st ? 10 : 2>{});
-    mat_half(LO{}, HI{}, true);
+    phase(LV{}, [&](auto PC) { iss([&] { issue_a(HI{}, B0{}, t + 2, PC); }); }, [&] { read_a(LO{}, B1{}); }, IC<st ? 10 : 2>{}, LO{}, HI{}, true);
     // O1
-    if constexpr (st) issue_w(HI{}, B1{}, t + 3);
-    read_w(LO{}, B1{});
-    mem_end(IC<st ? 10 : 0>{});
-    mat_half(LO{}, LO{}, true);
+    phase(LV{}, [&](auto PC) { iss([&] { issue_w(HI{}, B1{}, t + 3, PC); }); }, [&] { read_w(LO{}, B1{}); }, IC<st ? 10 : 0>{}, LO{}, LO{}, true);
     // O2
-    if constexpr (st) issue_a(LO{}, B1{}, t + 3);
-    read_a(HI{}, B1{});
-    mem_end(IC<st ? 10 : -1>{});
-    mat_half(HI{}, LO{}, true);
-    // O3: weight tile 0 is free: k-tile t + 2's is read now
-    if constexpr (st) {
-      issue_w(LO{}, B1{}, t + 3);
-      read_w(LO{}, B0{});
-    }
-    mem_end(IC<st ? 10 : -1>{});
-    mat_half(HI{}, HI{}, st || grp == 0);  // group 1 started one barrier late: it skips the last one
+    phase(LV{}, [&](auto PC) { iss([&] { issue_a(LO{}, B1{}, t + 3, PC); }); }, [&] { read_a(HI{}, B1{}); }, IC<st ? 10 : -1>{}, HI{}, LO{}, true);
+    // O3: weight tile 0 is free: k-tile t + 2's is read now; group 1 started one barrier late: it skips the last one
+    phase(LV{}, [&](auto PC) { iss([&] { issue_w(LO{}, B1{}, t + 3, PC); }); }, [&] { if constexpr (st) read_w(LO{}, B0{}); }, IC<st ? 10 : -1>{}, HI{}, HI{}, st || grp == 0);
   };
 
   // prologue: the seven quarters the steady state would have in flight, in its order; the first two landed and visible
-  issue_w(LO{}, B0{}, 0);
-  issue_a(LO{}, B0{}, 0);
-  issue_w(HI{}, B0{}, 0);
-  issue_a(HI{}, B0{}, 0);
-  issue_w(HI{}, B1{}, 1);
-  issue_a(LO{}, B1{}, 1);
-  issue_w(LO{}, B1{}, 1);
+  issue_w(LO{}, B0{}, 0, IC<-1>{});
+  issue_a(LO{}, B0{}, 0, IC<-1>{});
+  issue_w(HI{}, B0{}, 0, IC<-1>{});
+  issue_a(HI{}, B0{}, 0, IC<-1>{});
+  issue_w(HI{}, B1{}, 1, IC<-1>{});
+  issue_a(LO{}, B1{}, 1, IC<-1>{});
+  issue_w(LO{}, B1{}, 1, IC<-1>{});
   if constexpr (!(ABL & 4)) pp::wait_vmcnt<10>();
   pp::wg_barrier();
   if (grp == 1) pp::wg_barrier();  // half a phase behind group 0 from here on

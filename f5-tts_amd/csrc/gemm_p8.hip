@@ -7,22 +7,24 @@
 #include "gemm_p8.h"
 
 namespace {
-template <int NSPLIT, typename Epi, int ABL>
+template <int NSPLIT, typename Epi, int ABL, int OPT = 0>
 hipError_t launch_abl(const GemmCore& g, const Epi& e, hipStream_t s) {
-  auto kern = gemm_p8_kernel<NSPLIT, Epi, ABL>;
-  if constexpr (ABL != 0) {  // microbenchmark ablations only: the production instantiations get their limit in init_p8_kernels()
+  auto kern = gemm_p8_kernel<NSPLIT, Epi, ABL, OPT>;
+  if constexpr (ABL != 0 || OPT != 0) {  // microbenchmark ablations only: the production instantiations get their limit in init_p8_kernels()
     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
     if (err != hipSuccess) return err;
   }
   const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256), 1, 1);
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "gemm_p8 nsplit %d abl %d M=%d N=%d K=%d grid %u\n", NSPLIT, ABL, g.M, g.N, g.K, grid.x);
-  hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS_BYTES, s, g, e);
+  if (trace) fprintf(stderr, "gemm_p8 nsplit %d abl %d opt %d M=%d N=%d K=%d grid %u\n", NSPLIT, ABL, OPT, g.M, g.N, g.K, grid.x);
+  int sn = 0, st = 0;  // experiment (tools/gpu_run.sh p8b): "classes,ticks" — first-round workgroups start class * ticks * 10 ns late
+  if (const char* v = getenv("F5HIP_P8_STAGGER")) sscanf(v, "%d,%d", &sn, &st);
+  hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS_BYTES, s, g, e, sn, st);
   return hipGetLastError();
 }
 template <int NSPLIT, typename Epi>
 hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<NSPLIT, Epi, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<NSPLIT, Epi, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
 }
 }  // namespace
 
@@ -42,6 +44,17 @@ hipError_t launch_p8(const GemmCore& g, const Epi& e, int abl, hipStream_t s) {
       case 4: return launch_abl<NSPLIT, Epi, 4>(g, e, s);
       case 8: return launch_abl<NSPLIT, Epi, 8>(g, e, s);
       case 9: return launch_abl<NSPLIT, Epi, 9>(g, e, s);
+      case 2: {  // the epilogue's arithmetic without its stores
+        const PpEpiAct16<NSPLIT == 2 ? 2 : 0, ACT_GELU_TANH, 1> ens{e.bias, e.out, e.ld, e.M, e.N};
+        return launch_abl<NSPLIT, decltype(ens), 0>(g, ens, s);
+      }
+      // schedule experiments (tile ids 81-84): 100 + OPT
+      case 101: return launch_abl<NSPLIT, Epi, 0, 1>(g, e, s);
+      case 102: return launch_abl<NSPLIT, Epi, 0, 2>(g, e, s);
+      case 104: return launch_abl<NSPLIT, Epi, 0, 4>(g, e, s);
+      case 106: return launch_abl<NSPLIT, Epi, 0, 6>(g, e, s);
+      case 11: return launch_abl<NSPLIT, Epi, 1, 1>(g, e, s);  // (11080 / 12080: the same without the epilogue)
+      case 12: return launch_abl<NSPLIT, Epi, 1, 2>(g, e, s);
       default: return hipErrorNotSupported;
     }
   } else if (abl != 0) {

@@ -4,8 +4,12 @@
 
 #include "gemm.h"  // common.h pulls in the HIP runtime (or the host shim under F5_HIPEMU)
 
-enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3, OP_F16M2 = 4 };  // OP_F16M2: fp16m rows without the coarse values (common.h "fp16m2"): 96 bytes per 32 k  // GEMM operand kind; OP_F16M: fp16 + MX-fp6 correction lines (common.h), the
-                                                             // pipelined block-GEMM kernel only (no generic-kernel fallback: launches fail)
+// GEMM operand kind.  OP_F16M: fp16 + MX-fp6 correction lines (common.h "fp16m"); OP_F16M2: the same rows without their coarse values
+// (common.h "fp16m2": 96 bytes per 32 k).  Both exist for the pipelined block-GEMM kernels ONLY: a launch that those kernels do not take
+// FAILS (hipErrorInvalidValue) instead of falling back to the generic kernel, which has no MX k-loop.  Callers therefore pre-validate:
+// the engine chooses the modes per call (api.cpp `mx_call`: model shape, at least 8 tokens per sequence, gemm_mx_tiles_usable()) and runs
+// the call in OP_F16X3 when any precondition fails.
+enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3, OP_F16M2 = 4 };
 
 // ---- gemm.hip ---------------------------------------------------------------------------------
 // batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
@@ -14,6 +18,8 @@ hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream
 hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g, const EpiQKV& e, int variant, hipStream_t s);  // microbenchmarks / tests: < 0 = heuristic
 // explicit tile variant (microbenchmarks): 0 = 64x128, 1 = 128x64, 2 = 128x128 (rows x channels), -1 = heuristic
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s);
+// do the tuning knobs of this process leave every OP_F16M launch on a tile instantiated for MX lines? (gemm.hip)
+bool gemm_mx_tiles_usable();
 // one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
 hipError_t init_gemm_kernels();
 // race_probe.hip: the reproducer of round 2's co-residency fault in the fused q|k|v epilogue (microbenchmarks / tests only)

@@ -250,7 +250,10 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
  * off, qk_norm, long skip, UNetT / MMDiT, the materialised fp32 attention, "attn_kv_split" > 1, n >= 65536 or 2 * batch >= 65536 (the
  * row table packs (sequence, token) into 16 + 16 bits)),
  * "attn_kv_split" (1 off (default) / 2..8: flash attention with every query block cut into that many key ranges + a merge kernel —
- * shorter workgroups for small batches, csrc/attention_kernel.h). */
+ * shorter workgroups for small batches, csrc/attention_kernel.h),
+ * "mx_weights" (1 (default) / 0; read by the next f5hip_finalize_weights: whether the MX-line copies of the block weights that
+ * F5HIP_PREC_FP16M multiplies are built — 2 more halves per block-weight element on top of the fp32 blob and the plain / hi|lo half copies,
+ * +1.3 GB for F5-TTS Base; with 0 an FP16M call runs as FP16X3, for users of the other precisions who want the memory back). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
 /* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
  * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */

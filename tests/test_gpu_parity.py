@@ -617,6 +617,24 @@ def test_invalid_arguments_raise(engines):
         model.sample(wav.cuda(), bad, 40, steps=4, cfg_strength=2.0)
 
 
+@pytest.mark.gpu
+def test_fp16m_runs_as_fp16x3_where_the_mx_tiles_do_not_apply(engines):
+    """fp16m has no generic-kernel fallback inside a launch, so the engine must decide per CALL (csrc/api.cpp mx_call): sequences shorter
+    than 8 tokens — which the fused q|k|v launch of the pipelined kernel does not take (duration 6 / 7 raised 'launch_gemm_qkv
+    failed') — run in fp16x3, bit for bit, instead of failing.  (The tuning knobs that take launches away from the MX tiles are read once
+    per process: tests/test_pp_gemm_shim.py runs them in child processes.)"""
+    from f5_tts_amd.engine import F5HipCFM
+
+    eng = engines("tiny", 1)
+    for dur in (6, 7):
+        wav = synth.synth_wave(256 * 3, seed=1)
+        text = synth.synth_text_ids(1, 3, config.DIT_TINY.text_num_embeds, seed=1)
+        kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)
+        a, _ = F5HipCFM(eng, precision="fp16m").sample(wav.cuda(), text, dur, **kw)
+        b, _ = F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, dur, **kw)
+        assert torch.equal(a.cpu(), b.cpu()) and bool(torch.isfinite(a).all())
+
+
 # ---- L4 glue (f5-tts_amd/infer.py): checkpoint formats and infer_process -------------------------------------------------------
 VOCAB = [" "] + [chr(c) for c in range(33, 127)]  # id 0 = space (unknown), printable ASCII after it
 
