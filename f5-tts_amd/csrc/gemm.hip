@@ -381,7 +381,6 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
     }
     if constexpr (NSPLIT == 1 || NSPLIT == 2) {  // ablations of the ping-pong kernel: 1000 * code + 80 (code 1 no epilogue, 4 no LDS-DMA, 8 no MFMAs, 9 neither epilogue nor MFMAs)
       if (variant >= 1000 && variant % 1000 == 80 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant / 1000, s);
-      if (variant > 80 && variant < 90 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, 100 + (variant - 80), s);  // schedule experiments
     }
     if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
     return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
