@@ -311,6 +311,11 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
     //   M = 11k .. 22k: FF1 (GELU -> MX rows epilogue) 256x256 (150 -> 118 at 11k; two-per-CU 128-130), out / FF2 192x128 two per CU
     //   (22k: 292 -> 210; 256x256 231), q|k|v 128x192 two per CU (260 -> 177)
     //   M = 2812: q|k|v 192x192 (59 -> 48), FF1 192x128 / 8 waves (41 -> 32), out / FF2 96x128 / 4 waves (24 / 40 -> 21 / 34; its k-split 21 / 35)
+    // round 5: the ping-pong 256x256 kernel (gemm_p8.h, id 80) from 16k rows — FF1-type launches from 8k, where the lockstep 256x256 tile was
+    // the choice — (us, lockstep / two-per-CU choice -> ping-pong; profiles/r05a_p8_kernel_bench.log, r05c_*): M = 90k FF1 818 -> 757, FF2 769 ->
+    // 688, q|k|v 1225 -> 1106, out 435 -> 387; M = 45k FF1 425 -> 377; M = 22k FF1 201 -> 184, gate / residual launches 249 -> 233, q|k|v at
+    // 45k rows 697 -> 665; at 11k rows the two-per-CU tiles stay ahead on everything but FF1 (123 -> 110)
+    if (!mx2 && (g.M >= 16384 || (act16 && g.M >= 8192)) && p8_applies(2, g)) return 80;
     if (g.M >= 40000) return 50;
     if (g.M >= 4096) return qkv ? 61 : (act16 && g.M >= 8192) ? 50 : (g.N >= 2048 || g.M >= 8192) ? 62 : 63;
     static const int kss = [] { const char* e = getenv("F5HIP_MX_KSS"); return e ? atoi(e) : 1; }();  // A/B switch: the k-step-split tiles for the one-round launches
@@ -319,6 +324,9 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
     return g.N >= 3072 ? 55 : 59;
   }
   if (g.M < 512) return 0;  // a handful of row tiles: the generic small tiles
+  // plain fp16 rows: the ping-pong kernel from 16k rows (M = 22k FF1 122 -> 111 us, 45k 252 -> 220, 90k 534 -> 445 = 850 TF against hipBLASLt's
+  // 1165 without an epilogue; profiles/r05a_p8_kernel_bench.log, r05c_*); fp16x3 rows have no such kernel
+  if (nsplit_planes == 1 && g.M >= 16384 && p8_applies(1, g)) return 80;
   if (g.M >= 40000) return 50;
   // A few rounds (B = 2 .. 16): the 4-wave, 2-stage tiles that fit TWO workgroups per CU - the two run out of phase, one's prologue and
   // epilogue under the other's k-loop.  Kept out of the engine in round 2 because of wrong rope values that came and went with the build;

@@ -21,17 +21,7 @@
 //     wave) exactly two phases after the phase that read them (every wave's reads of the region have been waited for by then: WAR-safe with
 //     no extra wait), six phases before the phase that needs them: one quarter per phase, `s_waitcnt vmcnt(10)` (five younger quarters stay in
 //     flight) in the memory half of the phase BEFORE the consumer, so the landing is separated from the first read by a barrier both groups
-//     have passed.
-//   * PERSISTENT TILE LOOP: a launch is at most one workgroup per CU (gridDim = min(tiles, 256)), workgroup b takes the tiles b, b + grid, ..
-//     of the XCD-aware tile order, and the k-tile stream never stops at a tile boundary: the last pair of k-tiles of tile i requests the
-//     first two k-tiles of tile i + 1 in its usual slots (through the next tile's buffer descriptors — the per-lane offsets are tile
-//     independent, a tile's rows beyond M fall outside ITS descriptor), so the next tile starts on landed operands instead of the 112 KB
-//     prologue burst that every CU of a round would issue at the same moment (measured ~5 us per round at 90k rows, profiles/r05b_*), and
-//     tile i's stores drain under tile i + 1's first phases.  Around the epilogue: `vmcnt(0)` first (everything requested so far has
-//     landed — the epilogue's own first wait, for its bias loads, would wait for the same loads), group 0 passes the phase's closing
-//     barrier BEFORE its epilogue and group 1 AFTER, so both groups' epilogues run side by side; the first five phases of the next tile
-//     need no counted wait (all their operands were requested before the epilogue), the sixth waits with the usual count — by then the
-//     stores, which retire in order with the loads, have had five phases to be acknowledged.
+//     have passed.  The last pair of k-tiles is a second copy of the loop body with nothing left to issue and the counts 10, 8, .. 0.
 // Same MFMA order per accumulator as gemm_pp.h / gemm.h (k ascending; MX: hi k-step 0, hi k-step 1, the fp6 correction), so results equal the
 // other tiles' byte for byte (tests/test_pp_gemm_shim.py runs this kernel on the host shim against the generic kernel).
 #pragma once
@@ -51,11 +41,10 @@ using IC = std::integral_constant<int, V>;
 
 constexpr int P8_OPB = 256 * GEMM_KTB;    // one operand's k-tile: 256 rows x 128 B = 32 KB
 constexpr int P8_LDS_BYTES = 4 * P8_OPB;  // A buf 0 | A buf 1 | W buf 0 | W buf 1
-constexpr int P8_MAX_WGS = 256;           // one workgroup per CU (128 KB of LDS each)
 
-// ABL (microbenchmark ablations): bit 0 = no epilogue, bit 2 = no LDS-DMA, bit 3 = no MFMAs
+// ABL (microbenchmark ablations): bit 0 = no epilogue, bit 3 = no MFMAs
 template <int NSPLIT, typename Epi, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int ntiles) {
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   using namespace p8;
   static_assert(NSPLIT == 1 || NSPLIT == 2, "plain fp16 rows or MX lines");
   constexpr bool MX = NSPLIT == 2;
@@ -66,13 +55,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int n
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = pp::uniform(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
-  const int kbytes = g.K * 2 * NPL;   // bytes of one operand row; a multiple of 256 (launcher: an even number of k-tiles, at least 4)
-  const int nkt = kbytes / GEMM_KTB;  // k-tiles
-  // tile v of the launch (as gemm_pp_kernel: XCD-contiguous runs — v and v + gridDim sit on the same XCD —, channel tiles fastest, optional
-  // groups of row tiles) -> its first row / channel
-  auto tile_origin = [&](int v, int& m0, int& n0) {
-    const int nt = (g.N + BN - 1) / BN, nwg = ntiles;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = v & 7, slot = v >> 3;
+  int m0, n0;
+  {  // tile order as gemm_pp_kernel: XCD-contiguous runs, channel tiles fastest, optional groups of row tiles
+    const int nt = (g.N + BN - 1) / BN, nwg = gridDim.x;
+    const int bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
     const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     int mt, ntile;
     if (g.group_m > 1) {
@@ -86,58 +72,50 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int n
     }
     m0 = mt * BM;
     n0 = ntile * BN;
-  };
-  // the buffer descriptors of a tile start at ITS first row: rows past the operand's end are out of range (zeros) with tile-independent lane offsets
-  auto desc_a = [&](int m0) {
-    const int rows = g.a_rows - m0;
-    return make_rsrc(reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * 2, rows > 0 ? (uint32_t)((int64_t)(rows - 1) * g.lda * 2 + kbytes) : 0u);
-  };
-  auto desc_w = [&](int n0) {
-    const int rows = g.w_rows - n0;
-    return make_rsrc(reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * 2, rows > 0 ? (uint32_t)((int64_t)(rows - 1) * g.ldw * 2 + kbytes) : 0u);
-  };
+  }
+  const int kbytes = g.K * 2 * NPL;   // bytes of one operand row; a multiple of 256 (launcher: an even number of k-tiles)
+  const int nkt = kbytes / GEMM_KTB;  // k-tiles
+  const BufRsrc Ar = make_rsrc(g.A, (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * 2 + kbytes));
+  const BufRsrc Wr = make_rsrc(g.W, (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * 2 + kbytes));
 
   // LDS-DMA: piece P of an operand tile = rows 8P .. 8P+7 -> bytes [1024 P, +1024) of its buffer; lane l brings row 8P + l/8, logical
-  // 16-byte chunk (l%8) ^ swz(row) (the swizzle sits on the SOURCE side: the LDS destination of a DMA is lane-linear).  A wave's pieces of an
-  // operand are 16, 32 or 64 rows apart — swz(row) = (row >> 1) & 7 is the same for all of them — so ONE per-lane offset serves every piece
-  // and the distance rides in the scalar offset next to the k offset (2 long-lived VGPRs instead of 8).
-  //   A quarters (a01 = rows 0-63 of both groups' halves, a23 = rows 64-127): this wave brings pieces pa, pa + 2 (+ 8 for a23)
-  //   W quarters (w0 / w1 = first / second 32 rows of every 64-channel strip): pieces pw, pw + 2 (+ 4 for w1)
-  const int pa = 16 * grp + 4 * (wn >> 1) + (wn & 1);
-  const int pw = 8 * (wave >> 1) + (wave & 1);
-  uint32_t qa, qw;
-  {
-    int row = 8 * pa + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
-    qa = (uint32_t)((int64_t)row * g.lda * 2 + lc * 16);
-    row = 8 * pw + (lane >> 3);
-    lc = (lane & 7) ^ ((row >> 1) & 7);
-    qw = (uint32_t)((int64_t)row * g.ldw * 2 + lc * 16);
-  }
-  const uint32_t a16 = (uint32_t)(16 * g.lda * 2), w16 = (uint32_t)(16 * g.ldw * 2);  // 16 rows further, in bytes
+  // 16-byte chunk (l%8) ^ swz(row) (the swizzle sits on the SOURCE side: the LDS destination of a DMA is lane-linear).  This wave's two
+  // pieces of every quarter:
+  const int pa = 16 * grp + 2 * wn;                 // a01 quarter (a23: + 8 pieces)
+  const int pw = 8 * (wave >> 1) + 2 * (wave & 1);  // w0 quarter (w1: + 4 pieces)
+  uint32_t qa[2][2], qw[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int row = 8 * (pa + 8 * h + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+      qa[h][p] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * 2 + lc * 16) : OOB_ROW;
+      row = 8 * (pw + 4 * h + p) + (lane >> 3);
+      lc = (lane & 7) ^ ((row >> 1) & 7);
+      qw[h][p] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + lc * 16) : OOB_ROW;
+    }
   char* const a_dst = smem + pa * 1024;
   char* const w_dst = smem + 2 * OPB + pw * 1024;
-  auto issue_a = [&](BufRsrc R, auto H, auto BUF, int kt) {  // quarter a01 (H = 0) / a23 (1) of k-tile kt into buffer BUF
+  auto issue_a = [&](auto H, auto BUF, int kt) {  // quarter a01 (H = 0) / a23 (1) of k-tile kt into buffer BUF
     constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(R, a_dst + buf * OPB + h * 8192 + p * 2048, qa, (uint32_t)kt * GEMM_KTB + (uint32_t)(4 * h + p) * a16);
+    for (int p = 0; p < 2; ++p) pp::dma_b128(Ar, a_dst + buf * OPB + h * 8192 + p * 1024, qa[h][p], (uint32_t)kt * GEMM_KTB);
   };
-  auto issue_w = [&](BufRsrc R, auto H, auto BUF, int kt) {  // quarter w0 (H = 0) / w1 (1)
+  auto issue_w = [&](auto H, auto BUF, int kt) {  // quarter w0 (H = 0) / w1 (1)
     constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(R, w_dst + buf * OPB + h * 4096 + p * 2048, qw, (uint32_t)kt * GEMM_KTB + (uint32_t)(2 * h + p) * w16);
+    for (int p = 0; p < 2; ++p) pp::dma_b128(Wr, w_dst + buf * OPB + h * 4096 + p * 1024, qw[h][p], (uint32_t)kt * GEMM_KTB);
   };
 
-  f32x16 acc[TM][TN];  // (defined at the top of every tile: not carried around the tile loop)
-  auto zero_acc = [&] {
+  f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+  for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
-  };
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
   // fragment addressing: lane (row = lane & 31, half = lane >> 5) reads 16-byte chunks of its row's line.  Plain fp16: chunk 2 ks + half
   // for the 16-wide k-step ks = 0..3.  MX lines: chunks half and 2 + half (the two hi k-steps), 4 + 2 half and 5 + 2 half (the lane's P words).
@@ -166,38 +144,37 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int n
     constexpr int i = decltype(I)::value, buf = decltype(BUF)::value;
     static_for<4>([&](auto X) { fw[i][decltype(X)::value].u = pp::lds_read_b128<i * 4096 + buf * OPB>(fw_addr[decltype(X)::value]); });
   };
-  // One phase.  ISS: the quarter this phase requests (a callable), RD: its fragment reads, VM: the counted wait that makes the NEXT phase's
-  // operands (this wave's pieces) landed before the barrier that ends the memory half (-1: none needed), (JP, I): the quadrant its matrix half
-  // multiplies, closing: whether the matrix half ends with a barrier.
-  auto phase = [&](auto ISS, auto RD, auto VM, auto JP, auto I, bool closing) {
-    constexpr int vm = decltype(VM)::value;
+  auto mma_q = [&](auto JP, auto I) {  // quadrant (row tiles 2 JP, 2 JP + 1) x weight tile I over the whole k-tile
     constexpr int jp = decltype(JP)::value, i = decltype(I)::value;
-    // memory half
-    ISS();
-    RD();
-    if constexpr (vm >= 0 && !(ABL & 4)) pp::wait_vmcnt<(vm >= 0 ? vm : 0)>();
-    pp::wg_barrier();
-    // matrix half
-    pp::lds_wait();  // my fragment reads have landed; nothing is scheduled across
-    prio<1>();
-    // every fragment re-defined behind the wait (common.h pin_after_wait: hipcc takes an asm read's destination as written when the read is ISSUED)
+    // every fragment re-defined behind the wait that preceded this call (common.h pin_after_wait: hipcc takes an asm read's destination as
+    // written when the read is ISSUED)
     static_for<2>([&](auto JJ) { static_for<4>([&](auto X) { pin_after_wait(fa[decltype(JJ)::value][decltype(X)::value].u); }); });
     static_for<4>([&](auto X) { pin_after_wait(fw[i][decltype(X)::value].u); });
     if constexpr (ABL & 8) {
 #ifndef F5_HIPEMU
       asm volatile("" ::"v"(fw[i][0].u.x), "v"(fw[i][3].u.w), "v"(fa[0][0].u.x), "v"(fa[1][3].u.w));
 #endif
-    } else {
-      constexpr int NH = MX ? 2 : 4;  // fp16 MFMA k-steps of the line
-#pragma unroll
-      for (int x = 0; x < NH; ++x)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) Mma32<f16>::mma(acc[2 * jp + jj][i], fw[i][x], fa[jj][x]);
-      if constexpr (MX) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) mx_mma(acc[2 * jp + jj][i], fw[i][2].u, fw[i][3].u, fa[jj][2].u, fa[jj][3].u);  // both correction terms of the line
-      }
+      return;
     }
+    constexpr int NH = MX ? 2 : 4;  // fp16 MFMA k-steps of the line
+#pragma unroll
+    for (int x = 0; x < NH; ++x)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) Mma32<f16>::mma(acc[2 * jp + jj][i], fw[i][x], fa[jj][x]);
+    if constexpr (MX) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) mx_mma(acc[2 * jp + jj][i], fw[i][2].u, fw[i][3].u, fa[jj][2].u, fa[jj][3].u);  // both correction terms of the line
+    }
+  };
+  // end of a memory half: (this wave's pieces of) the next phase's operands have landed, then the barrier that ends the partner's matrix half
+  auto mem_end = [&](auto VM) {
+    if constexpr (decltype(VM)::value >= 0 && !(ABL & 4)) pp::wait_vmcnt<decltype(VM)::value>();
+    pp::wg_barrier();
+  };
+  auto mat_half = [&](auto JP, auto I, bool closing) {
+    pp::lds_wait();  // my fragment reads have landed; nothing is scheduled across
+    prio<1>();
+    mma_q(JP, I);
     prio<0>();
     pp::pin();
     if (closing) pp::wg_barrier();
@@ -207,82 +184,79 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi, int n
   using LO = IC<0>;  // a01 / w0 quarter, row tiles 0-1, weight tile 0
   using HI = IC<1>;  // a23 / w1
 
-  // The pair of k-tiles t (even: buffer 0), t + 1 (buffer 1) of the current tile (descriptors Ac, Wc).
-  // LAST 0: k-tiles t + 2, t + 3 of this tile are requested;  2: the last pair of a tile — the NEXT tile's k-tiles 0, 1 are requested through
-  // An, Wn (a workgroup's last tile has empty ones: its requests read nothing and land as zeros nobody reads — one code path, no second
-  // copy of the body whose accumulators would have to be merged with this one's at a join).
-  // FIRST 1: the first pair of a tile — phases E0 .. O0 read operands that landed before the tile began (the vmcnt(0) in front of the
-  // epilogue / behind the prologue), so they carry no counted wait; O1 is the first phase whose successor reads a quarter requested since.
-  auto pair = [&](auto LASTC, auto FIRSTC, int t, BufRsrc Ac, BufRsrc Wc, BufRsrc An, BufRsrc Wn) {
-    constexpr int last = decltype(LASTC)::value;
-    constexpr bool first = decltype(FIRSTC)::value != 0;
-    const int k2 = last == 2 ? 0 : t + 2, k3 = last == 2 ? 1 : t + 3;
-    const BufRsrc A2 = last == 2 ? An : Ac, W2 = last == 2 ? Wn : Wc;
-    constexpr int V = first ? -1 : 10;
+  // k-tiles t (even: buffer 0) and t + 1 (buffer 1).  MODE 0: steady state (k-tiles t + 2, t + 3 exist and are requested), 1: the last pair.
+  auto pair = [&](auto MODE, int t) {
+    constexpr bool st = decltype(MODE)::value == 0;
     // E0
-    phase([&] { issue_a(Ac, HI{}, B1{}, t + 1); }, [&] { read_a(LO{}, B0{}); }, IC<V>{}, LO{}, LO{}, true);
+    issue_a(HI{}, B1{}, t + 1);
+    read_a(LO{}, B0{});
+    mem_end(IC<10>{});
+    mat_half(LO{}, LO{}, true);
     // E1
-    phase([&] { issue_w(W2, LO{}, B0{}, k2); }, [&] { read_w(HI{}, B0{}); }, IC<V>{}, LO{}, HI{}, true);
+    if constexpr (st) issue_w(LO{}, B0{}, t + 2);
+    read_w(HI{}, B0{});
+    mem_end(IC<st ? 10 : 8>{});
+    mat_half(LO{}, HI{}, true);
     // E2
-    phase([&] { issue_a(A2, LO{}, B0{}, k2); }, [&] { read_a(HI{}, B0{}); }, IC<V>{}, HI{}, HI{}, true);
+    if constexpr (st) issue_a(LO{}, B0{}, t + 2);
+    read_a(HI{}, B0{});
+    mem_end(IC<st ? 10 : 6>{});
+    mat_half(HI{}, HI{}, true);
     // E3: weight tile 1 is free (its last MFMAs were E2's): k-tile t + 1's is read now
-    phase([&] { issue_w(W2, HI{}, B0{}, k2); }, [&] { read_w(HI{}, B1{}); }, IC<V>{}, HI{}, LO{}, true);
+    if constexpr (st) issue_w(HI{}, B0{}, t + 2);
+    read_w(HI{}, B1{});
+    mem_end(IC<st ? 10 : 4>{});
+    mat_half(HI{}, LO{}, true);
     // O0
-    phase([&] { issue_a(A2, HI{}, B0{}, k2); }, [&] { read_a(LO{}, B1{}); }, IC<V>{}, LO{}, HI{}, true);
+    if constexpr (st) issue_a(HI{}, B0{}, t + 2);
+    read_a(LO{}, B1{});
+    mem_end(IC<st ? 10 : 2>{});
+    mat_half(LO{}, HI{}, true);
     // O1
-    phase([&] { issue_w(W2, HI{}, B1{}, k3); }, [&] { read_w(LO{}, B1{}); }, IC<10>{}, LO{}, LO{}, true);
+    if constexpr (st) issue_w(HI{}, B1{}, t + 3);
+    read_w(LO{}, B1{});
+    mem_end(IC<st ? 10 : 0>{});
+    mat_half(LO{}, LO{}, true);
     // O2
-    phase([&] { issue_a(A2, LO{}, B1{}, k3); }, [&] { read_a(HI{}, B1{}); }, IC<10>{}, HI{}, LO{}, true);
-    // O3: weight tile 0 is free: the next k-tile's (k-tile t + 2, or the next tile's first) is read now.  The closing barrier: always inside a
-    // tile; at a tile's end group 0 passes it BEFORE its epilogue and group 1 AFTER (tile loop below) or — the workgroup's last tile — never
-    // (it started one barrier late)
-    phase([&] { issue_w(W2, LO{}, B1{}, k3); }, [&] { read_w(LO{}, B0{}); }, IC<10>{}, HI{}, HI{}, last == 0 || grp == 0);
+    if constexpr (st) issue_a(LO{}, B1{}, t + 3);
+    read_a(HI{}, B1{});
+    mem_end(IC<st ? 10 : -1>{});
+    mat_half(HI{}, LO{}, true);
+    // O3: weight tile 0 is free: k-tile t + 2's is read now
+    if constexpr (st) {
+      issue_w(LO{}, B1{}, t + 3);
+      read_w(LO{}, B0{});
+    }
+    mem_end(IC<st ? 10 : -1>{});
+    mat_half(HI{}, HI{}, st || grp == 0);  // group 1 started one barrier late: it skips the last one
   };
 
-  int v = blockIdx.x, m0, n0;
-  tile_origin(v, m0, n0);
-  BufRsrc Ac = desc_a(m0), Wc = desc_w(n0);
-  // prologue: the seven quarters a tile finds requested by its predecessor, in the steady state's order — all landed and visible, as behind an epilogue
-  issue_w(Wc, LO{}, B0{}, 0);
-  issue_a(Ac, LO{}, B0{}, 0);
-  issue_w(Wc, HI{}, B0{}, 0);
-  issue_a(Ac, HI{}, B0{}, 0);
-  issue_w(Wc, HI{}, B1{}, 1);
-  issue_a(Ac, LO{}, B1{}, 1);
-  issue_w(Wc, LO{}, B1{}, 1);
-  if constexpr (!(ABL & 4)) pp::wait_vmcnt<0>();
+  // prologue: the seven quarters the steady state would have in flight, in its order; the first two landed and visible
+  issue_w(LO{}, B0{}, 0);
+  issue_a(LO{}, B0{}, 0);
+  issue_w(HI{}, B0{}, 0);
+  issue_a(HI{}, B0{}, 0);
+  issue_w(HI{}, B1{}, 1);
+  issue_a(LO{}, B1{}, 1);
+  issue_w(LO{}, B1{}, 1);
+  if constexpr (!(ABL & 4)) pp::wait_vmcnt<10>();
   pp::wg_barrier();
   if (grp == 1) pp::wg_barrier();  // half a phase behind group 0 from here on
   read_w(LO{}, B0{});
-  while (true) {
-    zero_acc();
-    const int vn = v + (int)gridDim.x;
-    const bool has_next = vn < ntiles;
-    int mn = 0, nn = 0;
-    if (has_next) tile_origin(vn, mn, nn);
-    const BufRsrc An = desc_a(has_next ? mn : g.a_rows), Wn = desc_w(has_next ? nn : g.w_rows);  // (no successor: empty descriptors)
-    pair(IC<0>{}, IC<1>{}, 0, Ac, Wc, An, Wn);
-    for (int t = 2; t < nkt - 2; t += 2) pair(IC<0>{}, IC<0>{}, t, Ac, Wc, An, Wn);
-    pair(IC<2>{}, IC<0>{}, nkt - 2, Ac, Wc, An, Wn);
-    // everything requested so far (the next tile's first seven quarters) has landed: its first phases need no counted wait
-    if constexpr (!(ABL & 4)) pp::wait_vmcnt<0>();
-    if constexpr (ABL & 1) {
+  for (int t = 0; t < nkt - 2; t += 2) pair(IC<0>{}, t);
+  pair(IC<1>{}, nkt - 2);
+
+  if constexpr (ABL & 1) {
 #ifndef F5_HIPEMU
 #pragma unroll
-      for (int j = 0; j < TM; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
+        for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
-    } else {
-      pp_unscale<TM, TN>(acc, g, n0 + wn * 64, lane);
-      epi.template tile<TM, TN>(acc, m0 + grp * 128, n0 + wn * 64, lane);
-    }
-    if (!has_next) break;
-    pp::pin();
-    if (grp == 1) pp::wg_barrier();  // group 1's closing barrier of the tile's last phase, behind its epilogue (group 0 passed it before its own)
-    v = vn; m0 = mn; n0 = nn;
-    Ac = An; Wc = Wn;
+  } else {
+    pp_unscale<TM, TN>(acc, g, n0 + wn * 64, lane);
+    epi.template tile<TM, TN>(acc, m0 + grp * 128, n0 + wn * 64, lane);
   }
 }

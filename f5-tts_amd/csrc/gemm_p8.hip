@@ -8,20 +8,16 @@
 
 namespace {
 template <int NSPLIT, typename Epi, int ABL>
-hipError_t launch_abl(const GemmCore& g, const Epi& e, hipStream_t s, bool one_tile_each = false) {
+hipError_t launch_abl(const GemmCore& g, const Epi& e, hipStream_t s) {
   auto kern = gemm_p8_kernel<NSPLIT, Epi, ABL>;
   if constexpr (ABL != 0) {  // microbenchmark ablations only: the production instantiations get their limit in init_p8_kernels()
     const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS_BYTES);
     if (err != hipSuccess) return err;
   }
-  const int ntiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
-  // persistent: one workgroup per CU walks the tiles b, b + grid, ..  (F5HIP_P8_WGS: tuning knob of the microbenchmarks — e.g. the tile
-  // count itself = one tile per workgroup, the non-persistent form)
-  static const int wgs = [] { const char* v = getenv("F5HIP_P8_WGS"); return v && atoi(v) > 0 ? atoi(v) : P8_MAX_WGS; }();
-  const dim3 grid(ntiles < wgs || one_tile_each ? ntiles : wgs, 1, 1);
+  const dim3 grid(((g.M + 255) / 256) * ((g.N + 255) / 256), 1, 1);
   static const bool trace = getenv("F5HIP_GEMM_TRACE") != nullptr;
-  if (trace) fprintf(stderr, "gemm_p8 nsplit %d abl %d M=%d N=%d K=%d tiles %d grid %u\n", NSPLIT, ABL, g.M, g.N, g.K, ntiles, grid.x);
-  hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS_BYTES, s, g, e, ntiles);
+  if (trace) fprintf(stderr, "gemm_p8 nsplit %d abl %d M=%d N=%d K=%d grid %u\n", NSPLIT, ABL, g.M, g.N, g.K, grid.x);
+  hipLaunchKernelGGL(kern, grid, dim3(512), P8_LDS_BYTES, s, g, e);
   return hipGetLastError();
 }
 template <int NSPLIT, typename Epi>
@@ -30,11 +26,10 @@ hipError_t set_attr() {
 }
 }  // namespace
 
-bool p8_applies(int nsplit, const GemmCore& g) {  // an even number of whole k-tiles (the loop body is a pair), at least two pairs (a tile's first pair
-                                                  // requests its third and fourth k-tile), the operand modes built here, 31-bit offsets inside a tile's descriptor
+bool p8_applies(int nsplit, const GemmCore& g) {  // an even number of whole k-tiles (the loop body is a pair), the operand modes built here
   if (nsplit != 1 && nsplit != 2) return false;
   const int64_t kbytes = (int64_t)g.K * 2 * (nsplit == 2 ? 2 : 1);
-  return kbytes % (2 * GEMM_KTB) == 0 && kbytes >= 4 * GEMM_KTB && g.N % 32 == 0 && g.M >= 1 && 256 * g.lda * 2 < (int64_t)0x7ff00000 && 256 * g.ldw * 2 < (int64_t)0x7ff00000;
+  return kbytes % (2 * GEMM_KTB) == 0 && kbytes >= 2 * GEMM_KTB && g.N % 32 == 0 && g.M >= 1;
 }
 
 template <int NSPLIT, typename Epi>
@@ -47,8 +42,6 @@ hipError_t launch_p8(const GemmCore& g, const Epi& e, int abl, hipStream_t s) {
       case 4: return launch_abl<NSPLIT, Epi, 4>(g, e, s);
       case 8: return launch_abl<NSPLIT, Epi, 8>(g, e, s);
       case 9: return launch_abl<NSPLIT, Epi, 9>(g, e, s);
-      case 16: return launch_abl<NSPLIT, Epi, 0>(g, e, s, true);  // one tile per workgroup: the same kernel without its tile loop
-      case 17: return launch_abl<NSPLIT, Epi, 1>(g, e, s, true);
       default: return hipErrorNotSupported;
     }
   } else if (abl != 0) {

@@ -289,6 +289,22 @@ def cross_fade_concat(waves: Sequence[np.ndarray], fade_seconds: float, sr: int 
 
 
 # ---- inference ----------------------------------------------------------------------------------------------------------------
+def total_frames(prompt_frames: int, prompt_bytes: int, chunk: str, speed: float, fix_duration: Optional[float]) -> int:
+    """Length of prompt + generation in mel frames (reference utils_infer.py:487-496): a fixed total when `fix_duration` is given, otherwise
+    the prompt's frames-per-byte rate applied to the chunk's UTF-8 length and divided by the speed — which drops to 0.3 for chunks under
+    10 bytes so that very short texts are not rushed."""
+    if fix_duration is not None:
+        return int(fix_duration * target_sample_rate / hop_length)
+    chunk_bytes = len(chunk.encode("utf-8"))
+    pace = 0.3 if chunk_bytes < 10 else speed
+    return prompt_frames + int(prompt_frames / prompt_bytes * chunk_bytes / pace)
+
+
+# mel -> waveform per mel_spec_type (reference utils_infer.py:510-513): Vocos exposes .decode, a BigVGAN generator is called directly
+# (F5HipBigVGAN from load_vocoder("bigvgan"), or any caller-supplied generator)
+_VOCODERS = {"vocos": lambda voc, mel: voc.decode(mel), "bigvgan": lambda voc, mel: voc(mel)}
+
+
 def infer_batch_process(ref_audio, ref_text: str, gen_text_batches: Sequence[str], model_obj, vocoder, mel_spec_type: str = "vocos",
                         progress=None, target_rms: float = target_rms, cross_fade_duration: float = cross_fade_duration,
                         nfe_step: int = nfe_step, cfg_strength: float = cfg_strength, sway_sampling_coef: Optional[float] = sway_sampling_coef,
@@ -312,38 +328,34 @@ def infer_batch_process(ref_audio, ref_text: str, gen_text_batches: Sequence[str
     if len(ref_text[-1].encode("utf-8")) == 1:
         ref_text = ref_text + " "
 
-    def _infer_basic(gen_text: str):
-        local_speed = 0.3 if len(gen_text.encode("utf-8")) < 10 else speed
-        final_text_list = convert_char_to_pinyin([ref_text + gen_text])
-        ref_audio_len = audio.shape[-1] // hop_length
-        if fix_duration is not None:
-            duration = int(fix_duration * target_sample_rate / hop_length)
-        else:
-            ref_text_len, gen_text_len = len(ref_text.encode("utf-8")), len(gen_text.encode("utf-8"))
-            duration = ref_audio_len + int(ref_audio_len / ref_text_len * gen_text_len / local_speed)
-        generated, _ = model_obj.sample(cond=audio, text=final_text_list, duration=duration, steps=nfe_step, cfg_strength=cfg_strength,
-                                        sway_sampling_coef=sway_sampling_coef, seed=seed)
-        generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)
-        if mel_spec_type == "vocos":
-            wave_out = vocoder.decode(generated)
-        elif mel_spec_type == "bigvgan":  # F5HipBigVGAN (load_vocoder("bigvgan")) or any caller-supplied generator (utils_infer.py:512-513)
-            wave_out = vocoder(generated)
-        else:
-            raise ValueError("mel_spec_type must be vocos or bigvgan")
-        if rms < target_rms:
-            wave_out = wave_out * rms / target_rms
-        return wave_out.squeeze().cpu().numpy(), generated
+    prompt_frames = audio.shape[-1] // hop_length
+    prompt_bytes = len(ref_text.encode("utf-8"))
+    quiet_prompt = bool(rms < target_rms)  # the prompt was amplified to target_rms above: the output is brought back to its level
+    vocode = _VOCODERS.get(mel_spec_type)
+    if vocode is None:
+        raise ValueError("mel_spec_type must be vocos or bigvgan")
+
+    def synthesize(chunk: str):
+        """One text chunk -> (waveform as numpy, generated mel [1, n_mel, frames]) — the body of the reference's `process_batch`."""
+        total = total_frames(prompt_frames, prompt_bytes, chunk, speed, fix_duration)
+        mel, _ = model_obj.sample(cond=audio, text=convert_char_to_pinyin([ref_text + chunk]), duration=total, steps=nfe_step,
+                                  cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, seed=seed)
+        gen = mel.to(torch.float32)[:, prompt_frames:, :].permute(0, 2, 1)  # drop the prompt, channels first for the vocoder
+        wave = vocode(vocoder, gen)
+        if quiet_prompt:
+            wave = wave * rms / target_rms
+        return wave.squeeze().cpu().numpy(), gen
 
     seq = progress.tqdm(gen_text_batches) if progress is not None else gen_text_batches
     if streaming:
         for gen_text in seq:
-            w, _ = _infer_basic(gen_text)
+            w, _ = synthesize(gen_text)
             for j in range(0, len(w), chunk_size):
                 yield w[j:j + chunk_size], target_sample_rate
         return
     waves, specs = [], []
     with ThreadPoolExecutor() as ex:  # the context serialises its entry points; the pool only overlaps host work
-        futures = [ex.submit(_infer_basic, g) for g in gen_text_batches]
+        futures = [ex.submit(synthesize, g) for g in gen_text_batches]
         for fut in (progress.tqdm(futures) if progress is not None else futures):
             w, spec = fut.result()
             waves.append(w)

@@ -67,12 +67,6 @@ def test_pp_variant_equals_generic_kernel_fp16(emu_engine, capfd, variant, M, N,
 # Two groups of four waves half a phase apart, the LDS refilled by quarters two phases behind the reads: on the shim (LDS-DMA synchronous,
 # fibers switched at barriers) a quarter refilled a phase too early, a fragment read from the wrong buffer or a quadrant paired with the
 # wrong weight tile all show as differing bytes.  K = 256 .. 640: two pairs of k-tiles (one steady body + the last-pair body), three, and five pairs.
-# The launch is persistent (one workgroup per CU walks several tiles): F5HIP_P8_WGS = 3 (read at the first launch of each instantiation) makes
-# these 4- and 9-tile launches walk 1-3 tiles per workgroup — tile boundaries (the next tile's operands requested through its own descriptors
-# by the last pair of k-tiles, the epilogue between two tiles, group 1's barrier behind it) and a workgroup's last tile (empty successor).
-os.environ.setdefault("F5HIP_P8_WGS", "3")
-
-
 @pytest.mark.parametrize("M,N,K", [(300, 288, 256), (300, 288, 384), (520, 544, 640)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_p8_equals_generic_kernel_fp16(emu_engine, capfd, M, N, K, epi):  # noqa: F811

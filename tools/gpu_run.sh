@@ -106,44 +106,6 @@ PY
     F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 3 --warmup 1 --batch 8 $Q > $out/b8_v$v.json 2>> $out/bench.err; line $out/b8_v$v.json b8_variant$v
   done
   tail -3 $out/bench.err ;;
-p8b)
-  # round 5, second call: where the ping-pong kernel's LDS-DMA pieces are issued (tile ids 81 / 82), s_setprio off (84 / 86), what the epilogue
-  # costs without its stores (2080) and without GELU (epilogue 0), and first-round start staggers (F5HIP_P8_STAGGER = classes,ticks of 10 ns)
-  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-  { for prec in fp16 fp16m; do KB_CHECK=1 KB_SHAPES="5000,2048,1024" KB_PRECS=$prec KB_EPI=1 KB_VARIANTS=80,81,82,86 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | grep -v "rep [12]" | head -8; done; } > $out/check.log 2>&1
-  cat $out/check.log | cut -c1-250
-  SH="22496,2048,1024;89984,2048,1024;89984,1024,2048"
-  { for prec in fp16 fp16m; do
-      KB_SHAPES=$SH KB_PRECS=$prec KB_EPI=1 KB_VARIANTS=50,80,81,82,84,86,1080,11080,12080,2080 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi1 /" | cut -c1-500
-      KB_SHAPES=$SH KB_PRECS=$prec KB_EPI=0 KB_VARIANTS=50,80 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi0 /" | cut -c1-400
-    done
-    for stg in "0,0" "2,1500" "4,800" "4,1200" "8,500" "16,250"; do for prec in fp16 fp16m; do for epi in 1 2; do
-      F5HIP_P8_STAGGER=$stg KB_SHAPES="89984,2048,1024" KB_PRECS=$prec KB_EPI=$epi KB_VARIANTS=80 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/stagger $stg epi$epi /" | cut -c1-200
-    done; done; done; } > $out/kernel_bench.log 2>&1
-  cat $out/kernel_bench.log | cut -c1-420 ;;
-p8c)
-  # round 5, third call: the persistent tile loop of the ping-pong kernel (80) against the same kernel with one tile per workgroup (16080),
-  # the lockstep tile (50) and the heuristic; value checks at 704 tiles (2.75 tiles per workgroup); step A/B at B = 32 / 8 / 4
-  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-  { for epi in 0 1 2; do KB_CHECK=1 KB_SHAPES="22496,2048,1024;20000,1024,2048" KB_PRECS=fp16 KB_EPI=$epi KB_VARIANTS=80 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | head -8; done
-    for epi in 1 2; do KB_CHECK=1 KB_SHAPES="22496,2048,1024;20000,1024,2048" KB_PRECS=fp16m KB_EPI=$epi KB_VARIANTS=80 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | head -8; done
-    for prec in fp16 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec 32 1406 80 5 2>&1 | grep -E "^qkv|QKV_CHECK" | tail -2; done; } > $out/check.log 2>&1
-  cat $out/check.log | cut -c1-250
-  BIG="11248,2048,1024;22496,2048,1024;44992,2048,1024;89984,2048,1024;89984,1024,2048;89984,3072,1024;89984,1024,1024"
-  { for rep in 1 2; do for prec in fp16 fp16m; do
-      KB_SHAPES=$BIG KB_PRECS=$prec KB_EPI=1 KB_VARIANTS=-1,50,80,16080,1080,17080 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi1 /" | cut -c1-400
-      KB_SHAPES=$BIG KB_PRECS=$prec KB_EPI=2 KB_VARIANTS=-1,50,80 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi2 /" | cut -c1-400
-    done; done
-    for sq in "8 1406" "32 1406" "64 1406"; do for prec in fp16 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec $sq -1,50,80 10 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done; done; } > $out/kernel_bench.log 2>&1
-  cat $out/kernel_bench.log | cut -c1-330
-  Q="--no-cpu-baseline --no-other-configs"
-  for v in -1 80 -1 80; do
-    F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/b32_v$v.json 2>> $out/bench.err; line $out/b32_v$v.json b32_nfe32_variant$v
-  done
-  for b in 8 4; do for v in -1 80; do
-    F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 3 --warmup 1 --batch $b $Q > $out/b${b}_v$v.json 2>> $out/bench.err; line $out/b${b}_v$v.json b${b}_variant$v
-  done; done
-  tail -3 $out/bench.err ;;
 mx)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
   timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs2 or configs4 or packed_rows or ping_pong" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m.log; tail -25 $out/gpu_tests_fp16m.log
