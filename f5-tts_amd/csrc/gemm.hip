@@ -13,11 +13,6 @@ template <int NSPLIT, typename Epi>
 hipError_t launch_p8(const GemmCore& g, const Epi& e, int abl, hipStream_t s);
 bool p8_applies(int nsplit, const GemmCore& g);
 hipError_t init_p8_kernels();
-// gemm_p8s.hip: the ping-pong form of the one-round k-step-split tiles (ids 90 .. 94; gemm_p8s.h)
-template <int NSPLIT, typename Epi>
-hipError_t launch_p8s(const GemmCore& g, const Epi& e, int tile, int abl, hipStream_t s);
-bool p8s_applies(int nsplit, const GemmCore& g);
-hipError_t init_p8s_kernels();
 
 namespace {
 
@@ -250,10 +245,6 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
     if constexpr (NSPLIT == 1 || NSPLIT == 2) return launch_p8<NSPLIT, Epi>(g, e, 0, s);
     else return PP_NOT_APPLICABLE;
   }
-  if (variant >= 90 && variant <= 94) {  // its one-round form (gemm_p8s.h)
-    if constexpr (NSPLIT == 1 || NSPLIT == 2) return launch_p8s<NSPLIT, Epi>(g, e, variant, 0, s);
-    else return PP_NOT_APPLICABLE;
-  }
   if constexpr (NSPLIT == 4) {
     switch (variant) {
 #define F5_CASE(ID) case ID: return launch_pp_one<4, ID, Epi>(g, e, s);
@@ -398,8 +389,6 @@ hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int var
     }
     if constexpr (NSPLIT == 1 || NSPLIT == 2) {  // ablations of the ping-pong kernel: 1000 * code + 80 (code 1 no epilogue, 4 no LDS-DMA, 8 no MFMAs, 9 neither epilogue nor MFMAs)
       if (variant >= 1000 && variant % 1000 == 80 && e.act == ACT_GELU_TANH) return launch_p8<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant / 1000, s);
-      if (variant >= 1000 && variant % 1000 >= 90 && variant % 1000 <= 94 && e.act == ACT_GELU_TANH)
-        return launch_p8s<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant % 1000, variant / 1000, s);
     }
     if (e.act == ACT_GELU_TANH) return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_GELU_TANH>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
     return launch_pp<NSPLIT>(g, PpEpiAct16<FMT, ACT_NONE>{e.bias, e.out16, ld, g.M, g.N}, variant, s);
@@ -460,7 +449,7 @@ hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int b
 // engine asks here before it chooses MX lines for a call and runs the call in fp16x3 otherwise (f5hip_sample)
 bool gemm_mx_tiles_usable() {
   auto mx_tile = [](int id) {
-    if (id == 80 || (id >= 90 && id <= 94)) return true;
+    if (id == 80) return true;
 #define F5_IS(ID) if (id == ID) return true;
     F5_MX_TILES(F5_IS)
 #undef F5_IS
@@ -581,7 +570,7 @@ hipError_t init_gemm_kernels() {
 #ifndef F5_HIPEMU
   if ((e = set_glds_attrs<EpiStore>()) != hipSuccess || (e = set_glds_attrs<EpiQKV>()) != hipSuccess || (e = set_glds_attrs<EpiQKVFast>()) != hipSuccess) return e;
 #endif
-  if ((e = init_p8_kernels()) != hipSuccess || (e = init_p8s_kernels()) != hipSuccess) return e;
+  if ((e = init_p8_kernels()) != hipSuccess) return e;
   e = set_pp_attrs<1>();
   if (e != hipSuccess) return e;
   e = set_pp_attrs<2>();

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 OUT = os.path.join(ROOT, "tests", "c_abi", "_build", "engine_emu")
 LIB = os.path.join(OUT, "libf5hip_engine_emu.so")
-SOURCES = ("gemm.hip", "gemm_p8.hip", "gemm_p8s.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp", "microbench.cpp")
+SOURCES = ("gemm.hip", "gemm_p8.hip", "elementwise.hip", "convpos.hip", "attention.hip", "audio.hip", "api.cpp", "microbench.cpp")
 _running = []  # (Popen, object path) started by start_background()
 
 

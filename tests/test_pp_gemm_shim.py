@@ -99,45 +99,6 @@ def test_p8_qkv_epilogue(emu_engine, capfd, prec, K):  # noqa: F811
     assert diff == 0, err[-2000:]
 
 
-# ---- the one-round ping-pong tiles (csrc/gemm_p8s.h, ids 90 .. 94): k-step-split groups half a phase apart ---------------------------------
-# Two partial sums per output (the groups multiply alternate k-steps), so values to fp32 rounding — not bytes — against the generic kernel;
-# K from one pair of k-tiles past the ring (the prologue + the tail alone) to many; ragged rows / a channel count that is no tile multiple.
-P8S_CASES = [(90, 250, 224), (91, 250, 160), (92, 250, 96), (93, 250, 160), (94, 250, 96)]
-
-
-@pytest.mark.parametrize("variant,M,N", P8S_CASES)
-@pytest.mark.parametrize("epi,K", [(0, 384), (1, 512), (2, 1024)])
-def test_p8s_equals_generic_kernel_fp16(emu_engine, capfd, variant, M, N, epi, K):  # noqa: F811
-    for bad, nb, d, v in run(emu_engine, capfd, "fp16", variant, epi, M, N, K):
-        assert v > 0 and d <= (2e-3 if epi != 2 else 4e-6) * v, (bad, nb, d, v)  # (half-precision outputs: one fp16 ulp where a sum crosses a rounding boundary)
-
-
-@pytest.mark.parametrize("variant,M,N", P8S_CASES)
-@pytest.mark.parametrize("K", [192, 256, 704])
-def test_p8s_mx_lines_product_close_to_the_three_term_product(emu_engine, capfd, variant, M, N, K):  # noqa: F811
-    err = run_mx(emu_engine, capfd, variant, 2, M, N, K)
-    m = re.search(r"KB_CHECK fp16m variant \d+: max \|diff\| (\S+) mean (\S+) of max \|value\| (\S+)", err)
-    assert m, err
-    d, mean, v = (float(x) for x in m.groups())
-    assert v > 0 and 0 < d <= 1e-4 * v and mean <= 1e-5 * v, err
-
-
-@pytest.mark.parametrize("variant,M,N", [(90, 250, 224), (91, 250, 160)])
-def test_p8s_mx_output_rows_decode_to_the_fp16x3_rows(emu_engine, capfd, variant, M, N):  # noqa: F811
-    err = run_mx(emu_engine, capfd, variant, 1, M, N, 256)
-    m = re.search(r"KB_CHECK fp16m variant \d+ epi \d: (\d+) lines, (\d+) hi halves differ .* errors (\S+) / (\S+) block steps, (\d+) out of bounds", err)
-    assert m, err
-    lines, hidiff, ec, el, bad = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(5))
-    assert lines == M * N // 32 and bad == 0 and hidiff <= lines * 32 // 8 and 0 < ec <= 0.51 and 0 < el <= 1.5, err
-
-
-@pytest.mark.parametrize("variant", [90, 91, 92])
-@pytest.mark.parametrize("prec,K", [("fp16", 384), ("fp16m", 256)])
-def test_p8s_qkv_epilogue(emu_engine, capfd, variant, prec, K):  # noqa: F811
-    diff, err = run_qkv(emu_engine, capfd, prec, variant, 3, 150, K=K)
-    assert diff == 0, err[-2000:]
-
-
 # ---- fp16m: 2 fp16 MFMAs + 1 MX-fp6 MFMA per 32 k (common.h) ---------------------------------------------------------------------------
 # The correction terms are rounded to ~4 bits per factor, so the results are close to — not bytes of — the three-term product: the bound
 # is the scheme's own error (2^-16 per operand relative to the block maximum, summed over K), the check that it is non-zero shows the MX

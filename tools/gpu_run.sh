@@ -106,30 +106,6 @@ PY
     F5HIP_PP_VARIANT=$v timeout 900 python bench.py --steps 3 --warmup 1 --batch 8 $Q > $out/b8_v$v.json 2>> $out/bench.err; line $out/b8_v$v.json b8_variant$v
   done
   tail -3 $out/bench.err ;;
-p8s)
-  # round 5: the one-round ping-pong tiles (csrc/gemm_p8s.h, ids 90 .. 94) against the lockstep k-step-split tiles (68 / 69), the 4-wave 96x128
-  # (59) and its k-split (66): value checks on the GPU, times on the B = 1 shapes with ablations, B = 1 step A/B through the per-shape knobs
-  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-  B1="2812,3072,1024;2812,2048,1024;2812,1024,1024;2812,1024,2048"
-  { for prec in fp16 fp16m; do for epi in 1 2; do
-      KB_CHECK=1 KB_SHAPES="2812,2048,1024;2812,1024,2048" KB_PRECS=$prec KB_EPI=$epi KB_VARIANTS=90,91,92,93,94 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK|ERR" | grep -v "rep [12]" | head -12
-    done; done
-    for prec in fp16 fp16m; do timeout 300 python tools/kernel_bench.py qkv $prec 2 1406 90,91 5 2>&1 | grep -E "^qkv|QKV_CHECK" | awk 'NR%3==0 || /QKV_CHECK/'; done; } > $out/check.log 2>&1
-  cat $out/check.log | cut -c1-250
-  { for rep in 1 2; do for prec in fp16m fp16; do
-      KB_SHAPES=$B1 KB_PRECS=$prec KB_EPI=1 KB_VARIANTS=-1,68,69,59,90,91,92,93,94,1090,4090,8090,9090,1091,9091 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi1 /" | cut -c1-600
-      KB_SHAPES=$B1 KB_PRECS=$prec KB_EPI=2 KB_VARIANTS=-1,68,69,59,66,90,91,92,93,94 timeout 600 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi2 /" | cut -c1-500
-    done; done
-    for prec in fp16m fp16; do timeout 300 python tools/kernel_bench.py qkv $prec 2 1406 -1,68,56,90 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0'; done; } > $out/kernel_bench.log 2>&1
-  cat $out/kernel_bench.log | cut -c1-520
-  Q="--no-cpu-baseline --no-other-configs"
-  for i in 1 2; do
-    timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_base_$i.json 2>> $out/bench.err; line $out/b1_base_$i.json b1_base
-    F5HIP_PP_VARIANT_N3072=90 F5HIP_PP_VARIANT_N2048=91 timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_p8s_wide_$i.json 2>> $out/bench.err; line $out/b1_p8s_wide_$i.json b1_p8s_qkv_ff1
-    F5HIP_PP_VARIANT_N3072=90 F5HIP_PP_VARIANT_N2048=91 F5HIP_PP_VARIANT_N1024=92 timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_p8s_all_$i.json 2>> $out/bench.err; line $out/b1_p8s_all_$i.json b1_p8s_all
-    F5HIP_PP_VARIANT_N3072=90 F5HIP_PP_VARIANT_N2048=93 F5HIP_PP_VARIANT_N1024=94 timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_p8s_s4_$i.json 2>> $out/bench.err; line $out/b1_p8s_s4_$i.json b1_p8s_4stage
-  done
-  tail -3 $out/bench.err ;;
 mx)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
   timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs2 or configs4 or packed_rows or ping_pong" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m.log; tail -25 $out/gpu_tests_fp16m.log

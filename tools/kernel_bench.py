@@ -19,11 +19,7 @@ VARIANTS = {-1: "auto", 0: "64x128", 1: "128x64", 2: "128x128", 6: "glds128x64",
             61: "pp128x192s2", 62: "pp192x128s2", 63: "pp96x128s2", 64: "pp192x64s2",
             65: "pp192x128k2", 66: "pp96x128k2", 67: "pp192x64k2",
             68: "pp192x192ks", 69: "pp192x128ks", 70: "pp192x64ks", 80: "p8-256x256",
-            1080: "p8:noEpi", 4080: "p8:noDMA", 8080: "p8:noMFMA", 9080: "p8:noEpi+MFMA",
-            90: "p8s192x192", 91: "p8s192x128", 92: "p8s192x64", 93: "p8s192x128s4", 94: "p8s192x64s4"}
-for _id in (90, 91):
-    for _c, _n in ((1, "noEpi"), (4, "noDMA"), (8, "noMFMA"), (9, "noEpi+MFMA")):
-        VARIANTS[1000 * _c + _id] = f"{VARIANTS[_id]}:{_n}"
+            1080: "p8:noEpi", 4080: "p8:noDMA", 8080: "p8:noMFMA", 9080: "p8:noEpi+MFMA"}
 for _id in (50, 56, 59):
     for _c, _n in ((1, "noEpi"), (2, "noStore"), (3, "denseStore"), (4, "noDMA"), (8, "noMFMA"), (12, "noDMA+MFMA"), (13, "reads+barriers")):
         VARIANTS[1000 * _c + _id] = f"{VARIANTS[_id]}:{_n}"
