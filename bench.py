@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--schedule", default="default", choices=["default"], help="kept for command-line compatibility: there is one schedule")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default single-GPU run (BASELINE.json configs[1]) also times configs[2] (batch 32, NFE 32) and configs[4] (E2-TTS + BigVGAN, "
-                         "batch 8) in child processes and reports them in the line's `other_configs`; this switch leaves them out")
+                         "batch 8, and configs[3]'s per-GPU share: batch 32 at NFE 16) in child processes and reports them in the line's `other_configs`; this switch leaves them out")
     ap.add_argument("--tiny", action="store_true",
                     help="NOT a benchmark: the tiny model / Vocos at 120 frames (what smoke() runs), so that this file's own logic — self-launch, "
                          "rank protocol, JSON assembly — can be executed end to end, including on the CPU shim (tests/test_bench_on_shim.py)")
@@ -169,8 +169,11 @@ def cpu_baseline(cfg, sd, vsd, vcfg, wav, text, duration, nfe, t_gen, bigvgan=No
 
 def other_configs(a):
     """BASELINE.json's other single-GPU configurations, each in a child process of this file (its own context, memory and failure domain),
-    summarised for the headline line: configs[2] = batch 32, NFE 32; configs[4] = E2-TTS Base + BigVGAN, batch 8, NFE 16."""
+    summarised for the headline line: configs[2] = batch 32, NFE 32; configs[3]'s per-GPU share = batch 32 at NFE 16 (the 8-GPU line shards
+    256 utterances as 32 per rank with no collective inside a step, so one rank's step IS this workload); configs[4] = E2-TTS Base +
+    BigVGAN, batch 8, NFE 16."""
     runs = [("configs[2]", ["--batch", "32", "--nfe", "32", "--steps", "2", "--warmup", "1"]),
+            ("configs[3] per-GPU share (32 of 256 utterances)", ["--batch", "32", "--nfe", "16", "--steps", "2", "--warmup", "1"]),
             ("configs[4]", ["--model", "E2TTS_Base", "--vocoder", "bigvgan", "--batch", "8", "--nfe", "16", "--steps", "3", "--warmup", "1"])]
     out = []
     for name, args in runs:

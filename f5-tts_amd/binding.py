@@ -15,9 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "csrc", "libf5hip.so")
 BENCH_LIB_PATH = os.environ.get("F5HIP_BENCH_LIB") or os.path.join(_HERE, "csrc", "libf5hip_bench.so")
 
-ABI_VERSION = 8  # F5HIP_ABI_VERSION in include/f5hip.h
-PREC_FP32, PREC_FP16X3, PREC_FP16, PREC_FP16M, PREC_FP16M2 = 0, 1, 2, 3, 4
-PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16m": PREC_FP16M, "fp16m2": PREC_FP16M2}  # "fp16m2": microbenchmarks only (f5hip_sample rejects it; include/f5hip.h)
+ABI_VERSION = 9  # F5HIP_ABI_VERSION in include/f5hip.h
+PREC_FP32, PREC_FP16X3, PREC_FP16, PREC_FP16M = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16m": PREC_FP16M}
 
 
 class DitConfigC(C.Structure):

@@ -378,9 +378,9 @@ struct Stage {
 };
 
 // weight operand of a block GEMM in the given operand mode: fp32 blob rows, plain fp16 rows, or packed hi/lo rows
-WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f16* pk, const f16* mx = nullptr, const f16* m2 = nullptr) {
+WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f16* pk, const f16* mx = nullptr) {
   if (op == OP_F32) return WOp{w32, nullptr};
-  const void* w = op == OP_F16 ? (const void*)hi : op == OP_F16M ? (const void*)mx : op == OP_F16M2 ? (const void*)m2 : (const void*)pk;
+  const void* w = op == OP_F16 ? (const void*)hi : op == OP_F16M ? (const void*)mx : (const void*)pk;
   const auto it = ctx->walpha.find(w);
   return WOp{w, it == ctx->walpha.end() ? nullptr : it->second};
 }
@@ -419,13 +419,7 @@ int finalize_impl(f5hip_ctx* ctx) {
   // fp16m (fp16 + MX-fp6 correction lines, common.h): the four block GEMMs of the DiT / UNetT backbones when every one of them is a launch the
   // pipelined kernel takes (rows of whole 128-byte lines, at least a 3-stage ring of them) and the fused q|k|v epilogue applies
   ctx->mx_ok = ctx->mx_weights_opt && (c.backbone == 0 || c.backbone == 1) && c.dim_head == 64 && !c.qk_norm && !c.long_skip_connection && D / 32 >= 4 && inner / 32 >= 4 && F / 32 >= 4;
-  // fp16m2 rows (96 bytes per 32 k: the coarse values derived in the k-loop) for the one-round launches of a single utterance: 64-k tiles.
-  // OFF by default: measured 13-20 % slower per GEMM than the 128-byte lines, tile for tile (the conversions in the k-loop cost more than the
-  // bytes they save; profiles/r04h_*) — kept, like the ping-pong attention kernel, as the record of the experiment behind F5HIP_MX2=1
-  // (read here, per finalize: the weight copies in that form are only built when it is set).
-  const char* mx2_env = getenv("F5HIP_MX2");
-  ctx->mx2_ok = ctx->mx_ok && D % 64 == 0 && inner % 64 == 0 && F % 64 == 0 && D >= 192 && inner >= 192 && F >= 192 && mx2_env && mx2_env[0] == '1';
-  const int64_t mx_elems = (ctx->mx_ok ? per_block * c.depth * 2 : 0) + (ctx->mx2_ok ? per_block * c.depth * 3 / 2 : 0);
+  const int64_t mx_elems = ctx->mx_ok ? per_block * c.depth * 2 : 0;
   HIPCHK(ctx->half_pool.ensure((size_t)((per_block * c.depth + skip_elems + cstream_elems) * 3 + mx_elems) * sizeof(f16)));  // plain hi + packed hi/lo (+ MX lines)
   f16* hp = ctx->half_pool.as<f16>();
   // weight conditioning (GemmCore::w_alpha): rows of every half-precision weight copy, scale | alpha each
@@ -457,16 +451,14 @@ int finalize_impl(f5hip_ctx* ctx) {
       bw.qn = W(ctx, ba + "q_norm.weight");
       bw.kn = W(ctx, ba + "k_norm.weight");
     }
-    auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk, f16** mx = nullptr, f16** m2 = nullptr) -> hipError_t {
+    auto carve = [&](const float* src, int64_t rows, int64_t K, f16*& hi, f16*& pk, f16** mx = nullptr) -> hipError_t {
       hi = hp; hp += rows * K;
       pk = hp; hp += 2 * rows * K;
       if (mx) { *mx = hp; hp += 2 * rows * K; }
-      if (m2) { *m2 = hp; hp += rows * K * 3 / 2; }
       if (no_cond) {
         hipError_t e = launch_split_f16(src, rows * K, 1.0f, hi, nullptr, st);
         if (e != hipSuccess) return e;
         if (mx && (e = launch_pack_mx_rows(src, K, rows, (int)K, nullptr, *mx, 1, st)) != hipSuccess) return e;
-        if (m2 && (e = launch_pack_mx2_rows(src, K, rows, (int)K, nullptr, *m2, 1, st)) != hipSuccess) return e;
         return launch_split_f16_packed(src, rows, (int)K, pk, st);
       }
       float* scale = cp; cp += rows;
@@ -476,15 +468,13 @@ int finalize_impl(f5hip_ctx* ctx) {
       hipError_t e = launch_condition_weight(src, (int)rows, (int)K, scale, alpha, hi, pk, st);
       if (e != hipSuccess || !mx) return e;
       ctx->walpha[*mx] = alpha;  // the MX lines hold the same conditioned rows
-      if ((e = launch_pack_mx_rows(src, K, rows, (int)K, scale, *mx, 1, st)) != hipSuccess || !m2) return e;
-      ctx->walpha[*m2] = alpha;
-      return launch_pack_mx2_rows(src, K, rows, (int)K, scale, *m2, 1, st);
+      return launch_pack_mx_rows(src, K, rows, (int)K, scale, *mx, 1, st);
     };
-    const bool mxw = ctx->mx_ok, m2w = ctx->mx2_ok;
-    HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk, mxw ? &bw.wqkv_mx : nullptr, m2w ? &bw.wqkv_m2 : nullptr));
-    HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk, mxw ? &bw.wo_mx : nullptr, m2w ? &bw.wo_m2 : nullptr));
-    HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk, mxw ? &bw.w1_mx : nullptr, m2w ? &bw.w1_m2 : nullptr));
-    HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk, mxw ? &bw.w2_mx : nullptr, m2w ? &bw.w2_m2 : nullptr));
+    const bool mxw = ctx->mx_ok;
+    HIPCHK(carve(bw.wqkv, 3 * inner, D, bw.wqkv_hi, bw.wqkv_pk, mxw ? &bw.wqkv_mx : nullptr));
+    HIPCHK(carve(bw.wo, D, inner, bw.wo_hi, bw.wo_pk, mxw ? &bw.wo_mx : nullptr));
+    HIPCHK(carve(bw.w1, F, D, bw.w1_hi, bw.w1_pk, mxw ? &bw.w1_mx : nullptr));
+    HIPCHK(carve(bw.w2, D, F, bw.w2_hi, bw.w2_pk, mxw ? &bw.w2_mx : nullptr));
     if (bw.wskip) HIPCHK(carve(bw.wskip, D, 2 * D, bw.wskip_hi, bw.wskip_pk));
     if (mmdit) {  // text stream of the block (modules.py:791-814)
       const bool last = i == c.depth - 1;
@@ -966,14 +956,14 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     e.ldvt = (ns + 7) & ~7;
     const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
     e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-    if (split_qk(ctx, (op == OP_F16M || op == OP_F16M2) ? OP_F16X3 : op)) {  // lo planes only for what the flash kernel will read
+    if (split_qk(ctx, op == OP_F16M ? OP_F16X3 : op)) {  // lo planes only for what the flash kernel will read
       e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
       if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
     }
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk, bw.wqkv_mx, bw.wqkv_m2), ldA, M, 3 * inner, D));
+    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk, bw.wqkv_mx), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -999,10 +989,9 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const int pk = op == OP_F16X3 ? 1 : 0, wbytes = 2;
   const bool mx = ctx->mx_call;                     // fp16m: the four block GEMMs read MX lines (same row strides as the hi | lo lines)
-  const bool mx2 = mx && ctx->mx2_call;  // ... as 96-byte fp16m2 rows (one-round launches): the block operands have rows of 1.5 K halves
-  const int opb = mx2 ? OP_F16M2 : mx ? OP_F16M : op, pkb = mx2 ? 3 : mx ? 2 : pk;
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
-  const int64_t ldAb = mx2 ? (int64_t)D * 3 / 2 : ldA, ldOb = mx2 ? (int64_t)inner * 3 / 2 : ldO, ldFb = mx2 ? (int64_t)F * 3 / 2 : ldF;  // strides of the block operands
+  const int64_t ldAb = ldA, ldOb = ldO, ldFb = ldF;  // strides of the block operands (MX lines keep the hi | lo strides)
   f16* a_hi = ctx->a_hi.as<f16>() + p0 * ldA;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
   f16* o_all = ctx->o_hi.as<f16>();  // the attention writes row cu_rows[s] + q of the WHOLE packed order
@@ -1024,7 +1013,7 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
     CHK(run_attention(ctx, S, s0, n, op, false, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pkb, ldOb, st, nullptr, 0, cu));
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, inner), (double)Mp * inner * wbytes + (double)inner * D * wbytes + 2.0 * Mp * D * 4);
-      GemmCore g = core(o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx, bw.wo_m2), ldOb, Mp, D, inner);
+      GemmCore g = core(o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, Mp, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.res = x; e.ldres = D;  // every row is a valid row: no mask (modules.py:554-556 zeroes the padding only)
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1035,14 +1024,14 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, F, D), (double)Mp * D * wbytes + (double)F * D * wbytes + (double)Mp * F * wbytes);
-      GemmCore g = core(a_hi, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx, bw.w1_m2), ldAb, Mp, F, D);
+      GemmCore g = core(a_hi, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldAb, Mp, F, D);
       EpiStore e = epi_store(nullptr, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldFb;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, F), (double)Mp * F * wbytes + (double)F * D * wbytes + 2.0 * Mp * D * 4);
-      GemmCore g = core(f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx, bw.w2_m2), ldFb, Mp, D, F);
+      GemmCore g = core(f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldFb, Mp, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1126,10 +1115,9 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const int pk = op == OP_F16X3 ? 1 : 0;      // fp16x3 operands are packed hi/lo rows: lo plane = hi + 32 halves, row stride 2K
   const bool mx = ctx->mx_call;               // fp16m: the four block GEMMs read MX lines (same row strides as the hi | lo lines)
-  const bool mx2 = mx && ctx->mx2_call;  // ... as 96-byte fp16m2 rows (one-round launches): the block operands have rows of 1.5 K halves
-  const int opb = mx2 ? OP_F16M2 : mx ? OP_F16M : op, pkb = mx2 ? 3 : mx ? 2 : pk;
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t ldA = (int64_t)D * (pk ? 2 : 1), ldO = (int64_t)inner * (pk ? 2 : 1), ldF = (int64_t)F * (pk ? 2 : 1);
-  const int64_t ldAb = mx2 ? (int64_t)D * 3 / 2 : ldA, ldOb = mx2 ? (int64_t)inner * 3 / 2 : ldO, ldFb = mx2 ? (int64_t)F * 3 / 2 : ldF;  // strides of the block operands
+  const int64_t ldAb = ldA, ldOb = ldO, ldFb = ldF;  // strides of the block operands (MX lines keep the hi | lo strides)
   float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
   f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() + r0 * ldA : nullptr;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
@@ -1167,7 +1155,7 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx, bw.wo_m2), ldOb, M, D, inner));
+      GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, M, D, inner));
       EpiStore e = epi_store(x, D, bw.bo);
       e.colscale = md + 2 * D; e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1178,14 +1166,14 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     }
     {  // FeedForward: Linear -> tanh-GELU (modules.py:353-364,741)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), (double)M * D * wbytes + (double)F * D * wbytes + (double)M * F * wbytes);
-      GemmCore g = (core(A, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx, bw.w1_m2), ldAb, M, F, D));
+      GemmCore g = (core(A, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldAb, M, F, D));
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldFb;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {  // x += gate_mlp * ff (modules.py:755)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), (double)M * F * wbytes + (double)F * D * wbytes + 2.0 * M * D * 4);
-      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx, bw.w2_m2), ldFb, M, D, F));
+      GemmCore g = (core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldFb, M, D, F));
       EpiStore e = epi_store(x, D, bw.b2);
       e.colscale = md + 5 * D; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1238,11 +1226,10 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
   const int wbytes = op == OP_F32 ? 4 : 2;
   const int pk = op == OP_F16X3 ? 1 : 0;
   const bool mx = ctx->mx_call;  // fp16m: q|k|v, out, FF1, FF2 read MX lines (same row strides); the skip projection and proj_out stay fp16x3
-  const bool mx2 = mx && ctx->mx2_call;  // ... as 96-byte fp16m2 rows (one-round launches): the block operands have rows of 1.5 K halves
-  const int opb = mx2 ? OP_F16M2 : mx ? OP_F16M : op, pkb = mx2 ? 3 : mx ? 2 : pk;
+  const int opb = mx ? OP_F16M : op, pkb = mx ? 2 : pk;
   const int64_t pl = pk ? 2 : 1;
   const int64_t ldA = D * pl, ldO = inner * pl, ldF = F * pl, ldC = 2 * D * pl;  // operand row strides (elements)
-  const int64_t ldAb = mx2 ? (int64_t)D * 3 / 2 : ldA, ldOb = mx2 ? (int64_t)inner * 3 / 2 : ldO, ldFb = mx2 ? (int64_t)F * 3 / 2 : ldF;  // strides of the block operands
+  const int64_t ldAb = ldA, ldOb = ldO, ldFb = ldF;  // strides of the block operands (MX lines keep the hi | lo strides)
   float* a32 = op == OP_F32 ? ctx->a32.as<float>() + r0 * D : nullptr;
   f16* a_hi = op != OP_F32 ? ctx->a_hi.as<f16>() + r0 * ldA : nullptr;
   f16* a_lo = pk ? a_hi + 32 : nullptr;
@@ -1315,7 +1302,7 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx, bw.wo_m2), ldOb, M, D, inner);
+      GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, M, D, inner);
       EpiStore e = epi_store(x, D, bw.bo);
       e.rowmask = rowvalid; e.mask_mode = 1; e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1326,14 +1313,14 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     }
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, F, D), 0);
-      GemmCore g = core(A, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx, bw.w1_m2), ldAb, M, F, D);
+      GemmCore g = core(A, ldAb, wsel(ctx, opb, bw.w1, bw.w1_hi, bw.w1_pk, bw.w1_mx), ldAb, M, F, D);
       EpiStore e = epi_store(f32, F, bw.b1, ACT_GELU_TANH);
       e.out16 = f_hi; e.out16_lo = f_lo; e.pk16 = pkb; e.ldo16 = ldFb;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
     }
     {  // x = ff(...) + x (unett.py:301)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, F), 0);
-      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx, bw.w2_m2), ldFb, M, D, F);
+      GemmCore g = core(op == OP_F32 ? (const void*)f32 : (const void*)f_hi, ldFb, wsel(ctx, opb, bw.w2, bw.w2_hi, bw.w2_pk, bw.w2_mx), ldFb, M, D, F);
       EpiStore e = epi_store(x, D, bw.b2);
       e.res = x; e.ldres = D;
       HIPCHK(launch_gemm_store(opb, g, e, 1, st));
@@ -1848,8 +1835,6 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   // instantiation or the general q|k|v index path take the launches away from it: gemm_mx_tiles_usable)
   ctx->mx_call = precision == F5HIP_PREC_FP16M && ctx->mx_ok && !exact_attn && ctx->attn_kv_split <= 1 && n >= 8 && gemm_mx_tiles_usable() &&
                  (2 * (BN + B) + 512) * 4 * std::max<int64_t>(std::max<int64_t>(D, c.ff_inner), (int64_t)c.heads * c.dim_head) < (int64_t)0x7ff00000;
-  // ... as fp16m2 rows where every block GEMM of the call is a one-round launch (the tiles instantiated for that form: < 4096 rows)
-  ctx->mx2_call = ctx->mx_call && ctx->mx2_ok && 2 * (BN + B) < 4096;
 
   // cfg_strength < 1e-5: the reference evaluates only the conditional branch (cfm.py:166-177); otherwise cond + uncond rows are packed
   const int nb = cfg_strength < 1e-5f ? 1 : 2;

@@ -24,12 +24,11 @@ namespace {
 template <int NSPLIT, int PVSPLIT>
 hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   constexpr int lds = flash_lds_bytes<NSPLIT, PVSPLIT>();
-  static const int nw_env = [] { const char* v = getenv("F5HIP_ATTN_WAVES"); return v ? atoi(v) : 0; }();  // tuning knob: 4 or 6
   const int nqb6 = (a.n + 191) / 192, nqb4 = (a.n + QB - 1) / QB;
   // 192-row blocks when they (times the `co` identical launches that run concurrently: the cond / uncond chains) fit the chip in one
   // round of one workgroup per CU and the 128-row blocks neither fit one round nor fill two per CU
   const int e4 = bh * co * nqb4, e6 = bh * co * nqb6;
-  const bool six = nw_env ? nw_env == 6 : (e6 <= 256 && e4 > 256 && e4 < 512);
+  const bool six = e6 <= 256 && e4 > 256 && e4 < 512;
   if (a.kv_split > 1) {  // key-split variant: kv_split workgroups per query block + the merge (attention_kernel.h)
     if (!a.part_o || !a.part_ml || a.kv_split > 8) return hipErrorInvalidValue;
     a.nqb = nqb4; a.nwg = bh * nqb4 * a.kv_split;
@@ -40,51 +39,18 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
   }
   // Row sums of P: on the matrix pipe (a V^T fragment of ones, attention_kernel.h) where the kernel is VALU-bound — many workgroups per
   // CU: -9 % at B' = 16, -4 % at B' = 64, -6 % at n = 3000 — and on the VALU for the one-round 192-row launch of a single utterance, which is
-  // latency-bound and pays +3 % for the extra dependent MFMAs at the end of a tile (tools/r2_call30.sh).  F5HIP_ATTN_VALU_SUM=1 / 0 forces.
-  static const int vsum_env = [] { const char* v = getenv("F5HIP_ATTN_VALU_SUM"); return v ? atoi(v) : -1; }();
-  const bool vsum = vsum_env >= 0 ? vsum_env == 1 : six;
-  // lazy reference maximum (attention_kernel.h LAZY): whenever q carries log2(e); F5HIP_ATTN_LAZY=0 keeps the exact running maximum (A/B)
-  static const bool lazy_off = [] { const char* v = getenv("F5HIP_ATTN_LAZY"); return v && atoi(v) == 0; }();
-  const bool lazy = a.log2q && !lazy_off;
+  // latency-bound and pays +3 % for the extra dependent MFMAs at the end of a tile (profiles/r02h_attn_rowsum_ab.log).
+  const bool vsum = six;
+  // lazy reference maximum (attention_kernel.h LAZY): whenever q carries log2(e) (profiles/r03e_attn_lazy_ab.log)
+  const bool lazy = a.log2q != 0;
   // software-pipelined form of the plain-fp16 lazy configuration (attention_kernel.h flash_pipe_kernel) for the one-round 192-row launch,
   // where SIMDs hold one or two waves and a wave's own phases are all the overlap there is: 32.8 -> 31.8 us at B' = 2 (12.8 against 13.4 ms
   // per B = 1 sample); with two workgroups per CU it ties or loses (B' = 16: 197.9 against 192.0 us, B' = 64: 829 against 825), so the
-  // 128-row launches keep the phase-by-phase kernel.  F5HIP_ATTN_PIPE=0 / 1: never / also for the 128-row blocks (A/B).
-  static const int pipe_env = [] { const char* v = getenv("F5HIP_ATTN_PIPE"); return v ? atoi(v) : -1; }();
-  // ping-pong form (attention_kernel.h flash_pp_kernel): 8 waves, 256 query rows, the two halves one phase apart.  OFF by default (it measured
-  // 9 % slower); F5HIP_ATTN_PP=1 turns it on (A/B runs, tests/test_gpu_parity.py::test_ping_pong_attention_kernel_opt_in)
-  static const bool pp_off = [] { const char* v = getenv("F5HIP_ATTN_PP"); return !v || atoi(v) == 0; }();
+  // 128-row launches keep the phase-by-phase kernel (profiles/r03j_attn_pipe_ab.log).
   if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
-    if (lazy && !pp_off) {
-      static const int prio = [] { const char* v = getenv("F5HIP_ATTN_PP_PRIO"); return v ? atoi(v) : 1; }();
-      a.pp_prio = prio;
-      a.nqb = (a.n + 255) / 256; a.nwg = bh * a.nqb;
-      static const int pabl = [] { const char* v = getenv("F5HIP_ATTN_PP_ABLATE"); return v ? atoi(v) : 0; }();  // microbenchmark only
-      if (pabl == 1) hipLaunchKernelGGL(flash_pp_kernel<1>, dim3(a.nwg), dim3(512), lds, s, a);
-      else if (pabl == 2) hipLaunchKernelGGL(flash_pp_kernel<2>, dim3(a.nwg), dim3(512), lds, s, a);
-      else if (pabl == 3) hipLaunchKernelGGL(flash_pp_kernel<3>, dim3(a.nwg), dim3(512), lds, s, a);
-      else if (pabl == 4) hipLaunchKernelGGL(flash_pp_kernel<4>, dim3(a.nwg), dim3(512), lds, s, a);
-      else if (pabl == 5) hipLaunchKernelGGL(flash_pp_kernel<5>, dim3(a.nwg), dim3(512), lds, s, a);
-      else hipLaunchKernelGGL(flash_pp_kernel<0>, dim3(a.nwg), dim3(512), lds, s, a);
-      return hipGetLastError();
-    }
-  }
-  if constexpr (NSPLIT == 1 && PVSPLIT == 1) {
-    static const int abl = [] { const char* v = getenv("F5HIP_ATTN_ABLATE"); return v ? atoi(v) : 0; }();  // microbenchmark only (garbage results)
-    if (lazy && abl >= 1 && abl <= 7) {  // (the 128-row form, whatever the launch shape)
-      a.nqb = nqb4; a.nwg = bh * a.nqb;
-      static_for<7>([&](auto I) {
-        constexpr int A = decltype(I)::value + 1;
-        if (abl == A) hipLaunchKernelGGL((flash_pipe_kernel<4, false, A>), dim3(a.nwg), dim3(256), lds, s, a);
-      });
-      return hipGetLastError();
-    }
-    if (lazy && pipe_env != 0 && (six || pipe_env == 1)) {
-      a.nqb = six ? nqb6 : nqb4; a.nwg = bh * a.nqb;
-      if (six) { if (vsum) hipLaunchKernelGGL((flash_pipe_kernel<6, true>), dim3(a.nwg), dim3(384), lds, s, a);
-                 else hipLaunchKernelGGL((flash_pipe_kernel<6, false>), dim3(a.nwg), dim3(384), lds, s, a); }
-      else { if (vsum) hipLaunchKernelGGL((flash_pipe_kernel<4, true>), dim3(a.nwg), dim3(256), lds, s, a);
-             else hipLaunchKernelGGL((flash_pipe_kernel<4, false>), dim3(a.nwg), dim3(256), lds, s, a); }
+    if (lazy && six) {
+      a.nqb = nqb6; a.nwg = bh * a.nqb;
+      hipLaunchKernelGGL((flash_pipe_kernel<6, true>), dim3(a.nwg), dim3(384), lds, s, a);  // (row sums on the VALU: vsum == six)
       return hipGetLastError();
     }
   }
@@ -134,10 +100,7 @@ hipError_t set_attr_pipe() {
 
 hipError_t init_attention_kernels() {
   hipError_t e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(flash_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, flash_lds_bytes<1, 1>())) != hipSuccess) return e;
-  if ((e = set_attr_pipe<4, false>()) != hipSuccess || (e = set_attr_pipe<4, true>()) != hipSuccess || (e = set_attr_pipe<6, false>()) != hipSuccess ||
-      (e = set_attr_pipe<6, true>()) != hipSuccess)
-    return e;
+  if ((e = set_attr_pipe<6, true>()) != hipSuccess) return e;
   if ((e = set_attr<1, 1>()) != hipSuccess) return e;
   if ((e = set_attr<3, 1>()) != hipSuccess) return e;
   return set_attr<3, 3>();

@@ -35,7 +35,6 @@ struct FlashArgs {
   // Packed rows (engine option "packed_rows", with kvlen): the output row of query q of sequence b' is cu_rows[b'] + q instead of
   // b' * n + q, queries >= kvlen[b'] do not exist (their blocks exit at once) — the reference's varlen path, modules.py:522-543.
   const int32_t* cu_rows;
-  int pp_prio;  // flash_pp_kernel: raise the wave priority during the softmax phase (A/B switch F5HIP_ATTN_PP_PRIO, default on)
 };
 
 // Scores of keys that do not exist (>= kv_end) or lie in the masked hole [hole_lo, hole_hi) -> -inf, for the tile of keys t KT .. t KT + 63:
@@ -60,25 +59,6 @@ __device__ __forceinline__ void flash_mask_tile(f32x16 (&s)[2], int t, int hi, i
 // o[db][4 c + e].  o_packed 0: plain fp16 rows, 1: packed hi | lo lines (fp16x3), 2: MX lines (fp16m, common.h) — the lane's 16 features of
 // a 32-block are exactly the k-set of P_hi, so the pack needs no lane exchange.
 __device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16 (&o)[2], float inv, int64_t row, int hh, int hi, bool live) {
-  if (a.o_packed == 3) {  // fp16m2 rows [inner hi halves | units]: the lane pair (l, l ^ 32) trades halves first (whole waves: `live` only gates the stores)
-    char* orow3 = reinterpret_cast<char*>(a.o) + row * ((int64_t)a.heads * 64 * 3);
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      float x[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) x[t] = o[db][t] * inv;
-      mx2_unit_order(x);
-      uint32_t hv[8], xw[4];
-      mx2_pack16<false>(x, hv, xw);
-      if (live) {
-        char* hp = orow3 + (hh * 64 + 32 * db + 8 * hi) * 2;
-        *reinterpret_cast<uint4*>(hp) = make_uint4(hv[0], hv[1], hv[2], hv[3]);
-        *reinterpret_cast<uint4*>(hp + 32) = make_uint4(hv[4], hv[5], hv[6], hv[7]);
-        *reinterpret_cast<uint4*>(orow3 + (int64_t)a.heads * 128 + (hh * 2 + db) * 32 + 16 * hi) = make_uint4(xw[0], xw[1], xw[2], xw[3]);
-      }
-    }
-    return;
-  }
   const int64_t orow = row * ((int64_t)a.heads * 64 * (a.o_packed ? 2 : 1));
   if (a.o_packed == 2) {  // MX lines: the P word is the lane's own; the hi halves trade quads with the partner lane (l ^ 32) for 16-byte stores (whole waves)
 #pragma unroll
@@ -659,235 +639,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_pipe_kernel(Fl
 
   const float l_tot = VSUM ? l_run + __shfl_xor(l_run, 32, 64) : l_run;
   flash_store_row(a, o, 1.0f / l_tot, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi, qrow < q_end);
-}
-
-// Ping-pong form (round 3) of the production configuration (plain fp16 q, k, P, V; base-2 scores; lazy reference maximum; unsplit keys; row
-// sums on the matrix pipe).  What the ablations of flash_pipe_kernel showed (profiles/r03j_attn_ablate.log): with two independent 4-wave
-// workgroups per CU the parts of a tile ADD — 20 MFMAs cost their full 30-42 cycles each, the K / V traffic + barriers 20 %, the softmax
-// VALU 10 % — because the two waves of a SIMD run the same code in step and meet on the same pipe in every phase.  Here ONE workgroup of
-// 8 waves owns 256 query rows: waves w and w + 4 share a SIMD, and the two halves run the same per-tile sequence one PHASE apart, a
-// workgroup barrier between phases:
-//     phase 2t      half 0: S(t)   softmax VALU of tile t               half 1: M(t-1)
-//     phase 2t + 1  half 0: M(t)   20 MFMAs: row sums, scores of t+1, PV of t   half 1: S(t)
-// so a SIMD's matrix pipe always has exactly one wave feeding it while the other does its exponentials, its share of the next K / V^T
-// tile's LDS stores and the global loads of the tile after.  K / V^T traffic per query row halves (both halves read the same tiles).
-// Ring slot j & 1 holds bundle j = (K tile j + 1, V^T tile j), read in phases 2j + 1 (half 0) and 2j + 2 (half 1); half 1 writes its half of
-// bundle j in phase 2j - 1, half 0 in phase 2j — neither phase reads that slot (its previous bundle j - 2 was last read in phase 2j - 2).
-// ABL (microbenchmark only, garbage results): 1 no softmax VALU (max, reference check, exponentials), 2 no MFMAs, 3 no K / V traffic (global
-// loads, LDS stores), 4 no fragment reads (register operands), 5 = 1 + 3 (the softmax phase is empty).
-template <int ABL = 0>
-__global__ __launch_bounds__(512, 1) void flash_pp_kernel(FlashArgs a) {
-  constexpr int STAGE = K_PLANE + V_PLANE;
-  F5_DYN_LDS(char, smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = wave >> 2, hi = lane >> 5, ql = lane & 31;
-  const int bid = blockIdx.x;  // XCD-aware placement as flash_attn_kernel
-  const int q8 = a.nwg >> 3, r8 = a.nwg & 7, xcd = bid & 7, slot = bid >> 3;
-  const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-  const int bh = L / a.nqb, qb = L - bh * a.nqb;
-  const int bp = bh / a.heads, hh = bh - bp * a.heads;
-  const int n = a.n;
-  int kv_end = a.kvlen ? min(a.kvlen[bp], n) : n, hole_lo = 0, hole_hi = 0;
-  if (a.kvlen && a.kvlen2) {
-    hole_lo = kv_end;
-    hole_hi = min(a.seg2_off, n);
-    kv_end = min(a.seg2_off + a.kvlen2[bp], n);
-    if (hole_lo >= hole_hi) hole_lo = hole_hi = 0;
-  }
-  const int q_end = a.cu_rows ? (a.kvlen ? min(a.kvlen[bp], n) : n) : n;
-  if (qb * 256 >= q_end) return;  // (whole workgroup, before any barrier)
-  const int ntile = (kv_end + KT - 1) / KT;
-
-  const uint32_t k_bytes = (uint32_t)n * 128u, v_bytes = (uint32_t)(64 * a.ldv) * 2u;
-  const BufRsrc Kr = make_rsrc(a.k + (int64_t)bh * n * 64, k_bytes);
-  const BufRsrc Vr = make_rsrc(a.vt + (int64_t)bh * 64 * a.ldv, v_bytes);
-  const f16* Qp = a.q + (int64_t)bh * n * 64;
-  const int qrow = qb * 256 + wave * 32 + ql;
-  Frag fq[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    fq[ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
-
-  // this thread's 16-byte chunk of a K tile (key row tid >> 3) and of a V^T tile (feature row tid >> 3): 512 chunks each
-  const int crow = tid >> 3, ccol = tid & 7;
-  const uint32_t k_off = (uint32_t)(crow * 128 + ccol * 16), v_off = (uint32_t)(crow * a.ldv * 2 + ccol * 16);
-  uint4 rk[2], rv[2];  // two register sets: a bundle is loaded two tiles ahead of its LDS store
-  auto load_bundle = [&](int j, uint4& k4, uint4& v4) {  // K tile j + 1 and V^T tile j (j = -1: K tile 0 alone)
-    const uint32_t keyk = (uint32_t)(j + 1) * KT, keyv = (uint32_t)(j < 0 ? 0 : j) * KT;
-    const uint32_t vkey_off = keyv * 2 + (uint32_t)ccol * 16;
-    k4 = buffer_load_b128(Kr, k_off + keyk * 128);  // past the last key: zeros (descriptor bounds)
-    v4 = buffer_load_b128(Vr, (j >= 0 && vkey_off < (uint32_t)a.ldv * 2) ? v_off + keyv * 2 : OOB_OFF);
-  };
-  auto store_bundle = [&](int slot_, const uint4& k4, const uint4& v4) {
-    char* base = smem + slot_ * STAGE;
-    *reinterpret_cast<uint4*>(base + crow * K_ROWB + ccol * 16) = k4;
-    char* vd = base + K_PLANE + crow * V_ROWB + ccol * 16;
-    *reinterpret_cast<uint2*>(vd) = make_uint2(v4.x, v4.y);
-    *reinterpret_cast<uint2*>(vd + 8) = make_uint2(v4.z, v4.w);
-  };
-
-  f32x16 o[2], negm, sc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
-  float l_run = 0.f, alpha = 1.0f;
-  bool first = true;
-  Frag ones, fp[4];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
-  const uint32_t lds_k = fa::lds_addr(smem) + ql * K_ROWB + hi * 16, lds_v = fa::lds_addr(smem) + K_PLANE + ql * V_ROWB + hi * 8;
-
-  // S(t): this half's LDS stores of bundle t + half and the loads of bundle t + half + 2, then the softmax of tile t: sc -> fp (P as fp16)
-  auto softmax_phase = [&](int t, uint4& k4, uint4& v4) {
-    // VALU issue between the two waves of a SIMD goes by priority, then age, and a wave streaming MFMAs is always a candidate: without
-    // the raise the softmax of the younger half crawls beside the older half's matrix phase (tools/probes/mfma_pace_probe.hip: 18x)
-    if (a.pp_prio) __builtin_amdgcn_s_setprio(2);
-    const int b = t + half;
-    if (b >= 1 && ABL != 3 && ABL != 5) {
-      store_bundle(b & 1, k4, v4);
-      load_bundle(b + 2, k4, v4);
-    }
-    if constexpr (ABL == 1 || ABL == 5) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fp[i].f = (f32x4){sc[0][i], sc[0][4 + i], sc[1][i], sc[1][4 + i]};
-      first = false;
-      if (a.pp_prio) __builtin_amdgcn_s_setprio(0);
-      return;
-    }
-    if ((t + 1) * KT > kv_end || (t * KT < hole_hi && (t + 1) * KT > hole_lo)) {
-      flash_mask_tile(sc, t, hi, kv_end, hole_lo, hole_hi);
-    }
-    float mx = sc[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
-    alpha = 1.0f;
-    if (f5_wave_any(first || mx > LAZY_TAU)) {  // raise the reference (rare after the first tiles), as flash_attn_kernel's LAZY branch
-      const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
-      if (!first) {
-        alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sc[0][r] -= delta; sc[1][r] -= delta; negm[r] -= delta; }
-      first = false;
-    }
-#pragma unroll
-    for (int i = 0; i < 32; ++i) fp[i >> 3].h[i & 7] = (f16)__builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
-    if (a.pp_prio) __builtin_amdgcn_s_setprio(0);
-  };
-  // M(t): row sums of P_t, scores of tile t + 1 from the K plane of slot t & 1, O += V^T . P^T from its V^T plane — 20 MFMAs in a fixed
-  // order in which no two neighbours share an accumulator (a dependent MFMA right behind its producer is fine, one with a wait or a read
-  // in between stalls: MI355X_MICROARCH "one extra issue slot between two MFMAs on the same accumulator"), the two row-sum MFMAs that
-  // need no LDS operand first (they cover the first fragment reads).
-  auto mfma = [&](f32x16& acc, const Frag& x, const Frag& y) {
-    if constexpr (ABL == 2) acc[0] += x.f[0] * y.f[0];
-    else Mma32<f16>::mma(acc, x, y);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto matrix_phase = [&](int st) {
-    const uint32_t aK = lds_k + st * STAGE, aV0 = lds_v + st * STAGE, aV1 = aV0 + 32 * V_ROWB;
-    Frag fk[8], fv[4][2];
-    if constexpr (ABL == 4) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { fk[i] = fq[i & 3]; fv[i >> 1][i & 1] = fq[i & 3]; }
-    }
-    static_for<8>([&](auto I) {  // issue order = use order: (ks, kb) = (0,0) (0,1) (1,0) ...
-      constexpr int i = decltype(I)::value, kb = i & 1, ks = i >> 1;
-      if constexpr (ABL != 4) fa::read_b128<kb * 32 * K_ROWB + ks * 32>(fk[i], aK);
-    });
-    if constexpr (ABL != 4) {
-      fa::read_2b64<0>(fv[0][0], aV0);
-      fa::read_2b64<0>(fv[0][1], aV1);
-      fa::read_2b64<32>(fv[1][0], aV0);
-      fa::read_2b64<32>(fv[1][1], aV1);
-    }
-    f32x16 ra, rb;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ra[r] = 0.f; rb[r] = 0.f; }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma(ra, ones, fp[0]);
-    mfma(rb, ones, fp[1]);
-    if constexpr (ABL != 4) fa::landed_behind<4>(fk, ra, rb);  // the K fragments (older than the four V^T reads)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sc[0][r] = negm[r]; sc[1][r] = negm[r]; }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma(sc[0], fk[0], fq[0]);
-    mfma(sc[1], fk[1], fq[0]);
-    mfma(ra, ones, fp[2]);
-    mfma(sc[0], fk[2], fq[1]);
-    mfma(sc[1], fk[3], fq[1]);
-    mfma(rb, ones, fp[3]);
-    mfma(sc[0], fk[4], fq[2]);
-    mfma(sc[1], fk[5], fq[2]);
-    mfma(sc[0], fk[6], fq[3]);
-    mfma(sc[1], fk[7], fq[3]);
-    static_for<4>([&](auto G) {  // reads in flight: group g + 1's two (none behind the last group)
-      constexpr int g = decltype(G)::value;
-      if constexpr (ABL != 4) {
-        fa::landed<(g < 3 ? 2 : 0)>(fv[g][0], fv[g][1]);
-        if constexpr (g < 2) {
-          fa::read_2b64<(g + 2) * 32>(fv[g + 2][0], aV0);
-          fa::read_2b64<(g + 2) * 32>(fv[g + 2][1], aV1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma(o[0], fv[g][0], fp[g]);
-      mfma(o[1], fv[g][1], fp[g]);
-    });
-    l_run = l_run * alpha + (ra[0] + rb[0]);
-  };
-
-  load_bundle(-1, rk[0], rv[0]);
-  load_bundle(0, rk[1], rv[1]);
-  store_bundle(1, rk[0], rv[0]);  // K tile 0 -> slot 1
-  store_bundle(0, rk[1], rv[1]);  // bundle 0 -> slot 0
-  // set 0 is stored at even t, set 1 at odd t; the bundle a half stores at t is t + half
-  load_bundle(half ? 1 : 2, rk[0], rv[0]);
-  load_bundle(half ? 2 : 1, rk[1], rv[1]);
-  __syncthreads();
-  {
-    const char* sK = smem + STAGE + ql * K_ROWB + hi * 16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sc[0][r] = 0.f; sc[1][r] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      Frag fk;
-      fk.u = *reinterpret_cast<const uint4*>(sK + (i >> 2) * 32 * K_ROWB + (i & 3) * 32);
-      Mma32<f16>::mma(sc[i >> 2], fk, fq[i & 3]);
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  __syncthreads();            // slot 1 is refilled from phase 1 on
-  if (half) __syncthreads();  // half 1 runs one phase behind
-  __builtin_amdgcn_sched_barrier(0);
-  int t = 0;
-  // a phase boundary: nothing (an MFMA above all) may be scheduled across it
-  auto phase_end = [&] {
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (; t + 1 < ntile; t += 2) {
-    softmax_phase(t, rk[0], rv[0]);
-    phase_end();
-    matrix_phase(0);
-    phase_end();
-    softmax_phase(t + 1, rk[1], rv[1]);
-    phase_end();
-    matrix_phase(1);
-    phase_end();
-  }
-  if (t < ntile) {
-    softmax_phase(t, rk[0], rv[0]);
-    phase_end();
-    matrix_phase(0);
-    phase_end();
-  }
-  if (!half) phase_end();
-
-  flash_store_row(a, o, 1.0f / l_run, a.cu_rows ? (int64_t)a.cu_rows[bp] + qrow : (int64_t)bp * n + qrow, hh, hi, qrow < q_end);
 }
 
 // merge the kv_split partial results of every query row: O = sum_s e^(m_s - m) O_s / sum_s e^(m_s - m) l_s with m = max_s m_s (the

@@ -150,20 +150,6 @@ __device__ __forceinline__ void f5_swap32(uint32_t& a, uint32_t& b) {
   b = r[1];
 #endif
 }
-// 16 values a lane owns of a 32-channel tile in accumulator order (index 4 q + e <-> channel 8 q + 4 h + e, h = lane >> 5) -> the unit order of
-// fp16m2 (index 8 s + e <-> channel 16 s + 8 h + e): quads (2 s, 2 s + 1) trade halves with the partner lane (l ^ 32), as `widen` does for stores
-__device__ __forceinline__ void mx2_unit_order(float (&v)[16]) {
-  union { float f; uint32_t u; } x[16];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) x[t].f = v[t];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) f5_swap32(x[8 * s + e].u, x[8 * s + 4 + e].u);
-#pragma unroll
-  for (int t = 0; t < 16; ++t) v[t] = x[t].f;
-}
-
 // ---- fp16 + MX-fp6 corrections (operand mode fp16m, round 4) -----------------------------------------------------------------------------
 // The three-term product A_hi W_hi + A_hi W_lo + A_lo W_hi costs three fp16 MFMAs.  Its two correction terms are 2^-11 of the first and
 // only need ~4 significant bits per factor: on gfx950 they fit ONE v_mfma_scale_f32_32x32x64_f8f6f4 with e2m3 operands per 32 k, which runs
@@ -235,78 +221,6 @@ __device__ __forceinline__ void mx_mma(f32x16& acc, const uint4& w0, const uint4
   const i32x8 wv = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
   const i32x8 av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc, 2, 2, 0, (int)w1.z, 0, (int)a1.z);
-}
-
-// ---- fp16m2: the MX line without its coarse values (round 4, second half) ----------------------------------------------------------------
-// Half of an fp16m launch is operand bytes, and 12 of the 32 bytes of every P word restate what the `hi` halves say:
-// the coarse values c6.  Here they are derived in registers, from the two `hi` fragments a lane holds for the fp16 MFMAs anyway
-// (v_cvt_scalef32_pk32_fp6_f16: element i <- source i), so a row carries per 32 k its 32 hi halves and, per lane unit, 16 remainder codes +
-// the scale word = 96 bytes instead of 128.  Row layout: [K hi halves | K / 32 blocks x 2 units x 16 bytes], row stride 1.5 K halves.
-// Unit (block, g) covers the k-values of lane g's hi fragments: k = 32 blk + 16 s + 8 g + e, element t = 8 s + e.  Operand of the fp6 MFMA:
-// activation (c6 x 16 | l6 x 16), weight (l6 x 16 | c6 x 16): element i of one meets element i of the other, as in fp16m.
-typedef f16 f16x32 __attribute__((ext_vector_type(32)));
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
-
-// 16 values in unit order -> their hi halves (8 dwords, t order: two 16-byte runs of 8 consecutive k) and the unit's 16 bytes
-template <bool WEIGHT>
-__device__ __forceinline__ void mx2_pack16(const float (&v)[16], uint32_t (&hi)[8], uint32_t (&x)[4]) {
-  float amax = 0.f;
-#pragma unroll
-  for (int t = 0; t < 16; ++t) amax = fmaxf(amax, fabsf(v[t]));
-  union { float f; uint32_t u; } cv;
-  cv.f = amax;
-  int ex = (int)((cv.u >> 23) & 0xffu);
-  ex = ex < MX_MIN_EXP ? MX_MIN_EXP : ex;
-  const int sb = ex - 2;
-  cv.u = (uint32_t)sb << 23;
-  const float S = cv.f;
-  f16x32 l;
-#pragma unroll
-  for (int t = 0; t < 16; t += 2) {
-    const f16 h0 = (f16)v[t], h1 = (f16)v[t + 1];
-    union { f16 h[2]; uint32_t u; } pk;
-    pk.h[0] = h0; pk.h[1] = h1;
-    hi[t >> 1] = pk.u;
-    l[t] = (f16)((v[t] - (float)h0) * 2048.0f);  // the remainder x 2^11 has <= 13 significant bits: a half keeps 11 of them, the code 4
-    l[t + 1] = (f16)((v[t + 1] - (float)h1) * 2048.0f);
-  }
-#pragma unroll
-  for (int t = 16; t < 32; ++t) l[t] = (f16)0.f;
-  const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(l, S);
-  x[0] = r[0]; x[1] = r[1]; x[2] = r[2];
-  x[3] = (uint32_t)(WEIGHT ? sb : sb - 11) | ((uint32_t)sb << 23);  // byte 0: the fp6 MFMA's scale; bits 30:23: the codes' scale as a float (mx2_coarse)
-}
-
-// the coarse codes of a lane's 16 hi halves (fragments f0, f1 of the block's two k-steps) at the unit's scale (x_w = the unit's scale word)
-template <bool WEIGHT>
-__device__ __forceinline__ u32x3 mx2_coarse(const uint4& f0, const uint4& f1, uint32_t x_w) {
-  // the conversion takes 32 halves; the lane has 16: the upper half of the source (and of the result) is nobody's — left undefined, so no
-  // register is spent or written for it
-  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-  typedef unsigned int u32x8v __attribute__((ext_vector_type(8)));
-  typedef unsigned int u32x16v __attribute__((ext_vector_type(16)));
-  const u32x4v a = {f0.x, f0.y, f0.z, f0.w}, b = {f1.x, f1.y, f1.z, f1.w};
-  const u32x8v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-#ifdef F5_HIPEMU
-  const u32x8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-  const u32x16v s16 = __builtin_shufflevector(ab, z, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-#else
-  const u32x16v s16 = __builtin_shufflevector(ab, ab, 0, 1, 2, 3, 4, 5, 6, 7, -1, -1, -1, -1, -1, -1, -1, -1);
-#endif
-  union { u32x16v u; f16x32 h; } src;
-  src.u = s16;
-  union { float f; uint32_t u; } cv;
-  cv.u = x_w & 0x7f800000u;  // bits 30:23 of the unit's scale word: the conversion's scale as a float (byte 0: the MFMA's E8M0 scale)
-  const u32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(src.h, cv.f);
-  u32x3 c = {r[0], r[1], r[2]};
-  return c;
-}
-
-// acc += the two correction terms of one 32-k block: weight unit wx (l6 codes | scale) + its coarse codes wc, activation unit ax + ac
-__device__ __forceinline__ void mx2_mma(f32x16& acc, const uint4& wx, const u32x3& wc, const uint4& ax, const u32x3& ac) {
-  const i32x8 wv = {(int)wx.x, (int)wx.y, (int)wx.z, (int)wc[0], (int)wc[1], (int)wc[2], 0, 0};
-  const i32x8 av = {(int)ac[0], (int)ac[1], (int)ac[2], (int)ax.x, (int)ax.y, (int)ax.z, 0, 0};
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, av, acc, 2, 2, 0, (int)wx.w, 0, (int)ax.w);
 }
 
 // A wave's own LDS writes become readable by its own lanes: LDS operations of one wave are processed in order, so nothing has to be

@@ -108,8 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // instruction touched all 32 lines of the row; 332 against 188 ms of LayerNorm per B = 32 step.  profiles/r04c_*.)  LDS image: group G at
 // slot (G & ~7) | ((G & 7) ^ 2 ((G >> 3) & 3)): the natural writes (8 lanes = one 128-byte line) and the transposed reads (a lane pair per
 // line, four lines per 8 lanes) are both bank-conflict free.
-template <int NB, bool EARLY, bool FMT2 = false>  // FMT2: fp16m2 rows (K hi halves | units; the unit of lane (blk, g) = channels 32 blk + 16 s + 8 g + e)
-                                                  // passes: D <= 1024 NB; EARLY: per-channel parameters requested before the row reduction (few rows: latency; many
+template <int NB, bool EARLY>  // passes: D <= 1024 NB; EARLY: per-channel parameters requested before the row reduction (few rows: latency; many
                               // rows: the registers cost occupancy and with it bandwidth — as layernorm_kernel, profiles/r04d_*: 4.0 against 5.7 TB/s)
 __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restrict__ x, int64_t ldx, int M, int D, float eps,
                                                             const float* __restrict__ weight, const float* __restrict__ bias,
@@ -182,34 +181,11 @@ __global__ __launch_bounds__(256) void layernorm_mx_kernel(const float* __restri
     float y[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      // fp16m: float4 group 2 q + h of the block (channels 8 q + 4 h + e); fp16m2: group 4 (q / 2) + 2 h + (q % 2) (channels 16 s + 8 h + 4 c + e)
-      const int G = blk * 8 + (FMT2 ? 4 * (q >> 1) + 2 * h + (q & 1) : 2 * q + h);
+      const int G = blk * 8 + 2 * q + h;  // float4 group 2 q + h of the block (channels 8 q + 4 h + e)
       const float4 t = tp[(G & ~7) | ((G & 7) ^ (2 * ((G >> 3) & 3)))];
       y[4 * q] = t.x; y[4 * q + 1] = t.y; y[4 * q + 2] = t.z; y[4 * q + 3] = t.w;
     }
-    if constexpr (FMT2) { uint32_t xw[4]; mx2_pack16<false>(y, hi[b], xw); p[b][0] = xw[0]; p[b][1] = xw[1]; p[b][2] = xw[2]; p[b][3] = xw[3]; }
-    else mx_pack16<false>(y, hi[b], p[b]);
-  }
-  if constexpr (FMT2) {  // image of the row as it lies in memory: [D hi halves | D bytes of units] = 3 D bytes, then consecutive 16-byte pieces
-    wave_lds_sync();
-    char* img2 = reinterpret_cast<char*>(tp);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int blk = 32 * b + (lane >> 1);
-      if (32 * blk < D) {
-        *reinterpret_cast<uint4*>(img2 + (32 * blk + 8 * h) * 2) = make_uint4(hi[b][0], hi[b][1], hi[b][2], hi[b][3]);
-        *reinterpret_cast<uint4*>(img2 + (32 * blk + 16 + 8 * h) * 2) = make_uint4(hi[b][4], hi[b][5], hi[b][6], hi[b][7]);
-        *reinterpret_cast<uint4*>(img2 + 2 * D + blk * 32 + 16 * h) = make_uint4(p[b][0], p[b][1], p[b][2], p[b][3]);
-      }
-    }
-    wave_lds_sync();
-    char* orow2 = reinterpret_cast<char*>(out16 + (int64_t)row * ldo16);
-#pragma unroll
-    for (int i = 0; i < 3 * NB; ++i) {
-      const int pc = i * 64 + lane;
-      if (pc * 16 < 3 * D) *reinterpret_cast<uint4*>(orow2 + pc * 16) = *reinterpret_cast<const uint4*>(img2 + pc * 16);
-    }
-    return;
+    mx_pack16<false>(y, hi[b], p[b]);
   }
   // The packed lines leave through LDS as well: a lane holds 64 scattered bytes of its line (8-byte hi pieces, its 32-byte P words), and
   // stores of 16 bytes at a 64-byte stride reach 4.0 TB/s where the fp16x3 kernel's contiguous ones reach 5.7 (profiles/r04d_*).  Image of
@@ -259,32 +235,6 @@ __global__ __launch_bounds__(256) void pack_mx_rows_kernel(const float* src, int
   for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(line + (8 * q + 4 * h) * 2) = make_uint2(hi[2 * q], hi[2 * q + 1]);
   *reinterpret_cast<uint4*>(line + 64 + 32 * h) = make_uint4(p[0], p[1], p[2], p[3]);
   *reinterpret_cast<uint4*>(line + 80 + 32 * h) = make_uint4(p[4], p[5], p[6], p[7]);
-}
-
-// fp16m2 rows (common.h): [rows, K] fp32 x rowscale[r] -> [K hi halves | K / 32 x 2 units of 16 bytes], row stride 1.5 K halves.  One thread per
-// (row, 32-k block, unit g): the unit's 16 values are two runs of 8 consecutive k (32 blk + 16 s + 8 g + e).
-template <bool WEIGHT>
-__global__ __launch_bounds__(256) void pack_mx2_rows_kernel(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst) {
-  const int upr = K / 16;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * upr) return;
-  const int64_t r = i / upr;
-  const int u = (int)(i - r * upr), blk = u >> 1, g = u & 1;
-  const float rs = rowscale ? rowscale[r] : 1.0f;
-  float v[16];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const float4 t = *reinterpret_cast<const float4*>(src + r * ld + 32 * blk + 16 * s + 8 * g + 4 * c);
-      v[8 * s + 4 * c] = t.x * rs; v[8 * s + 4 * c + 1] = t.y * rs; v[8 * s + 4 * c + 2] = t.z * rs; v[8 * s + 4 * c + 3] = t.w * rs;
-    }
-  uint32_t hi[8], x[4];
-  mx2_pack16<WEIGHT>(v, hi, x);
-  char* row = reinterpret_cast<char*>(dst) + r * 3 * (int64_t)K;
-  *reinterpret_cast<uint4*>(row + (32 * blk + 8 * g) * 2) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-  *reinterpret_cast<uint4*>(row + (32 * blk + 16 + 8 * g) * 2) = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-  *reinterpret_cast<uint4*>(row + 2 * (int64_t)K + blk * 32 + 16 * g) = make_uint4(x[0], x[1], x[2], x[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,17 +582,13 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps
                             hipStream_t s, int pk16, int64_t ldo16, int mode) {
   if (D % 4 || D > 2048 || M <= 0) return hipErrorInvalidValue;
   if (ldo16 == 0) ldo16 = ldo;
-  if (pk16 == 2 || pk16 == 3) {  // MX operand rows (fp16m lines / fp16m2 rows): a kernel of its own lane layout
+  if (pk16 == 2) {  // MX operand rows (fp16m lines): a kernel of its own lane layout
     if (D % 32 || out32 || !out16 || ldo16 % 8 || (reinterpret_cast<uintptr_t>(out16) & 15) || (weight && scale)) return hipErrorInvalidValue;
     dim3 grid((M + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     const bool early = M < 8192;
-#define F5_LNMX(NB, E, F2) hipLaunchKernelGGL((layernorm_mx_kernel<NB, E, F2>), grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode)
-    if (pk16 == 3) {  // fp16m2 rows
-      if (D % 64) return hipErrorInvalidValue;
-      if (D <= 1024) { if (early) F5_LNMX(1, true, true); else F5_LNMX(1, false, true); }
-      else { if (early) F5_LNMX(2, true, true); else F5_LNMX(2, false, true); }
-    } else if (D <= 1024) { if (early) F5_LNMX(1, true, false); else F5_LNMX(1, false, false); }
-    else { if (early) F5_LNMX(2, true, false); else F5_LNMX(2, false, false); }
+#define F5_LNMX(NB, E) hipLaunchKernelGGL((layernorm_mx_kernel<NB, E>), grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out16, ldo16, mode)
+    if (D <= 1024) { if (early) F5_LNMX(1, true); else F5_LNMX(1, false); }
+    else { if (early) F5_LNMX(2, true); else F5_LNMX(2, false); }
 #undef F5_LNMX
     return hipGetLastError();
   }
@@ -653,9 +599,8 @@ hipError_t launch_layernorm(const float* x, int64_t ldx, int M, int D, float eps
   // Two shapes of the same arithmetic.  Few rows (one utterance: < 3 waves per SIMD, latency-bound): parameters requested before the
   // reduction and paired 16-byte stores, 7.24 against 7.70 ms per B = 1 sample.  Many rows (bandwidth-bound, 8 waves per SIMD hide the
   // second round trip): the lean kernel — the early parameters cost registers and the lane exchange LDS-pipe slots, 229 against 187 ms per
-  // B = 32 sample (same box, tools/r2_call18.sh).  F5HIP_LN_LATE / F5HIP_LN_EARLY force one (A/B runs).
-  static const int forced = getenv("F5HIP_LN_LATE") ? 1 : getenv("F5HIP_LN_EARLY") ? 0 : -1;
-  const bool late = forced >= 0 ? forced == 1 : M >= 8192;
+  // B = 32 sample (same box, profiles/r02d_*).
+  const bool late = M >= 8192;
 #define F5_LN(V, E, P) hipLaunchKernelGGL((layernorm_kernel<V, E>), grid, dim3(256), 0, s, x, ldx, M, D, eps, weight, bias, scale, shift, out32, out16, out16_lo, ldo, pk16, ldo16, mode, P)
   if (late) {
     if (D <= 256) F5_LN(1, false, 0); else if (D <= 512) F5_LN(2, false, 0); else if (D <= 1024) F5_LN(4, false, 0); else F5_LN(8, false, 0);
@@ -781,14 +726,6 @@ hipError_t launch_condition_weight(const float* src, int rows, int K, float* sca
   if (K % 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(row_pow2_scale_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, src, rows, K, scale, alpha);
   hipLaunchKernelGGL(split_f16_rows_kernel, dim3(grid_1d((int64_t)rows * K)), dim3(256), 0, s, src, (int64_t)rows, K, scale, hi, pk);
-  return hipGetLastError();
-}
-hipError_t launch_pack_mx2_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s) {
-  if (K % 64 || ld % 4 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
-  const int64_t units = rows * (K / 16);
-  const dim3 grid((unsigned)((units + 255) / 256));
-  if (weight) hipLaunchKernelGGL(pack_mx2_rows_kernel<true>, grid, dim3(256), 0, s, src, ld, rows, K, rowscale, dst);
-  else hipLaunchKernelGGL(pack_mx2_rows_kernel<false>, grid, dim3(256), 0, s, src, ld, rows, K, rowscale, dst);
   return hipGetLastError();
 }
 hipError_t launch_pack_mx_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s) {

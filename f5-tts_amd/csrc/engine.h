@@ -132,7 +132,6 @@ struct BlockW {  // per DiT block
   f16 *wqkv_hi, *wo_hi, *w1_hi, *w2_hi;  // plain fp16 rows [N, K]             (precision FP16)
   f16 *wqkv_pk, *wo_pk, *w1_pk, *w2_pk;  // packed hi/lo rows [N, 2K] (gemm.h) (precision FP16X3)
   f16 *wqkv_mx = nullptr, *wo_mx = nullptr, *w1_mx = nullptr, *w2_mx = nullptr;  // MX lines [N, 2K] (common.h) (precision FP16M; DiT / UNetT backbone, ctx->mx_ok)
-  f16 *wqkv_m2 = nullptr, *wo_m2 = nullptr, *w1_m2 = nullptr, *w2_m2 = nullptr;  // fp16m2 rows [N, 1.5K] (common.h) (precision FP16M at few rows; ctx->mx2_ok)
   // UNetT only: RMSNorm gains and the later-half skip projection Linear(2D -> D, no bias)
   const float *g_attn = nullptr, *g_ff = nullptr, *wskip = nullptr;
   f16 *wskip_hi = nullptr, *wskip_pk = nullptr;
@@ -269,7 +268,6 @@ struct f5hip_ctx {
   hipStream_t cap_stream = nullptr;
   bool mx_ok = false;          // finalize: the MX-line weight copies exist (DiT backbone whose block GEMMs the pipelined kernel takes)
   bool mx_call = false;        // f5hip_sample: this call's block GEMMs read MX lines (precision FP16M and every condition holds)
-  bool mx2_ok = false, mx2_call = false;  // the same for the 96-byte form (fp16m2 rows): built / used by this call (one-round launches: < 4096 rows)
   int attn_kv_split = 1;       // option "attn_kv_split": key ranges per query block in the flash kernel (1 = off); attn_part = its scratch
   DevBuf attn_part;
   // host inputs of queued copies (the entry points never wait for the stream) and the ordering of calls that arrive on different streams:

@@ -186,7 +186,7 @@ F5_PPV(70, 3, 1, 2, 2, 3, 3, +2);  // 192x64,  2 x 4 waves of 96x32, 3 stages = 
 
 // what the pipelined kernel needs from a launch: fp16 operands whose rows are whole 128-byte k-tiles (at least 3 of them), channel
 // count a multiple of 32, one batch, every byte offset of the operands within 31 bits
-constexpr int pp_planes(int nsplit) { return (nsplit == 1 || nsplit == 4) ? 1 : 2; }  // 128-byte (hi) lines hold 64 k (plain fp16, fp16m2) or 32 k (hi | lo, hi | MX words)
+constexpr int pp_planes(int nsplit) { return nsplit == 1 ? 1 : 2; }  // 128-byte lines hold 64 k (plain fp16) or 32 k (hi | lo, hi | MX words)
 template <int NSPLIT>
 bool pp_applies(const GemmCore& g, int batch) {
   const int64_t kbytes = (int64_t)g.K * 2 * pp_planes(NSPLIT);
@@ -194,14 +194,8 @@ bool pp_applies(const GemmCore& g, int batch) {
          (int64_t)g.a_rows * g.lda * 2 < (int64_t)0x7ff00000 && (int64_t)g.w_rows * g.ldw * 2 < (int64_t)0x7ff00000;
 }
 
-// Ring depth of a tile in an operand mode: fp16m2 stages hold 64 k (192 bytes per row instead of 128 for 32 k), so the 3-stage tiles whose
-// ring would pass 160 KB run 2 stages there (the same k in flight: 128 against 96)
 template <int NSPLIT, int ID>
-constexpr int pp_ns() {
-  using C = PpV<ID>;
-  if constexpr (NSPLIT == 4) return gemm_pp2_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, C::NS, C::KSP>() > 160 * 1024 ? 2 : C::NS;
-  else return C::NS;
-}
+constexpr int pp_ns() { return PpV<ID>::NS; }
 
 // "this tile does not take this launch" (the caller falls back to the generic kernel): a value no HIP call returns here, so that a real
 // launch failure is never mistaken for it
@@ -211,7 +205,7 @@ template <int NSPLIT, int ID, typename Epi, int ABL = 0>
 hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
   using C = PpV<ID>;
   constexpr int NSX = pp_ns<NSPLIT, ID>();
-  constexpr int lds = NSPLIT == 4 ? gemm_pp2_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>() : gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>();
+  constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>();
   static_assert(lds <= 160 * 1024, "ring does not fit the LDS");
   static_assert(C::KSP * C::KSS == 1 || C::WGM * C::WGN * C::TM * C::TN * 4096 <= lds, "the partial-sum exchange of the split tiles reuses the ring");
   if constexpr (C::KSS > 1) {  // even / odd tiles alternate the fragment buffers: an even number of k-tiles, a whole pipeline
@@ -237,22 +231,13 @@ hipError_t launch_pp_one(const GemmCore& g, const Epi& e, hipStream_t s) {
 // the tiles instantiated for MX lines (NSPLIT 2): the tiles pick_pp_variant can choose in that mode plus their microbenchmark
 // alternatives — every instantiation is a minute of build time
 #define F5_MX_TILES(X) X(50) X(54) X(55) X(56) X(59) X(61) X(62) X(63) X(66) X(68) X(69)
-// fp16m2 rows (NSPLIT 4): no k-step split; 64-k tiles
-#define F5_MX2_TILES(X) X(55) X(56) X(59)  // (the 8-wave 256x256 tile does not fit fp16m2's conversion temporaries into 256 registers: rows >= 4096 stay on fp16m lines)
 template <int NSPLIT, typename Epi>
 hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s) {
   if (variant == 80) {  // the ping-pong kernel (gemm_p8.h): plain fp16 rows and MX lines
     if constexpr (NSPLIT == 1 || NSPLIT == 2) return launch_p8<NSPLIT, Epi>(g, e, 0, s);
     else return PP_NOT_APPLICABLE;
   }
-  if constexpr (NSPLIT == 4) {
-    switch (variant) {
-#define F5_CASE(ID) case ID: return launch_pp_one<4, ID, Epi>(g, e, s);
-      F5_MX2_TILES(F5_CASE)
-#undef F5_CASE
-      default: return PP_NOT_APPLICABLE;
-    }
-  } else if constexpr (NSPLIT == 2) {
+  if constexpr (NSPLIT == 2) {
     switch (variant) {
 #define F5_CASE(ID) case ID: return launch_pp_one<2, ID, Epi>(g, e, s);
       F5_MX_TILES(F5_CASE)
@@ -290,7 +275,7 @@ hipError_t launch_pp(const GemmCore& g, const Epi& e, int variant, hipStream_t s
 // Tile choice.  A launch costs rounds x (time of one workgroup), so prefer the tile whose workgroup count fills whole rounds of the CUs
 // with the largest wave tiles; measured tables: DESIGN.md section 4 (tools/kernel_bench.py, profiles/r02*).
 inline int64_t ktiles_of(const GemmCore& g, int nsplit_planes) { return (int64_t)g.K * 2 * nsplit_planes / GEMM_KTB; }
-int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool mx = false, bool act16 = false, bool mx2 = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
+int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool mx = false, bool act16 = false) {  // nsplit_planes: 1 plain fp16 rows, 2 packed hi | lo rows
   static const int forced = [] { const char* e = getenv("F5HIP_PP_VARIANT"); return e ? atoi(e) : -1; }();  // tuning knob; 0 = never use the pipelined kernel
   if (forced >= 0) return forced;
   static const int f3072 = [] { const char* e = getenv("F5HIP_PP_VARIANT_N3072"); return e ? atoi(e) : -1; }();  // per-shape tuning knobs (tools/)
@@ -315,11 +300,11 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
     // the choice — (us, lockstep / two-per-CU choice -> ping-pong; profiles/r05a_p8_kernel_bench.log, r05c_*): M = 90k FF1 818 -> 757, FF2 769 ->
     // 688, q|k|v 1225 -> 1106, out 435 -> 387; M = 45k FF1 425 -> 377; M = 22k FF1 201 -> 184, gate / residual launches 249 -> 233, q|k|v at
     // 45k rows 697 -> 665; at 11k rows the two-per-CU tiles stay ahead on everything but FF1 (123 -> 110)
-    if (!mx2 && (g.M >= 16384 || (act16 && g.M >= 8192)) && p8_applies(2, g)) return 80;
+    if ((g.M >= 16384 || (act16 && g.M >= 8192)) && p8_applies(2, g)) return 80;
     if (g.M >= 40000) return 50;
     if (g.M >= 4096) return qkv ? 61 : (act16 && g.M >= 8192) ? 50 : (g.N >= 2048 || g.M >= 8192) ? 62 : 63;
-    static const int kss = [] { const char* e = getenv("F5HIP_MX_KSS"); return e ? atoi(e) : 1; }();  // A/B switch: the k-step-split tiles for the one-round launches
-    const bool even_kt = !mx2 && ktiles_of(g, 2) % 2 == 0 && ktiles_of(g, 2) >= 4;  // (fp16m2 has no k-step-split tiles)
+    constexpr bool kss = true;  // the k-step-split tiles for the one-round launches (q|k|v 44.8 -> 40.7 us, FF1 32 -> 30.4; profiles/r04d_kernel_bench_mx.log)
+    const bool even_kt = ktiles_of(g, 2) % 2 == 0 && ktiles_of(g, 2) >= 4;
     if (g.M >= 2048) return g.N >= 3072 ? (kss && even_kt ? 68 : 56) : g.N >= 2048 ? (kss && even_kt ? 69 : 55) : 59;
     return g.N >= 3072 ? 55 : 59;
   }
@@ -355,10 +340,10 @@ int pick_pp_variant(const GemmCore& g, int nsplit_planes, bool qkv = false, bool
 template <int NSPLIT>
 hipError_t try_pp_store(const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   if (!pp_applies<NSPLIT>(g, batch)) return PP_NOT_APPLICABLE;
-  if (variant < 0) variant = pick_pp_variant(g, pp_planes(NSPLIT), false, NSPLIT == 2 || NSPLIT == 4, e.out16 != nullptr, NSPLIT == 4);
+  if (variant < 0) variant = pick_pp_variant(g, pp_planes(NSPLIT), false, NSPLIT == 2, e.out16 != nullptr);
   if (variant < 50) return PP_NOT_APPLICABLE;
   constexpr bool PK = NSPLIT != 1;
-  constexpr int FMT = NSPLIT == 3 ? 1 : NSPLIT == 2 ? 2 : NSPLIT == 4 ? 3 : 0;  // the operand format the consumer of out16 reads = this launch's own
+  constexpr int FMT = NSPLIT == 3 ? 1 : NSPLIT == 2 ? 2 : 0;  // the operand format the consumer of out16 reads = this launch's own
   const bool plain_out = e.alpha == 1.f && e.bias && !e.out2 && !e.zdiv;
   if (plain_out && e.out16 && !e.out32 && !e.res && !e.colscale && !e.rowmask && (e.act == ACT_GELU_TANH || e.act == ACT_NONE) &&
       (PK ? (e.pk16 == FMT && (FMT == 3 ? e.ldo16 >= 3 * (int64_t)g.N / 2 : (e.out16_lo == e.out16 + 32 && e.ldo16 >= 2 * (int64_t)g.N))) : (!e.out16_lo && !e.pk16))) {
@@ -420,8 +405,8 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
   GemmCore g = g0;
   if (g.group_m == 0) g.group_m = default_group_m(g);
   if constexpr (std::is_same<Epi, EpiStore>::value) {
-    if (op == OP_F16M || op == OP_F16M2) {  // MX lines / rows: the pipelined kernel or nothing (the engine checks the shapes before it chooses the mode)
-      const hipError_t r = (variant >= 0 && variant < 50) ? PP_NOT_APPLICABLE : op == OP_F16M ? try_pp_store<2>(g, e, batch, variant, s) : try_pp_store<4>(g, e, batch, variant, s);
+    if (op == OP_F16M) {  // MX lines: the pipelined kernel or nothing (the engine checks the shapes before it chooses the mode)
+      const hipError_t r = (variant >= 0 && variant < 50) ? PP_NOT_APPLICABLE : try_pp_store<2>(g, e, batch, variant, s);
       return r == PP_NOT_APPLICABLE ? hipErrorInvalidValue : r;
     }
     if ((variant < 0 || variant >= 50) && (op == OP_F16 || op == OP_F16X3)) {
@@ -430,7 +415,7 @@ hipError_t dispatch(int op, const GemmCore& g0, const Epi& e, int batch, int var
       if (variant >= 50) return hipErrorInvalidValue;  // an explicitly requested pipelined tile that does not take this launch
     }
   }
-  if (op == OP_F16M || op == OP_F16M2) return hipErrorInvalidValue;
+  if (op == OP_F16M) return hipErrorInvalidValue;
   switch (op) {
     case OP_F32: return launch_tiled<float, 1, Epi>(g, e, batch, variant, s);
     case OP_F16: return launch_tiled<f16, 1, Epi>(g, e, batch, variant, s);
@@ -445,7 +430,7 @@ hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int b
   return dispatch<EpiStore>(op, g, e, batch, -1, s);
 }
 // OP_F16M launches have no generic-kernel fallback, so the tuning knobs that take a launch away from the tiles instantiated for MX lines
-// (a forced tile id outside F5_MX_TILES / 0 = "never the pipelined kernel", the general q|k|v index path) make the mode unusable: the
+// (a forced tile id outside F5_MX_TILES / 0 = "never the pipelined kernel") make the mode unusable: the
 // engine asks here before it chooses MX lines for a call and runs the call in fp16x3 otherwise (f5hip_sample)
 bool gemm_mx_tiles_usable() {
   auto mx_tile = [](int id) {
@@ -459,23 +444,21 @@ bool gemm_mx_tiles_usable() {
     const char* v = getenv(name);
     if (v && atoi(v) >= 0 && !mx_tile(atoi(v))) return false;
   }
-  return getenv("F5HIP_QKV_EPI_GENERIC") == nullptr;
+  return true;
 }
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s) {
   return dispatch<EpiStore>(op, g, e, batch, variant, s);
 }
 hipError_t launch_gemm_qkv(int op, const GemmCore& g0, const EpiQKV& e0, hipStream_t s) { return launch_gemm_qkv_variant(op, g0, e0, -1, s); }
 hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0, int want, hipStream_t s) {
-  static const bool generic = getenv("F5HIP_QKV_EPI_GENERIC") != nullptr;  // A/B switch: the general (division / 64-bit) index path
   EpiQKV e = e0;
-  e.fast = 0;
-  if (!generic) epi_qkv_prepare(e, g0.M);  // fast = 1 when its preconditions hold
+  epi_qkv_prepare(e, g0.M);  // fast = 1 when its preconditions hold (else the general division / 64-bit index path)
   // the pipelined kernel: half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour
-  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M || op == OP_F16M2) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
-      ((op == OP_F16 || op == OP_F16M2) ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
+  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
+      (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
     GemmCore g = g0;
     if (g.group_m == 0) g.group_m = default_group_m(g);
-    const int variant = want >= 50 ? want : pick_pp_variant(g, (op == OP_F16 || op == OP_F16M2) ? 1 : 2, true, op == OP_F16M || op == OP_F16M2, false, op == OP_F16M2);
+    const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true, op == OP_F16M, false);
     // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
     const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
     const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
@@ -486,11 +469,11 @@ hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0,
       p.nseq = e.nseq; p.heads = e.heads; p.pe_heads = e.pe_heads; p.slab_n = e.slab_n; p.pos_off = e.pos_off; p.ldvt = (int)e.ldvt;
       p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
       p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb; p.rowinfo = e.rowinfo;
-      const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : op == OP_F16M ? launch_pp<2>(g, p, variant, s) : op == OP_F16M2 ? launch_pp<4>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
+      const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : op == OP_F16M ? launch_pp<2>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
       if (r != PP_NOT_APPLICABLE) return r;
     }
   }
-  if (op == OP_F16M || op == OP_F16M2) return hipErrorInvalidValue;  // MX lines / rows: no generic-kernel fallback
+  if (op == OP_F16M) return hipErrorInvalidValue;  // MX lines: no generic-kernel fallback
   const int gv = want >= 0 && want < 50 ? want : -1;
   if (e.fast) {
     static_assert(sizeof(EpiQKVFast) == sizeof(EpiQKV), "same fields");
@@ -506,7 +489,7 @@ template <int NSPLIT, int ID, typename Epi>
 hipError_t set_pp_attr() {
   using C = PpV<ID>;
   constexpr int NSX = pp_ns<NSPLIT, ID>();
-  constexpr int lds = NSPLIT == 4 ? gemm_pp2_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>() : gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>();
+  constexpr int lds = gemm_pp_lds_bytes<C::TM, C::TN, C::WGM, C::WGN, NSX, C::KSP>();
   return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<f16, NSPLIT, C::TM, C::TN, C::WGM, C::WGN, NSX, C::JG, Epi, 0, C::KSP, C::KSS>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
@@ -524,24 +507,10 @@ hipError_t set_pp_attrs_mx() {
 #undef F5_ATTR
   return e;
 }
-template <typename Epi>
-hipError_t set_pp_attrs_mx2() {
-  hipError_t e = hipSuccess;
-#define F5_ATTR(ID) e = e == hipSuccess ? set_pp_attr<4, ID, Epi>() : e;
-  F5_MX2_TILES(F5_ATTR)
-#undef F5_ATTR
-  return e;
-}
 template <int NSPLIT>
 hipError_t set_pp_attrs() {  // every tile id 50 .. 70 x every wave-tile epilogue launch_pp can be asked for
   hipError_t e;
-  if constexpr (NSPLIT == 4) {
-    if ((e = set_pp_attrs_mx2<PpEpiAct16<3, ACT_GELU_TANH>>()) != hipSuccess) return e;
-    if ((e = set_pp_attrs_mx2<PpEpiAct16<3, ACT_NONE>>()) != hipSuccess) return e;
-    if ((e = set_pp_attrs_mx2<PpEpiGateRes<true>>()) != hipSuccess) return e;
-    if ((e = set_pp_attrs_mx2<PpEpiGateRes<false>>()) != hipSuccess) return e;
-    return set_pp_attrs_mx2<PpEpiQKV>();
-  } else if constexpr (NSPLIT == 2) {
+  if constexpr (NSPLIT == 2) {
     if ((e = set_pp_attrs_mx<PpEpiAct16<2, ACT_GELU_TANH>>()) != hipSuccess) return e;
     if ((e = set_pp_attrs_mx<PpEpiAct16<2, ACT_NONE>>()) != hipSuccess) return e;
     if ((e = set_pp_attrs_mx<PpEpiGateRes<true>>()) != hipSuccess) return e;
@@ -574,8 +543,6 @@ hipError_t init_gemm_kernels() {
   e = set_pp_attrs<1>();
   if (e != hipSuccess) return e;
   e = set_pp_attrs<2>();
-  if (e != hipSuccess) return e;
-  e = set_pp_attrs<4>();
   if (e != hipSuccess) return e;
   return set_pp_attrs<3>();
 }

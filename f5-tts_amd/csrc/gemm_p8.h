@@ -75,38 +75,41 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   }
   const int kbytes = g.K * 2 * NPL;   // bytes of one operand row; a multiple of 256 (launcher: an even number of k-tiles)
   const int nkt = kbytes / GEMM_KTB;  // k-tiles
-  const BufRsrc Ar = make_rsrc(g.A, (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * 2 + kbytes));
-  const BufRsrc Wr = make_rsrc(g.W, (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * 2 + kbytes));
+  // the tile's rows start at the buffer descriptors' base: rows past the operand's end are out of range (zeros), no per-lane row test
+  const int arows = g.a_rows - m0, wrows = g.w_rows - n0;
+  const BufRsrc Ar = make_rsrc(reinterpret_cast<const char*>(g.A) + (int64_t)m0 * g.lda * 2, arows > 0 ? (uint32_t)((int64_t)(arows - 1) * g.lda * 2 + kbytes) : 0u);
+  const BufRsrc Wr = make_rsrc(reinterpret_cast<const char*>(g.W) + (int64_t)n0 * g.ldw * 2, wrows > 0 ? (uint32_t)((int64_t)(wrows - 1) * g.ldw * 2 + kbytes) : 0u);
 
   // LDS-DMA: piece P of an operand tile = rows 8P .. 8P+7 -> bytes [1024 P, +1024) of its buffer; lane l brings row 8P + l/8, logical
-  // 16-byte chunk (l%8) ^ swz(row) (the swizzle sits on the SOURCE side: the LDS destination of a DMA is lane-linear).  This wave's two
-  // pieces of every quarter:
-  const int pa = 16 * grp + 2 * wn;                 // a01 quarter (a23: + 8 pieces)
-  const int pw = 8 * (wave >> 1) + 2 * (wave & 1);  // w0 quarter (w1: + 4 pieces)
-  uint32_t qa[2][2], qw[2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      int row = 8 * (pa + 8 * h + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
-      qa[h][p] = (m0 + row) < g.a_rows ? (uint32_t)((int64_t)(m0 + row) * g.lda * 2 + lc * 16) : OOB_ROW;
-      row = 8 * (pw + 4 * h + p) + (lane >> 3);
-      lc = (lane & 7) ^ ((row >> 1) & 7);
-      qw[h][p] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + lc * 16) : OOB_ROW;
-    }
+  // 16-byte chunk (l%8) ^ swz(row) (the swizzle sits on the SOURCE side: the LDS destination of a DMA is lane-linear).  A wave's pieces of an
+  // operand are 16, 32 or 64 rows apart — swz(row) = (row >> 1) & 7 is the same for all of them — so ONE per-lane offset serves every piece
+  // and the distance rides in the scalar offset next to the k offset (2 long-lived VGPRs instead of 8).
+  //   A quarters (a01 = rows 0-63 of both groups' halves, a23 = rows 64-127): this wave brings pieces pa, pa + 2 (+ 8 for a23)
+  //   W quarters (w0 / w1 = first / second 32 rows of every 64-channel strip): pieces pw, pw + 2 (+ 4 for w1)
+  const int pa = 16 * grp + 4 * (wn >> 1) + (wn & 1);
+  const int pw = 8 * (wave >> 1) + (wave & 1);
+  uint32_t qa, qw;
+  {
+    int row = 8 * pa + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
+    qa = (uint32_t)((int64_t)row * g.lda * 2 + lc * 16);
+    row = 8 * pw + (lane >> 3);
+    lc = (lane & 7) ^ ((row >> 1) & 7);
+    qw = (uint32_t)((int64_t)row * g.ldw * 2 + lc * 16);
+  }
+  const uint32_t a16 = (uint32_t)(16 * g.lda * 2), w16 = (uint32_t)(16 * g.ldw * 2);  // 16 rows further, in bytes
   char* const a_dst = smem + pa * 1024;
   char* const w_dst = smem + 2 * OPB + pw * 1024;
   auto issue_a = [&](auto H, auto BUF, int kt) {  // quarter a01 (H = 0) / a23 (1) of k-tile kt into buffer BUF
     constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(Ar, a_dst + buf * OPB + h * 8192 + p * 1024, qa[h][p], (uint32_t)kt * GEMM_KTB);
+    for (int p = 0; p < 2; ++p) pp::dma_b128(Ar, a_dst + buf * OPB + h * 8192 + p * 2048, qa, (uint32_t)kt * GEMM_KTB + (uint32_t)(4 * h + p) * a16);
   };
   auto issue_w = [&](auto H, auto BUF, int kt) {  // quarter w0 (H = 0) / w1 (1)
     constexpr int h = decltype(H)::value, buf = decltype(BUF)::value;
     if constexpr (ABL & 4) return;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) pp::dma_b128(Wr, w_dst + buf * OPB + h * 4096 + p * 1024, qw[h][p], (uint32_t)kt * GEMM_KTB);
+    for (int p = 0; p < 2; ++p) pp::dma_b128(Wr, w_dst + buf * OPB + h * 4096 + p * 2048, qw, (uint32_t)kt * GEMM_KTB + (uint32_t)(2 * h + p) * w16);
   };
 
   f32x16 acc[TM][TN];
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   // fragment addressing: lane (row = lane & 31, half = lane >> 5) reads 16-byte chunks of its row's line.  Plain fp16: chunk 2 ks + half
   // for the 16-wide k-step ks = 0..3.  MX lines: chunks half and 2 + half (the two hi k-steps), 4 + 2 half and 5 + 2 half (the lane's P words).
   const uint32_t lds0 = pp::lds_base(smem);
-  uint32_t fa_addr[4], fw_addr[4];  // + 4096 * (32-row tile) + OPB * buffer as immediates
+  uint32_t fa_addr[4];  // + 4096 * (32-row tile) + OPB * buffer as immediates; the W fragments' = + wdelta (wave-uniform), added at the read
   {
     const int r = lane & 31, fswz = (r >> 1) & 7, fh = lane >> 5;
 #pragma unroll
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
       const int chunk = MX ? (x < 2 ? 2 * x + fh : 4 + 2 * fh + (x - 2)) : 2 * x + fh;
       const uint32_t o = (uint32_t)(r * GEMM_KTB + ((chunk ^ fswz) << 4));
       fa_addr[x] = lds0 + o + (uint32_t)(grp * 128 * GEMM_KTB);
-      fw_addr[x] = lds0 + 2 * OPB + o + (uint32_t)(wn * 64 * GEMM_KTB);
     }
   }
+  const uint32_t wdelta = (uint32_t)(2 * OPB + wn * 64 * GEMM_KTB - grp * 128 * GEMM_KTB);
   Frag fa[2][4], fw[2][4];  // the two row tiles of the current A pair / the two weight tiles x the four 16-byte reads of a line
   auto read_a = [&](auto JP, auto BUF) {  // row tiles 2 JP, 2 JP + 1 of this wave's 128 rows
     constexpr int jp = decltype(JP)::value, buf = decltype(BUF)::value;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   };
   auto read_w = [&](auto I, auto BUF) {  // weight tile I of this wave's 64 channels
     constexpr int i = decltype(I)::value, buf = decltype(BUF)::value;
-    static_for<4>([&](auto X) { fw[i][decltype(X)::value].u = pp::lds_read_b128<i * 4096 + buf * OPB>(fw_addr[decltype(X)::value]); });
+    static_for<4>([&](auto X) { fw[i][decltype(X)::value].u = pp::lds_read_b128<i * 4096 + buf * OPB>(fa_addr[decltype(X)::value] + wdelta); });
   };
   auto mma_q = [&](auto JP, auto I) {  // quadrant (row tiles 2 JP, 2 JP + 1) x weight tile I over the whole k-tile
     constexpr int jp = decltype(JP)::value, i = decltype(I)::value;
@@ -256,7 +259,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
   } else {
-    pp_unscale<TM, TN>(acc, g, n0 + wn * 64, lane);
-    epi.template tile<TM, TN>(acc, m0 + grp * 128, n0 + wn * 64, lane);
+    // the epilogue's per-lane address arithmetic hangs off an opaque copy of the lane id: loop-invariant code motion would otherwise compute
+    // it ahead of the k-loop and carry it through — with MX lines (fragment tuples + copies) that is what tipped the kernel into scratch
+    int lane_e = lane;
+#ifndef F5_HIPEMU
+    asm volatile("" : "+v"(lane_e));
+#endif
+    pp_unscale<TM, TN>(acc, g, n0 + wn * 64, lane_e);
+    epi.template tile<TM, TN>(acc, m0 + grp * 128, n0 + wn * 64, lane_e);
   }
 }

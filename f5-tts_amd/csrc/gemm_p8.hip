@@ -29,7 +29,7 @@ hipError_t set_attr() {
 bool p8_applies(int nsplit, const GemmCore& g) {  // an even number of whole k-tiles (the loop body is a pair), the operand modes built here
   if (nsplit != 1 && nsplit != 2) return false;
   const int64_t kbytes = (int64_t)g.K * 2 * (nsplit == 2 ? 2 : 1);
-  return kbytes % (2 * GEMM_KTB) == 0 && kbytes >= 2 * GEMM_KTB && g.N % 32 == 0 && g.M >= 1;
+  return kbytes % (2 * GEMM_KTB) == 0 && kbytes >= 2 * GEMM_KTB && g.N % 32 == 0 && g.M >= 1 && 256 * g.lda * 2 < (int64_t)0x7ff00000 && 256 * g.ldw * 2 < (int64_t)0x7ff00000;  // (31-bit offsets inside a tile)
 }
 
 template <int NSPLIT, typename Epi>

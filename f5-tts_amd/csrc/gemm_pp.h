@@ -112,7 +112,7 @@ __device__ __forceinline__ uint4 widen(uint32_t (&a)[2], uint32_t (&b)[2]) {
 // + 0..3 (acc[j][i][4 q + e]).  Rows >= M and channels >= N fall outside the buffer descriptors / are skipped per 32-channel tile.
 
 // FeedForward first linear (modules.py:353-364): tanh-GELU(acc + bias) -> the operand rows of the second linear, packed hi/lo (PK) or plain fp16
-// FMT: 0 plain fp16 rows, 1 packed hi | lo rows (fp16x3), 2 MX lines (fp16m: hi | P_0 | P_1, common.h), 3 fp16m2 rows (K hi halves | units, ld = 1.5 N)
+// FMT: 0 plain fp16 rows, 1 packed hi | lo rows (fp16x3), 2 MX lines (fp16m: hi | P_0 | P_1, common.h)
 template <int FMT, int ACT, int NOSTORE = 0>  // NOSTORE: microbenchmark ablations — 1: the arithmetic without the stores, 2: the same bytes
                                              // stored lane-linearly (1 KB runs per instruction; WRONG layout: what does the row-strided pattern cost?)
 struct PpEpiAct16 {
@@ -136,21 +136,6 @@ struct PpEpiAct16 {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const uint32_t row = (uint32_t)(m_w + 32 * j + r) * (uint32_t)(ld * 2);
-        if constexpr (FMT == 3) {  // fp16m2 rows: the unit of lane-half h covers channels 16 s + 8 h + e — the half-wave exchange of `widen`, on fp32
-          float v[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = apply_act(ACT, acc[j][i][4 * q + e] + (e == 0 ? b[q].x : e == 1 ? b[q].y : e == 2 ? b[q].z : b[q].w));
-          mx2_unit_order(v);  // -> v[8 s + 0..7] = channels 16 s + 8 h + 0..7
-          uint32_t hv[8], xw[4];
-          mx2_pack16<false>(v, hv, xw);
-          const uint32_t hrow = row + (uint32_t)nb * 2u + 16u * (uint32_t)h;
-          pp::store_b128(R, hrow, make_uint4(hv[0], hv[1], hv[2], hv[3]));
-          pp::store_b128(R, hrow + 32u, make_uint4(hv[4], hv[5], hv[6], hv[7]));
-          pp::store_b128(R, row + (uint32_t)N * 2u + (uint32_t)(nb >> 5) * 32u + 16u * (uint32_t)h, make_uint4(xw[0], xw[1], xw[2], xw[3]));
-          continue;
-        }
         if constexpr (FMT == 2) {  // the lane's 16 channels 8 q + 4 h + e are exactly the k-set of P_h
           float x[16];
 #pragma unroll
@@ -399,14 +384,6 @@ template <int TM, int TN, int WGM, int WGN, int NS, int KSP = 1>
 constexpr int gemm_pp_lds_bytes() {
   return NS * KSP * 32 * (WGM * TM + WGN * TN) * GEMM_KTB;
 }
-// fp16m2 (NSPLIT 4): a k-tile is 64 k = a 128-byte hi line + a 64-byte line of remainder units per row; the unit lines arrive in pieces of
-// 16 rows, so their part of the stage is rounded up to whole pieces per wave
-constexpr int pp_x_rows(int rows, int waves) { return (rows + 16 * waves - 1) / (16 * waves) * 16 * waves; }
-template <int TM, int TN, int WGM, int WGN, int NS, int KSP = 1>
-constexpr int gemm_pp2_lds_bytes() {
-  return NS * KSP * (32 * (WGM * TM + WGN * TN) * GEMM_KTB + (pp_x_rows(32 * WGM * TM, WGM * WGN) + pp_x_rows(32 * WGN * TN, WGM * WGN)) * 64);
-}
-
 // TM x TN 32x32 tiles per wave, WGM x WGN waves, ring of NS stages, JG activation tiles per fragment slot (TM % JG == 0).
 // KSP = 2 ("k-split"): TWO groups of WGM x WGN waves work on the SAME output tile, group g on the k-tiles 2 s + g — two waves per SIMD with
 // the large wave tiles of a 4-wave workgroup: one group's LDS-DMA issue, fragment reads and waits hide behind the other's MFMAs, and the
@@ -422,17 +399,14 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   constexpr int DW = NW * KSS;   // waves that fill one (sub-)stage
   constexpr int BM = 32 * WGM * TM, BN = 32 * WGN * TN;
   constexpr bool MX = NSPLIT == 2;                 // fp16m lines: 32 hi halves | P_0 | P_1 (common.h) — 2 fp16 MFMAs + 1 fp6 MFMA per 32 k
-  constexpr bool MX2 = NSPLIT == 4;                // fp16m2 rows: K hi halves | remainder units (common.h) — a k-tile = 64 k = a 128-byte hi line + a 64-byte unit line
   constexpr int NPL = (NSPLIT == 3 || MX) ? 2 : 1;
-  constexpr int NFR = (MX || MX2) ? 3 : NPL;       // 16-byte fragments per tile: hi | lo, hi | the two halves of the lane's P words, or hi(2 blk) | hi(2 blk + 1) | unit(blk)
-  constexpr int KS = (NPL == 2 || MX2) ? 2 : 4;    // fragment steps per k-tile: 16-wide MFMA k-steps; fp16m2: the two 32-k blocks of the tile
+  constexpr int NFR = MX ? 3 : NPL;                // 16-byte fragments per tile: hi | lo, or hi | the two halves of the lane's P words
+  constexpr int KS = NPL == 2 ? 2 : 4;             // fragment steps per k-tile: 16-wide MFMA k-steps
   constexpr int KSL = KS / KSS;                    // k-steps one group multiplies per k-tile
   constexpr int PA = BM / 8 / DW, PW = BN / 8 / DW;  // DMA pieces (8 rows x 128 B) per wave per k-tile
-  constexpr int PAX = MX2 ? pp_x_rows(BM, DW) / 16 / DW : 0, PWX = MX2 ? pp_x_rows(BN, DW) / 16 / DW : 0;  // unit-line pieces (16 rows x 64 B)
-  constexpr int LPT = PA + PW + PAX + PWX;
-  constexpr int TILE_A = BM * GEMM_KTB, XA0 = (BM + BN) * GEMM_KTB, XW0 = XA0 + pp_x_rows(BM, DW) * 64;  // stage: A hi | W hi | A units | W units
-  constexpr int SUB = MX2 ? XW0 + pp_x_rows(BN, DW) * 64 : (BM + BN) * GEMM_KTB, STAGE = KSP * SUB;  // a stage holds the k-tiles of all groups
-  static_assert(!MX2 || KSS == 1, "fp16m2: no k-step split (a unit belongs to the lane that holds both hi fragments of its block)");
+  constexpr int LPT = PA + PW;
+  constexpr int TILE_A = BM * GEMM_KTB;
+  constexpr int SUB = (BM + BN) * GEMM_KTB, STAGE = KSP * SUB;  // a stage holds the k-tiles of all groups
   constexpr int NSLOT = TM / JG;                   // fragment slots per k-step
   static_assert(PA * 8 * DW == BM && PW * 8 * DW == BN, "tile rows must split evenly into 8-row DMA pieces over the waves");
   static_assert(TM % JG == 0 && NS >= 2 && NS <= 5 && (NS - 1) * LPT <= 63 && (KSP == 1 || KSP == 2) && (KSS == 1 || KSS == 2) && KSP * KSS <= 2,
@@ -467,7 +441,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
     n0 = ntile * BN;
   }
   const int kbytes = g.K * 2 * NPL;  // bytes of the hi (| lo | P) part of one operand row; a multiple of 128 (launcher)
-  const int rowbytes = MX2 ? g.K * 3 : kbytes;  // fp16m2: + K bytes of remainder units behind the hi halves
+  const int rowbytes = kbytes;
   const int nkt = kbytes / GEMM_KTB / KSP;  // k-tiles of this group (a multiple of KSP in total: launcher)
   const BufRsrc Ar = make_rsrc(g.A, (uint32_t)((int64_t)(g.a_rows - 1) * g.lda * 2 + rowbytes));
   const BufRsrc Wr = make_rsrc(g.W, (uint32_t)((int64_t)(g.w_rows - 1) * g.ldw * 2 + rowbytes));
@@ -483,21 +457,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
     const int row = 8 * (dwave * PW + p) + (lane >> 3), lc = (lane & 7) ^ ((row >> 1) & 7);
     w_off[p] = (n0 + row) < g.w_rows ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + lc * 16) : OOB_ROW;
   }
-  // fp16m2 unit lines: piece P = rows 16P .. 16P+15 x 64 B; lane l brings row 16P + l/4, logical chunk (l%4) ^ ((row >> 2) & 3); pieces past the
-  // tile's rows (a tile of 96 rows over 4 waves) read out of range: zeros into rows nobody reads
-  uint32_t ax_off[PAX ? PAX : 1], wx_off[PWX ? PWX : 1];
-  if constexpr (MX2) {
-#pragma unroll
-    for (int p = 0; p < PAX; ++p) {
-      const int row = 16 * (dwave * PAX + p) + (lane >> 2), lc = (lane & 3) ^ ((row >> 2) & 3);
-      ax_off[p] = (row < BM && (m0 + row) < g.a_rows) ? (uint32_t)((int64_t)(m0 + row) * g.lda * 2 + g.K * 2 + lc * 16) : OOB_ROW;
-    }
-#pragma unroll
-    for (int p = 0; p < PWX; ++p) {
-      const int row = 16 * (dwave * PWX + p) + (lane >> 2), lc = (lane & 3) ^ ((row >> 2) & 3);
-      wx_off[p] = (row < BN && (n0 + row) < g.w_rows) ? (uint32_t)((int64_t)(n0 + row) * g.ldw * 2 + g.K * 2 + lc * 16) : OOB_ROW;
-    }
-  }
   auto issue = [&](int kt, int stage) {
     char* base = smem + stage * STAGE;
     const uint32_t kb = (uint32_t)(KSP * kt + (KSP == 1 ? 0 : grp)) * GEMM_KTB;
@@ -505,12 +464,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
     for (int p = 0; p < PA; ++p) pp::dma_b128(Ar, base + (dwave * PA + p) * 1024, a_off[p], kb);
 #pragma unroll
     for (int p = 0; p < PW; ++p) pp::dma_b128(Wr, base + TILE_A + (dwave * PW + p) * 1024, w_off[p], kb);
-    if constexpr (MX2) {
-#pragma unroll
-      for (int p = 0; p < PAX; ++p) pp::dma_b128(Ar, base + XA0 + (dwave * PAX + p) * 1024, ax_off[p], kb >> 1);
-#pragma unroll
-      for (int p = 0; p < PWX; ++p) pp::dma_b128(Wr, base + XW0 + (dwave * PWX + p) * 1024, wx_off[p], kb >> 1);
-    }
   };
 
   f32x16 acc[TM][TN];
@@ -531,18 +484,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
 #pragma unroll
     for (int ksl = 0; ksl < KSL; ++ksl) {
       const int ks = KSS == 1 ? ksl : ksl * KSS + grp;  // k-step split: this group's k-steps of the line
-      if constexpr (MX2) {  // ks = the 32-k block of the 64-k tile: hi k-steps 2 ks (p = 0) and 2 ks + 1 (p = 1) of the 128-byte line, unit (ks, fhi) of the 64-byte line (p = 2)
-        if (p < 2) {
-          const uint32_t o = (uint32_t)(frow + (((2 * (2 * ks + p) + fhi) ^ fswz) << 4));
-          fa_addr[p][ksl] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
-          fw_addr[p][ksl] = lds0 + o + TILE_A + (uint32_t)(wn * 32 * TN) * GEMM_KTB;
-        } else {
-          const uint32_t o = (uint32_t)((lane & 31) * 64 + (((2 * ks + fhi) ^ (((lane & 31) >> 2) & 3)) << 4));
-          fa_addr[p][ksl] = lds0 + o + XA0 + (uint32_t)(wm * 32 * TM) * 64;
-          fw_addr[p][ksl] = lds0 + o + XW0 + (uint32_t)(wn * 32 * TN) * 64;
-        }
-        continue;
-      }
       const int chunk = (MX && p > 0) ? 4 + 2 * fhi + (p - 1) : p * 4 + 2 * ks + fhi;
       const uint32_t o = (uint32_t)(frow + ((chunk ^ fswz) << 4));
       fa_addr[p][ksl] = lds0 + o + (uint32_t)(wm * 32 * TM) * GEMM_KTB;
@@ -553,24 +494,19 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
   auto k_loop = [&](auto GC) {
   constexpr int G = decltype(GC)::value;  // this wave's group (meaningful for MX && KSS == 2 only)
     Frag fa[2][NFR][JG], fw[2][NFR][TN];
-    u32x3 cw[2][TN];  // fp16m2: the coarse codes of the weight tiles of the current block (derived once per block, used by its NSLOT slots)
 
     // slot s of a k-tile = (k-step s / NSLOT, activation tiles JG * (s % NSLOT) ..); its weight fragments are read with the k-step's first slot.
     // Slots are numbered v = parity * SLOTS + s over a PAIR of k-tiles: the fragment buffers alternate with v, so tiles with an odd number
     // of slots or k-steps (the k-step split) run as even / odd tiles; with even counts the parity is always 0.
     constexpr int SLOTS = KSL * NSLOT;
     constexpr bool PAIRED = (SLOTS % 2 != 0) || (KSL % 2 != 0);
-    // fp16m2 on the 8-wave tiles (two waves per SIMD: 256 registers each): ONE buffer of weight fragments — 3 fragments x TN tiles x 2 buffers
-    // next to 128 accumulators spilled inside the k-loop.  The weight fragments of a block are then requested behind the previous block's last
-    // MFMAs (WHICH = 2) instead of a slot ahead; the SIMD's other wave covers that read.
-    constexpr bool WSB = MX2 && (64 * WGM * WGN * KSP * KSS >= 512);
     auto read_slot = [&](auto SC, uint32_t soff, auto WHICHC) {  // SC = integral_constant<int, v>; WHICH: bit 0 the activation fragments, bit 1 the weight fragments
-      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = WSB ? 0 : ((v / SLOTS) * KSL + ks) & 1;
+      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
       constexpr int WHICH = decltype(WHICHC)::value;
       static_for<NFR>([&](auto P) {
         constexpr int p = decltype(P)::value;
         auto reads = [&] {
-          constexpr int TS = (MX2 && p == 2) ? 2048 : 4096;  // bytes of 32 rows of the line the fragment comes from
+          constexpr int TS = 4096;  // bytes of 32 rows of a line
           if constexpr (jg == 0 && (WHICH & 2)) {
             const uint32_t wb = fw_addr[p][ks] + soff;
             static_for<TN>([&](auto I) { fw[wbuf][p][decltype(I)::value].u = pp::lds_read_b128<decltype(I)::value * TS>(wb); });
@@ -580,7 +516,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
             static_for<JG>([&](auto J) { fa[buf][p][decltype(J)::value].u = pp::lds_read_b128<(jg * JG + decltype(J)::value) * TS>(ab); });
           }
         };
-        if constexpr (!MX || p == 0) reads();  // (fp16m2: all three fragments of the block, every slot)
+        if constexpr (!MX || p == 0) reads();
         else if constexpr (KSS == 1) { if constexpr (ks == KSL - 1) reads(); }  // the lane's MX words: with the line's last k-step
         else { if constexpr (G != v / SLOTS) reads(); }                          // k-step split: the group whose turn this k-tile is
       });
@@ -588,25 +524,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
       // hipcc's own interleaving of a slot's first MFMAs with the next slot's reads is the better one; profiles/r02b_kernel_bench.md)
     };
     auto mma_slot = [&](auto SC) {
-      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = WSB ? 0 : ((v / SLOTS) * KSL + ks) & 1;
-      if constexpr (MX2) {  // every fragment feeds a conversion or a copy: re-define all of them behind the wait that preceded this call
-        static_for<JG>([&](auto J) { static_for<3>([&](auto P) { pin_after_wait(fa[buf][decltype(P)::value][decltype(J)::value].u); }); });
-        if constexpr (jg == 0) static_for<TN>([&](auto I) {
-          static_for<3>([&](auto P) { pin_after_wait(fw[wbuf][decltype(P)::value][decltype(I)::value].u); });
-          cw[wbuf][decltype(I)::value] = mx2_coarse<true>(fw[wbuf][0][decltype(I)::value].u, fw[wbuf][1][decltype(I)::value].u, fw[wbuf][2][decltype(I)::value].u.w);
-        });
-#pragma unroll
-        for (int jj = 0; jj < JG; ++jj) {
-          const u32x3 ca = mx2_coarse<false>(fa[buf][0][jj].u, fa[buf][1][jj].u, fa[buf][2][jj].u.w);
-#pragma unroll
-          for (int i = 0; i < TN; ++i) {
-            Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][0][i], fa[buf][0][jj]);
-            Mma32<T>::mma(acc[jg * JG + jj][i], fw[wbuf][1][i], fa[buf][1][jj]);
-            mx2_mma(acc[jg * JG + jj][i], fw[wbuf][2][i].u, cw[wbuf][i], fa[buf][2][jj].u, ca);
-          }
-        }
-        return;
-      }
+      constexpr int v = decltype(SC)::value, s = v % SLOTS, ks = s / NSLOT, jg = s % NSLOT, buf = v & 1, wbuf = ((v / SLOTS) * KSL + ks) & 1;
       if constexpr (MX && (KSS == 1 ? ks == KSL - 1 : G != v / SLOTS)) {  // this slot multiplies MX words: re-define them behind the wait that preceded this call
         static_for<JG>([&](auto J) { pin_after_wait(fa[buf][1][decltype(J)::value].u); pin_after_wait(fa[buf][2][decltype(J)::value].u); });
         if constexpr (jg == 0) static_for<TN>([&](auto I) { pin_after_wait(fw[wbuf][1][decltype(I)::value].u); pin_after_wait(fw[wbuf][2][decltype(I)::value].u); });
@@ -639,18 +557,10 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
       constexpr int mode = decltype(MODE)::value, v0 = decltype(PAR)::value * SLOTS, v0_next = PAIRED ? (1 - decltype(PAR)::value) * SLOTS : 0;
       // slots 0 .. SLOTS-2: wait for this slot's fragments, read the next slot's, multiply
       using BOTH = std::integral_constant<int, 3>;
-      using AONLY = std::integral_constant<int, 1>;
-      using WONLY = std::integral_constant<int, 2>;
       static_for<SLOTS - 1>([&](auto S) {
         pp::lds_wait();
-        if constexpr (WSB) {
-          read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff, AONLY{});
-          mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
-          read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff, WONLY{});
-        } else {
-          read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff, BOTH{});
-          mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
-        }
+        read_slot(std::integral_constant<int, v0 + decltype(S)::value + 1>{}, soff, BOTH{});
+        mma_slot(std::integral_constant<int, v0 + decltype(S)::value>{});
       });
       pp::lds_wait();  // the last slot's fragments: every read of this tile by this wave has landed
       if constexpr (mode != 2) {
@@ -662,11 +572,9 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
             if (t + NS < nkt) issue(t + NS, stage);
           }
         }
-        if constexpr (WSB) read_slot(std::integral_constant<int, v0_next>{}, soff_next, AONLY{});
-        else read_slot(std::integral_constant<int, v0_next>{}, soff_next, BOTH{});
+        read_slot(std::integral_constant<int, v0_next>{}, soff_next, BOTH{});
       }
       mma_slot(std::integral_constant<int, v0 + SLOTS - 1>{});
-      if constexpr (WSB && mode != 2) read_slot(std::integral_constant<int, v0_next>{}, soff_next, WONLY{});
     };
 
     // prologue: tiles 0 .. NS-1 in flight, tile 0 landed and visible, its first fragments requested

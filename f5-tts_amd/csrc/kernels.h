@@ -4,12 +4,11 @@
 
 #include "gemm.h"  // common.h pulls in the HIP runtime (or the host shim under F5_HIPEMU)
 
-// GEMM operand kind.  OP_F16M: fp16 + MX-fp6 correction lines (common.h "fp16m"); OP_F16M2: the same rows without their coarse values
-// (common.h "fp16m2": 96 bytes per 32 k).  Both exist for the pipelined block-GEMM kernels ONLY: a launch that those kernels do not take
-// FAILS (hipErrorInvalidValue) instead of falling back to the generic kernel, which has no MX k-loop.  Callers therefore pre-validate:
-// the engine chooses the modes per call (api.cpp `mx_call`: model shape, at least 8 tokens per sequence, gemm_mx_tiles_usable()) and runs
-// the call in OP_F16X3 when any precondition fails.
-enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3, OP_F16M2 = 4 };
+// GEMM operand kind.  OP_F16M: fp16 + MX-fp6 correction lines (common.h "fp16m").  It exists for the pipelined block-GEMM kernels ONLY: a
+// launch that those kernels do not take FAILS (hipErrorInvalidValue) instead of falling back to the generic kernel, which has no MX k-loop.
+// Callers therefore pre-validate: the engine chooses the mode per call (api.cpp `mx_call`: model shape, at least 8 tokens per sequence,
+// gemm_mx_tiles_usable()) and runs the call in OP_F16X3 when any precondition fails.
+enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3 };
 
 // ---- gemm.hip ---------------------------------------------------------------------------------
 // batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
@@ -80,8 +79,6 @@ hipError_t launch_split_f16(const float* src, int64_t n, float prescale, f16* hi
 hipError_t launch_split_f16_packed(const float* src, int64_t rows, int K, f16* dst, hipStream_t s);
 // [rows, K] fp32 (row stride ld floats) x rowscale[r] (or null) -> MX operand rows of OP_F16M (common.h): weight != 0 packs the W side
 hipError_t launch_pack_mx_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s);
-// the same -> fp16m2 rows of OP_F16M2 ([K hi halves | units], 1.5 K halves per row; K % 64 == 0)
-hipError_t launch_pack_mx2_rows(const float* src, int64_t ld, int64_t rows, int K, const float* rowscale, f16* dst, int weight, hipStream_t s);
 // W [rows, K] fp32 -> per-row power-of-two scale (largest entry to [2^12, 2^13)) and its inverse, the plain fp16 copy hi [rows, K] and the
 // packed hi | lo copy pk [rows, 2K] of the scaled rows (GemmCore::w_alpha takes `alpha`)
 // dst[r, :] = src[rowmap[r], :] (gather) / dst[rowmap[r], :] = src[r, :] (scatter) over `rows` rows of C floats (C % 4 == 0)

@@ -100,9 +100,8 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   if (init_gemm_kernels() != hipSuccess) return F5HIP_ERR_HIP;
   hipStream_t s = nullptr;
   Tmp t;
-  const int op = precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : precision == F5HIP_PREC_FP16M ? OP_F16M : precision == F5HIP_PREC_FP16M2 ? OP_F16M2 : OP_F16X3;
-  const bool mx2 = op == OP_F16M2;  // fp16m2 rows: 1.5 K halves per row
-  const bool mx = op == OP_F16M || mx2;  // MX lines / rows: the pipelined tiles only (variant < 0 or >= 50)
+  const int op = precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : precision == F5HIP_PREC_FP16M ? OP_F16M : OP_F16X3;
+  const bool mx = op == OP_F16M;  // MX lines: the pipelined tiles only (variant < 0 or >= 50)
   float* a32 = t.get<float>((size_t)M * K);
   float* w32 = t.get<float>((size_t)N * K);
   float* bias = t.get<float>(N);
@@ -116,9 +115,7 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   if (fill(a32, (int64_t)M * K, 1u, 1.0f, s) != hipSuccess || fill(w32, (int64_t)N * K, 2u, 0.05f, s) != hipSuccess ||
       fill(bias, N, 3u, 0.02f, s) != hipSuccess)
     return F5HIP_ERR_HIP;
-  if (mx2) {
-    if (K % 64 || launch_pack_mx2_rows(a32, K, M, K, nullptr, ah, 0, s) != hipSuccess || launch_pack_mx2_rows(w32, K, N, K, nullptr, wh, 1, s) != hipSuccess) return F5HIP_ERR_HIP;
-  } else if (mx) {
+  if (mx) {
     if (launch_pack_mx_rows(a32, K, M, K, nullptr, ah, 0, s) != hipSuccess || launch_pack_mx_rows(w32, K, N, K, nullptr, wh, 1, s) != hipSuccess) return F5HIP_ERR_HIP;
   } else if (x3) {
     if (launch_split_f16_packed(a32, M, K, ah, s) != hipSuccess || launch_split_f16_packed(w32, N, K, wh, s) != hipSuccess) return F5HIP_ERR_HIP;
@@ -130,7 +127,6 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   g.A = op == OP_F32 ? (const void*)a32 : (const void*)ah;
   g.W = op == OP_F32 ? (const void*)w32 : (const void*)wh;
   g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
-  if (mx2) { g.lda = g.ldw = (int64_t)K * 3 / 2; }
   EpiStore e{};
   e.alpha = 1.f; e.bias = bias; e.ldo = N; e.ldres = N;
   if (epilogue == 2) {  // out-proj / FF2: x += gate * (acc + bias), fp32 residual stream
@@ -139,18 +135,16 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
   } else {               // 0: bias only, 1: FF1 (tanh-GELU); operand rows of the next GEMM
     e.act = epilogue == 1 ? ACT_GELU_TANH : ACT_NONE;
     if (op == OP_F32) e.out32 = o32;
-    else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = mx2 ? 3 : mx ? 2 : 1; e.ldo16 = mx2 ? 3 * (int64_t)N / 2 : 2 * (int64_t)N; } }
+    else { e.out16 = oh; if (x3) { e.out16_lo = oh + 32; e.pk16 = mx ? 2 : 1; e.ldo16 = 2 * (int64_t)N; } }
   }
   if (getenv("KB_CHECK") && mx) {  // MX lines against the three-term product of the same fp32 operands (generic kernel, epilogue 2: fp32 results)
-    if (epilogue != 2 && mx2) {
-      fprintf(stderr, "KB_CHECK fp16m2: epilogue 2 only here (its operand rows are checked by f5hip_bench_mx_pack and by the engine's parity tests)\n");
-    } else if (epilogue != 2) {
+    if (epilogue != 2) {
       // the MX rows this launch writes (the next GEMM's operand) against the hi | lo rows of the fp16x3 generic kernel on the same fp32
       // operands, decoded on the host: hi halves, then per half-line the coarse values and the remainders within their rounding steps
       f16 *a3 = t.get<f16>((size_t)M * K * 2), *w3 = t.get<f16>((size_t)N * K * 2), *o3 = t.get<f16>((size_t)M * N * 2);
       if (!a3 || !w3 || !o3 || launch_split_f16_packed(a32, M, K, a3, s) != hipSuccess || launch_split_f16_packed(w32, N, K, w3, s) != hipSuccess) return F5HIP_ERR_HIP;
       GemmCore g3 = g;
-      g3.A = a3; g3.W = w3; g3.lda = g3.ldw = 2 * (int64_t)K;  // (fp16m2 rows are 1.5 K halves long: the reference reads hi | lo rows)
+      g3.A = a3; g3.W = w3; g3.lda = g3.ldw = 2 * (int64_t)K;
       EpiStore e3 = e;
       e3.out16 = o3; e3.out16_lo = o3 + 32; e3.pk16 = 1;
       const size_t nh = (size_t)M * N * 2;
@@ -174,7 +168,7 @@ int f5hip_bench_gemm(f5hip_ctx* ctx, int precision, int variant, int epilogue, i
       f16 *a3 = t.get<f16>((size_t)M * K * 2), *w3 = t.get<f16>((size_t)N * K * 2);
       if (!a3 || !w3 || launch_split_f16_packed(a32, M, K, a3, s) != hipSuccess || launch_split_f16_packed(w32, N, K, w3, s) != hipSuccess) return F5HIP_ERR_HIP;
       GemmCore g3 = g;
-      g3.A = a3; g3.W = w3; g3.lda = g3.ldw = 2 * (int64_t)K;  // (fp16m2 rows are 1.5 K halves long: the reference reads hi | lo rows)
+      g3.A = a3; g3.W = w3; g3.lda = g3.ldw = 2 * (int64_t)K;
       std::vector<float> ref((size_t)M * N), got((size_t)M * N);
       for (int pass = 0; pass < 2; ++pass) {
         if (fill(res, (int64_t)M * N, 4u, 1.0f, s) != hipSuccess) return F5HIP_ERR_HIP;

@@ -251,6 +251,42 @@ def stress_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig, seed: int
     return out
 
 
+def trained_like_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Weight STATISTICS of a trained checkpoint on the seeded tensors (DiT / UNetT) — no checkpoint is reachable from the build container, and
+    Gaussian N(0, 1 / sqrt(in)) matrices flatter every quantiser: (1) heavy-tailed entries — every matrix of the per-step path (block
+    projections, AdaLN and time-MLP linears, input / output projections, text pointwise convs) is redrawn as Student-t (4 degrees of freedom:
+    kurtosis far above a Gaussian's, a few entries 6-10 sigma out) at its tensor's own standard deviation; (2) per-output-channel gains exp(N(0,
+    0.5^2)) and per-input-channel gains exp(N(0, 0.3^2)) (what learned norm gains and residual scaling leave behind in a checkpoint: rows and
+    columns whose scales differ by factors of 3-5); (3) biases redrawn with the same tails; (4) norm gains far from 1: text ConvNeXt LayerNorm
+    weights N(1, 0.3^2) clipped to [0.3, 2], their biases N(0, 0.2^2), GRN gamma N(0, 0.5^2), UNetT RMSNorm gains N(1, 0.3^2).  Same keys, same
+    shapes: loads into the reference unchanged; drawn from its own generator."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7000003 * seed + 313)
+    out = {k: v.clone() for k, v in sd.items()}
+
+    def student_t(shape):  # t_4 = N / sqrt(chi2_4 / 4), unit variance after / sqrt(2)
+        z = torch.randn(shape, generator=g)
+        chi = torch.randn((4,) + tuple(shape), generator=g).square().sum(0)
+        return z / torch.sqrt(chi / 4.0) / math.sqrt(2.0)
+
+    for k, v in sd.items():
+        if not v.is_floating_point() or k.endswith("inv_freq") or "text_embed.text_embed.weight" in k:
+            continue
+        if k.endswith(("norm.weight", ".g")):  # LayerNorm weights of the text ConvNeXt blocks, RMSNorm gains of the UNetT
+            out[k] = (1.0 + 0.3 * torch.randn(v.shape, generator=g)).clamp(0.3, 2.0)
+        elif k.endswith("norm.bias"):
+            out[k] = 0.2 * torch.randn(v.shape, generator=g)
+        elif k.endswith("grn.gamma"):
+            out[k] = 0.5 * torch.randn(v.shape, generator=g)
+        elif v.ndim == 2 and k.endswith(".weight"):
+            w = student_t(v.shape) * float(v.std())
+            w = w * torch.exp(0.5 * torch.randn(v.shape[0], 1, generator=g)) * torch.exp(0.3 * torch.randn(1, v.shape[1], generator=g))
+            out[k] = w * float(v.std() / w.std())  # the tensor keeps its overall scale: the model stays in its operating range
+        elif v.ndim == 1 and k.endswith(".bias"):
+            out[k] = student_t(v.shape) * float(v.std())
+    return out
+
+
 def synth_loud_wave(n_samples: int, seed: int = 0, batch: int = 1) -> torch.Tensor:
     """A prompt that hits the rails: ``0.6 * N(0,1)`` clipped to +-1 (about 10 % of the samples clip; rms ~= 0.55, so the RMS rule of
     ``utils_infer.py:463-465`` does not rescale it)."""

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 8
+#define F5HIP_ABI_VERSION 9  /* v9: option "mx_weights"; precision value 4 (a microbenchmark-only operand form of v8) removed */
 
 /* status codes */
 enum {
@@ -53,9 +53,9 @@ enum {
  *   FP16M   FP16X3 with the two correction terms of every product of the DiT block GEMMs (q|k|v, out, FF1, FF2) taken as ONE MX-fp6
  *           matrix instruction per 32 k instead of two fp16 ones (1.5 MFMA-equivalents per product instead of 3; same accuracy class:
  *           DESIGN.md section 2).  Backbones / shapes / options the MX path is not built for run as FP16X3 (never less accurate).
- *   FP16M2  not a mode of f5hip_sample (rejected there): names the 96-byte-row operand form of FP16M in the microbenchmarks of
- *           libf5hip_bench.so (f5hip_bench.h).  The engine uses that form inside FP16M only when F5HIP_MX2=1 is set at finalize. */
-enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2, F5HIP_PREC_FP16M = 3, F5HIP_PREC_FP16M2 = 4 };
+ *           (Value 4 named a 96-byte-row operand form of FP16M in ABI v8's microbenchmarks — an experiment that lost 13-20 % per GEMM,
+ *           now tools/experiments/removed_r05.patch; the value is rejected.) */
+enum { F5HIP_PREC_FP32 = 0, F5HIP_PREC_FP16X3 = 1, F5HIP_PREC_FP16 = 2, F5HIP_PREC_FP16M = 3 };
 
 /* Architecture of the backbone: the keyword arguments of reference src/f5_tts/model/backbones/dit.py:171-192 (DiT) /
  * unett.py:109-128 (UNetT) that change inference arithmetic. */

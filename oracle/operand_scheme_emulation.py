@@ -15,6 +15,12 @@ the planes the kernel would multiply), with the attention operands rounded to fp
           v_mfma_scale_f32_32x32x64_f8f6f4 with fp6 operands at 4x the fp16 rate, so this product costs 1 + 2/4 = 1.5 fp16 MFMAs
     mx8   the same with e4m3 elements (2x the fp16 rate: 2.0 fp16 MFMAs; same 4-bit significand, wider exponent)
     mx4   the same with e2m1 elements (fp4)
+    mx6k  mx6 with the KERNEL's blocks (round 5): one scale per 16 values — the k-set a lane owns, k = 8 q + 4 h + e of a 32-k block, not 16
+          consecutive k —, scale exponent floored at MX_MIN_EXP, the remainder taken x 2^11 before the conversion (common.h mx_pack16)
+    exact the fp32 product (isolates the other error sources)
+
+`--attn` chooses what the attention products round (round 5, the error decomposition of VERDICT r04 item 4): fp16 (the engine's default:
+q, k, P, V in fp16), fp32 (nothing), qk (q and k only), pv (P and V only).
 
     python oracle/operand_scheme_emulation.py --case base_v1_cfg1 --runs "all=x3;qkv=ahi;qkv=whi;out=ahi;all=mx6"
 
@@ -79,10 +85,36 @@ def mx_quant(x, fmt):
     return out.reshape(x.shape)
 
 
+def mx6_kernel(x, remainder):
+    """The kernel's own MX-fp6 rounding of an operand plane (common.h mx_pack16): per 32-k block the two lane sets {8 q + 4 h + e}, h = 0, 1, of
+    16 values each take their scale from the largest |VALUE| of the set (S = 2^(E - 2)); `remainder` planes (x - fp16(x)) are multiplied by
+    2^11 first (exact) and carry the scale byte E - 2 - 11, i.e. the same relative grid.  Here: x is the plane to encode, given as a pair
+    (values the scale is taken from, values to round)."""
+    vals, plane = x
+    k = vals.shape[-1]
+    assert k % 32 == 0
+    idx = torch.arange(32).reshape(4, 2, 4)            # (q, h, e) -> k = 8 q + 4 h + e
+    perm = torch.cat([idx[:, 0, :].reshape(-1), idx[:, 1, :].reshape(-1)])  # h = 0 set, then h = 1 set
+    vb = vals.reshape(*vals.shape[:-1], k // 32, 32)[..., perm].reshape(*vals.shape[:-1], k // 32, 2, 16)
+    pb = plane.reshape(*plane.shape[:-1], k // 32, 32)[..., perm].reshape(*plane.shape[:-1], k // 32, 2, 16)
+    amax = vb.abs().amax(-1, keepdim=True)
+    ex = torch.floor(torch.log2(amax.clamp_min(2.0 ** (16 - 127))))          # biased exponent floored at MX_MIN_EXP = 16
+    S = torch.exp2(ex - 2)
+    y = (pb * (2048.0 if remainder else 1.0)) / S
+    a = y.abs()
+    be = torch.floor(torch.log2(a.clamp_min(2.0 ** -40))).clamp_min(0)      # e2m3: smallest normal binade 2^0, subnormal step 2^-3
+    step = torch.exp2(be - 3)
+    q = (torch.round(a / step) * step).clamp_max(7.5)                        # v_cvt_scalef32 saturates at 7.5
+    out = torch.sign(y) * q * S / (2048.0 if remainder else 1.0)
+    inv = torch.argsort(perm)
+    return out.reshape(*plane.shape[:-1], k // 32, 32)[..., inv].reshape(plane.shape)
+
+
 class Schemes:
     """Stands in for `torch.nn.functional` inside the oracle module."""
 
-    def __init__(self, sd, plan):
+    def __init__(self, sd, plan, attn="fp16"):
+        self.attn = attn
         self.plan = plan  # class -> scheme
         self.cls = {}
         for k, v in sd.items():
@@ -128,6 +160,13 @@ class Schemes:
             y = TF.linear(xh, c["hi"]) + TF.linear(xl, c["hi"])
         elif sch == "x1":
             y = TF.linear(xh, c["hi"])
+        elif sch == "exact":
+            return TF.linear(x, w, b)
+        elif sch == "mx6k":
+            ws = c["hi"] + c["lo"]   # the conditioned weight values (the scale of a weight set is taken from them)
+            xv = xh + xl
+            y = TF.linear(xh, c["hi"]) + (TF.linear(mx6_kernel((xv, xh), False), mx6_kernel((ws, c["lo"]), True)) +
+                                          TF.linear(mx6_kernel((xv, xl), True), mx6_kernel((ws, c["hi"]), False)))
         elif sch in ("mx6", "mx8", "mx4"):
             fmt = dict(mx6="e2m3", mx8="e4m3", mx4="e2m1")[sch]
             y = TF.linear(xh, c["hi"]) + (TF.linear(mx_quant(xh, fmt), self._wq(w, "lo", fmt)) + TF.linear(mx_quant(xl, fmt), self._wq(w, "hi", fmt)))
@@ -138,15 +177,19 @@ class Schemes:
 
     def scaled_dot_product_attention(self, q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False):
         # the engine's default: plain fp16 q (pre-scaled), k, P, V; fp32 softmax and accumulators
-        q = r16(q * (q.shape[-1] ** -0.5))
-        k = r16(k)
+        if self.attn == "fp32":
+            return TF.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
+        rq = r16 if self.attn in ("fp16", "qk") else (lambda t: t)
+        rp = r16 if self.attn in ("fp16", "pv") else (lambda t: t)
+        q = rq(q * (q.shape[-1] ** -0.5))
+        k = rq(k)
         s = q @ k.transpose(-1, -2)
         if attn_mask is not None:
             s = s.masked_fill(~attn_mask, float("-inf"))
         m = s.amax(-1, keepdim=True)
         e = torch.exp(s - m)
-        e16 = r16(e)
-        return (e16 @ r16(v)) / e16.sum(-1, keepdim=True)
+        e16 = rp(e)
+        return (e16 @ rp(v)) / e16.sum(-1, keepdim=True)
 
 
 def parse_run(spec):
@@ -164,6 +207,7 @@ def main():
     ap.add_argument("--runs", default="all=x3;qkv=ahi;qkv=whi;out=ahi;out=whi;all=mx6")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--out", default="")
+    ap.add_argument("--attn", default="fp16", help="fp16 | fp32 | qk | pv, or a ;-separated list as long as --runs")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     c = MG.FULL_CASES[a.case]
@@ -172,14 +216,19 @@ def main():
     gold = torch.as_tensor(np.load(os.path.join(ROOT, "tests", "golden", a.case + ".npz"))["out"])
     ref_len = wav.shape[-1] // 256
     res = {}
-    for spec in a.runs.split(";"):
+    specs = a.runs.split(";")
+    attns = a.attn.split(";") if ";" in a.attn else [a.attn] * len(specs)
+    durs = duration.tolist() if torch.is_tensor(duration) else [int(duration)] * gold.shape[0]
+    lens_l = lens.tolist() if lens is not None else [ref_len] * gold.shape[0]
+    for spec, attn in zip(specs, attns):
         t0 = time.perf_counter()
-        O.F = Schemes(sd, parse_run(spec))
+        O.F = Schemes(sd, parse_run(spec), attn)
         try:
             out, _ = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
         finally:
             O.F = TF
-        d = (out - gold)[:, ref_len:].abs()
+        d = torch.cat([(out[b, lens_l[b]:durs[b]] - gold[b, lens_l[b]:durs[b]]).abs().reshape(-1) for b in range(gold.shape[0])])  # the generated frames of every row
+        spec = f"{spec} attn={attn}"
         res[spec] = dict(max_abs=d.max().item(), mean_abs=d.mean().item(), rms=d.pow(2).mean().sqrt().item())
         print(f"{a.case:16s} {spec:34s} max-abs {res[spec]['max_abs']:.3e}  mean-abs {res[spec]['mean_abs']:.3e}  rms {res[spec]['rms']:.3e}"
               f"   ({time.perf_counter() - t0:.0f} s)", flush=True)

@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
       default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
     }
     wr("out.bin", out);
-  } else if (mode == "attn") {  // nsplit(1|2|3) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU; 8 = ping-pong kernel]
+  } else if (mode == "attn") {  // nsplit(1|2|3) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU]
     const int nsplit = A(0), Bp = A(1), heads = A(2), n = A(3), kvs = A(4), o_packed = A(5), has_kvlen = A(6), pipe = argc > 10 ? A(7) : 0;
     const int bh = Bp * heads, ldv = (n + 7) & ~7;
     auto q = rd<f16>("q.bin"), ql = rd<f16>("q_lo.bin", true), k = rd<f16>("k.bin"), kl = rd<f16>("k_lo.bin", true);
@@ -155,10 +155,7 @@ int main(int argc, char** argv) {
       const int nw = pipe % 10, lds = flash_lds_bytes<1, 1>();
       a.log2q = 1;
       a.nqb = (n + 32 * nw - 1) / (32 * nw); a.nwg = bh * a.nqb;
-      if (pipe == 8) {  // the ping-pong kernel: 8 waves, 256 rows
-        a.nqb = (n + 255) / 256; a.nwg = bh * a.nqb;
-        hipemu::launch(dim3(a.nwg), dim3(512), lds, [&] { flash_pp_kernel<0>(a); });
-      } else if (pipe == 4) hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_pipe_kernel<4, false>(a); });
+      if (pipe == 4) hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_pipe_kernel<4, false>(a); });
       else if (pipe == 14) hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_pipe_kernel<4, true>(a); });
       else if (pipe == 6) hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_pipe_kernel<6, false>(a); });
       else hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_pipe_kernel<6, true>(a); });

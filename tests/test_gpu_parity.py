@@ -37,13 +37,15 @@ def engines():
 
     cache = {}
 
-    def get(preset, wseed, vocos=False, stress=False):
-        key = (preset, wseed, vocos, stress)
+    def get(preset, wseed, vocos=False, stress=False, trained=False):
+        key = (preset, wseed, vocos, stress, trained)
         if key not in cache:
             cfg = config.PRESETS[preset]
             sd = synth.synth_dit_state_dict(cfg, seed=wseed)
             if stress:
                 sd = synth.stress_dit_state_dict(sd, cfg, seed=wseed)
+            if trained:
+                sd = synth.trained_like_dit_state_dict(sd, cfg, seed=wseed)
             vcfg = config.VOCOS_TINY if vocos else None
             eng = F5HipEngine(cfg, vcfg, device=0)
             if vocos:
@@ -68,7 +70,8 @@ def test_sample_matches_reference_golden(engines, name, prec, tol):
 
     c = MG.CASES[name]
     cfg, wav, text, duration, lens = MG.case_inputs(c)
-    model = F5HipCFM(engines(c["preset"], c["wseed"], stress=c.get("stress", False)), precision=prec, ode_method=c.get("method", "euler"))
+    model = F5HipCFM(engines(c["preset"], c["wseed"], stress=c.get("stress", False), trained=c.get("trained", False)), precision=prec,
+                     ode_method=c.get("method", "euler"))
     out, traj = model.sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
     g = gold(name)
     steps = c["kw"]["steps"]
@@ -279,74 +282,6 @@ def test_flash_attention_equals_materialised_attention(engines):
     assert maxerr(plain, exact.cpu()) < 3e-4
 
 
-def test_ping_pong_attention_kernel_opt_in():
-    """flash_pp_kernel (8 waves, 256 query rows, the two halves a phase apart) is OFF by default — it measured 9 % slower — and kept as the
-    record of that experiment behind F5HIP_ATTN_PP=1 (read once per process: a child process).  It carries its own cu_rows / lazy-maximum /
-    key-mask logic, so it is run here against reference-minted goldens: a fixed-length case and the ragged key-mask case, padded and with
-    packed rows."""
-    import subprocess
-
-    code = """
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-import f5_tts_amd
-from f5_tts_amd import config, synth
-from f5_tts_amd.engine import F5HipCFM, F5HipEngine
-from oracle import make_golden as MG
-worst = 0.0
-for name, packed in (("tiny_v1_nfe16", 0), ("tiny_mask_ragged_b3", 0), ("tiny_mask_ragged_b3", 1)):
-    c = MG.CASES[name]
-    cfg, wav, text, duration, lens = MG.case_inputs(c)
-    eng = F5HipEngine(cfg, None, device=0)
-    eng.load_state_dict(synth.synth_dit_state_dict(cfg, seed=c["wseed"]))
-    eng.set_option("packed_rows", packed)
-    out, _ = F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
-    g = np.load(%r + "/" + name + ".npz")["out"]
-    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * out.shape[0]
-    for b, d in enumerate(durs):
-        worst = max(worst, float((out[b, :d].cpu() - torch.as_tensor(g[b, :d])).abs().max()))
-    eng.close()
-print("PP_WORST", worst)
-""" % (ROOT, GOLD)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F5HIP_ATTN_PP="1"), timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    worst = float(r.stdout.split("PP_WORST")[1].split()[0])
-    print(f"ping-pong attention kernel (F5HIP_ATTN_PP=1): worst max-abs over three goldens {worst:.2e}")
-    assert worst < X3TOL
-
-
-@pytest.mark.parametrize("name,tol", [("tiny_v1_ragged_b2", MXTOL), ("tiny_mask_ragged_b3", MXTOL), ("small_v1", 4e-4), ("base_v1_cfg1", FULL_TOL)])  # (small_v1: the bound of the Small-model test)
-def test_fp16m2_rows_opt_in(monkeypatch, name, tol):
-    """F5HIP_MX2=1 (read per finalize): fp16m with 96-byte operand rows for calls below 4096 rows — the coarse values of the correction
-    product derived in the k-loop from the `hi` fragments instead of being stored (csrc/common.h mx2_*, gemm_pp.h NSPLIT 4).  OFF by default:
-    13-20 % slower per GEMM than the 128-byte lines on the GPU (profiles/r04h_*).  Kept correct: the same goldens, a
-    tiny ragged one with packed rows too, the full-size configs[1] case; and different in the last bits from the default form (it ran)."""
-    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
-
-    full = name in MG.FULL_CASES
-    c = (MG.FULL_CASES if full else MG.CASES)[name]
-    cfg, wav, text, duration, lens = MG.case_inputs(c)
-    sd = synth.synth_dit_state_dict(cfg, seed=c["wseed"])
-    outs = {}
-    for env, packed in (("0", 0), ("1", 0)) + ((("1", 1),) if name == "tiny_mask_ragged_b3" else ()):
-        monkeypatch.setenv("F5HIP_MX2", env)
-        eng = F5HipEngine(cfg, None, device=0)
-        eng.load_state_dict(sd)
-        eng.set_option("packed_rows", packed)
-        out, _ = F5HipCFM(eng, precision="fp16m", ode_method=c.get("method", "euler")).sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
-        outs[(env, packed)] = out.cpu()
-        eng.close()
-    g = torch.as_tensor(gold(name)["out"])
-    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * g.shape[0]
-    worst = 0.0
-    for (env, packed), out in outs.items():
-        if env == "1":
-            worst = max(worst, max(float((out[b, :d] - g[b, :d]).abs().max()) for b, d in enumerate(durs)))
-    print(f"fp16m2 rows (F5HIP_MX2=1) {name}: generated-mel max-abs {worst:.2e}")
-    assert worst < tol
-    assert not torch.equal(outs[("0", 0)], outs[("1", 0)])
-
-
 @pytest.mark.parametrize("prec,tol", [("fp32", TIGHT), ("fp16x3", X3TOL)])
 def test_key_padding_mask_ragged_batch(prec, tol):
     """attn_mask_enabled=True (reference modules.py:513-516): keys beyond each utterance's duration are masked —
@@ -461,6 +396,30 @@ def test_dynamic_range_stress_golden_full_size():
             out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
             e = maxerr(out[:, 468:], g["out"][:, 468:])
             print(f"dynamic-range stress, full size, {prec}: generated-mel max-abs {e:.2e} (|mel| max {np.abs(g['out']).max():.2f})")
+            assert e < tol
+            assert maxerr(traj[1], g["traj_1"]) < tol
+    finally:
+        eng.close()
+
+
+def test_trained_like_weights_golden_full_size():
+    """no trained checkpoint is reachable from the build container, and every other golden multiplies Gaussian matrices.
+    This one is the configs[1] case on weights with a checkpoint's STATISTICS (synth.trained_like_dit_state_dict: Student-t entries — a few at
+    6-10 sigma —, per-row and per-column log-normal gains, LayerNorm / GRN / bias parameters far from their initial values), minted by the
+    reference's own CFM.sample: the margin of the fp16 + MX-fp6 operand scheme (block scales per 16 values, weight rows conditioned by
+    powers of two) where a block holds an outlier."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["base_v1_trained_like"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(MG.case_weights(c))
+    g = gold("base_v1_trained_like")
+    try:
+        for prec, tol in (("fp16m", FULL_TOL), ("fp16x3", FULL_TOL), ("fp32", TIGHT)):
+            out, traj = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, **c["kw"])
+            e = maxerr(out[:, 468:], g["out"][:, 468:])
+            print(f"trained-like weight statistics, full size, {prec}: generated-mel max-abs {e:.2e} (|mel| max {np.abs(g['out']).max():.2f})")
             assert e < tol
             assert maxerr(traj[1], g["traj_1"]) < tol
     finally:

@@ -48,13 +48,14 @@ def code_objects(tmp_path_factory):
     return out
 
 
-def pp_kernels(dis):
-    """{name: [instructions]} of the gemm_pp kernels in a disassembly."""
+def pp_kernels(dis, family="gemm_pp_kernel"):
+    """{name: [instructions]} of the gemm_pp (or, family = "gemm_p8_kernel", the ping-pong) kernels in a disassembly."""
     out, name = {}, None
+    pat = r"Li0ELi[12]ELi[12]EEv8GemmCore" if family == "gemm_pp_kernel" else r"Li0EEv8GemmCore"  # ABL = 0: not a microbenchmark ablation
     for ln in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
         if m:
-            name = m.group(1) if "gemm_pp_kernel" in m.group(1) and re.search(r"Li0ELi[12]ELi[12]EEv8GemmCore", m.group(1)) else None  # ABL = 0: not a microbenchmark ablation
+            name = m.group(1) if family in m.group(1) and re.search(pat, m.group(1)) else None
             if name:
                 out[name] = []
             continue
@@ -122,12 +123,50 @@ def kernel_metadata(co):
     return out
 
 
+def test_ping_pong_gemm_schedule(code_objects):
+    """gemm_p8.h: the steady-state loop body is a pair of k-tiles = 8 phases: 16 barriers, 16 LDS-DMA pieces (2 per phase), 8 counted waits — all
+    vmcnt(10), never 0 (five quarters stay in flight) —, 8 priority raises, 64 (plain fp16) / 48 (MX lines: 32 fp16 + 16 fp6) MFMAs, 48 fragment reads."""
+    checked = 0
+    for co in code_objects:
+        dis = subprocess.run([TOOLS[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        for name, body in pp_kernels(dis, "gemm_p8_kernel").items():
+            addr = {}
+            for idx, (ln, ins) in enumerate(body):
+                m = re.search(r"//\s*([0-9A-Fa-f]+):", ln)
+                if m:
+                    addr[int(m.group(1), 16)] = idx
+            base = int(re.search(r"//\s*([0-9A-Fa-f]+):", body[0][0]).group(1), 16)
+            loops = []
+            for idx, (ln, ins) in enumerate(body):
+                if ins.startswith("s_cbranch") or ins.startswith("s_branch"):
+                    m = re.search(r"<[^>]*\+0x([0-9a-f]+)>", ln)
+                    if m and base + int(m.group(1), 16) in addr and addr[base + int(m.group(1), 16)] < idx:
+                        loops.append((addr[base + int(m.group(1), 16)], idx))
+            loops = [(a, b) for a, b in loops if any("v_mfma" in ins for _, ins in body[a:b])]
+            assert loops, name
+            a, b = max(loops, key=lambda ab: ab[1] - ab[0])
+            loop = [ins for _, ins in body[a:b]]
+            mx = "gemm_p8_kernelILi2E" in name
+            count = lambda pre, suf="": sum(1 for i in loop if i.startswith(pre) and i.rstrip().endswith(suf))  # noqa: E731
+            vm = [int(re.search(r"vmcnt\((\d+)\)", i).group(1)) for i in loop if i.startswith("s_waitcnt") and "vmcnt" in i]
+            assert count("s_barrier") == 16 and count("buffer_load_dwordx4", "lds") == 16 and count("s_setprio 1") == 8, name
+            assert vm == [10] * 8, (name, vm)
+            assert count("v_mfma") == (48 if mx else 64) and count("ds_read_b128") == 48, (name, count("v_mfma"), count("ds_read_b128"))
+            assert not any(i.startswith("scratch_") for i in loop), name  # nothing spilled inside the loop
+            checked += 1
+    assert checked >= 10, checked
+
+
 def test_no_kernel_spills(code_objects):
+    """No kernel keeps values in scratch — with one bounded exception: the MX-line instantiations of gemm_p8_kernel park ONE landed 16-byte
+    fragment (<= 24 bytes per lane) around the last pair of k-tiles, outside the steady-state loop (test_ping_pong_gemm_schedule checks the loop
+    itself; the in-flight-read walk below covers their reads)."""
     spilled, n = [], 0
     for co in code_objects:
         for k in kernel_metadata(co):
             n += 1
-            if int(k.get("private_segment_fixed_size", "0")) > 0:
+            sz = int(k.get("private_segment_fixed_size", "0"))
+            if sz > (24 if "gemm_p8_kernelILi2E" in k["name"] else 0):
                 spilled.append((k["name"], k["private_segment_fixed_size"]))
     assert n > 100, n
     assert not spilled, spilled
@@ -173,7 +212,7 @@ def _regs(tok):
 
 
 def test_no_register_of_an_inflight_lds_read_is_reused_before_its_wait(code_objects):
-    """The fragment reads of gemm_pp.h are inline asm, so the compiler believes their destination registers are written when the read is
+    """The fragment reads of gemm_pp.h (and of the ping-pong kernel, gemm_p8.h) are inline asm, so the compiler believes their destination registers are written when the read is
     ISSUED.  A destination dword nobody uses (round 4: the zero word of an MX operand, of which the matrix instruction reads six of eight
     registers) is then free for reuse at once — hipcc put an LDS address there, and the read's late write-back turned the following reads
     into garbage: NaNs on the GPU, nothing on the host shim.  The second form of the same assumption: the copies that assemble an MX
@@ -183,7 +222,7 @@ def test_no_register_of_an_inflight_lds_read_is_reused_before_its_wait(code_obje
     checked, bad = 0, []
     for co in code_objects:
         dis = subprocess.run([TOOLS[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
-        for name, body in pp_kernels(dis).items():
+        for name, body in list(pp_kernels(dis).items()) + list(pp_kernels(dis, "gemm_p8_kernel").items()):
             addr = {}
             for idx, (ln, _) in enumerate(body):
                 m = re.search(r"//\s*([0-9A-Fa-f]+):", ln)
@@ -226,10 +265,6 @@ def test_no_register_of_an_inflight_lds_read_is_reused_before_its_wait(code_obje
                     # or read (the data is not there yet) — operands like v[10:13], v7, a[0:15]; modifiers / immediates do not parse
                     for pos, tok in enumerate(ops):
                         r = _regs(tok.split(" ")[0])
-                        if r and op == "v_cvt_scalef32_pk32_fp6_f16" and pos == 1 and len(r[1]) == 16:
-                            # fp16m2 (common.h mx2_coarse): the lane has 16 halves for a 32-half conversion; source dwords 8-15 are left
-                            # undefined on purpose and their six result codes are dropped — whatever those registers hold, in flight or not
-                            r = (r[0], set(sorted(r[1])[:8]))
                         if r and any(kind == r[0] and set(regs) & r[1] for kind, regs in pending):
                             bad.append((name[:90], ins))
                             break

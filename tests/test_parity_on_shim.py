@@ -44,13 +44,15 @@ def shim_engines(engine_emu_lib):  # noqa: F811
     mp.setattr(E.F5HipEngine, "__init__", init_on_cpu)
     cache = {}
 
-    def get(preset, wseed, vocos=False, stress=False):
-        key = (preset, wseed, vocos, stress)
+    def get(preset, wseed, vocos=False, stress=False, trained=False):
+        key = (preset, wseed, vocos, stress, trained)
         if key not in cache:
             cfg = config.PRESETS[preset]
             sd = synth.synth_dit_state_dict(cfg, seed=wseed)
             if stress:
                 sd = synth.stress_dit_state_dict(sd, cfg, seed=wseed)
+            if trained:
+                sd = synth.trained_like_dit_state_dict(sd, cfg, seed=wseed)
             vcfg = config.VOCOS_TINY if vocos else None
             eng = E.F5HipEngine(cfg, vcfg, device=0)  # a descriptor only (init_on_cpu)
             if vocos:
@@ -68,34 +70,9 @@ def shim_engines(engine_emu_lib):  # noqa: F811
 @pytest.mark.parametrize("name,prec,tol", [(n, "fp32", G.TIGHT) for n in CASES] +
                          [(n, "fp16x3", G.X3TOL) for n in (CASES if ALL_CASES else ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2"))] +
                          # fp16m: MX lines in the DiT block GEMMs (LayerNorm / flash / GELU producers, the MX k-loop); the other backbones run it as fp16x3
-                         [(n, "fp16m", G.MXTOL) for n in (CASES if ALL_CASES else ("tiny_v1_ragged_b2", "tiny_mask_ragged_b3", "tiny48_ragged_b2", "tiny_inner512", "tiny_unett_noskip"))])
+                         [(n, "fp16m", G.MXTOL) for n in (CASES if ALL_CASES else ("tiny_v1_ragged_b2", "tiny_mask_ragged_b3", "tiny48_ragged_b2", "tiny_inner512", "tiny_unett_noskip", "tiny_v1_trained_like", "tiny_unett_trained_like"))])
 def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
     G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
-
-
-@pytest.mark.parametrize("name", ["tiny_v1_ragged_b2", "tiny_inner512"])
-def test_fp16m2_rows_opt_in_on_the_shim(shim_engines, monkeypatch, name):
-    """F5HIP_MX2=1 (read per finalize): fp16m with 96-byte operand rows — the LayerNorm / flash / GELU producers in that form, the
-    conversions in the k-loop (csrc/common.h mx2_*, gemm_pp.h NSPLIT 4).  Off by default (slower on the GPU: DESIGN.md section 4); here
-    it has to match the same goldens, and differ in the last bits from the 128-byte lines — i.e. it did run."""
-    from f5_tts_amd import config, synth
-    from f5_tts_amd import engine as E
-
-    c = G.MG.CASES[name]
-    cfg, wav, text, duration, lens = G.MG.case_inputs(c)
-    outs = []
-    for env in ("0", "1"):
-        monkeypatch.setenv("F5HIP_MX2", env)
-        eng = E.F5HipEngine(config.PRESETS[c["preset"]], None, device=0)
-        eng.load_state_dict(synth.synth_dit_state_dict(config.PRESETS[c["preset"]], seed=c["wseed"]))
-        out, _ = E.F5HipCFM(eng, precision="fp16m").sample(wav, text, duration, lens=lens, **c["kw"])
-        outs.append(out.clone())
-        eng.close()
-    g = torch.as_tensor(G.gold(name)["out"])
-    durs = duration.tolist() if torch.is_tensor(duration) else [duration] * g.shape[0]
-    for b, d in enumerate(durs):
-        assert float((outs[1][b, :d] - g[b, :d]).abs().max()) < G.MXTOL
-    assert not torch.equal(outs[0], outs[1])
 
 
 def test_mel_front_ends_on_the_shim(shim_engines):
@@ -129,10 +106,10 @@ def test_mel_edge_lengths_on_the_shim(shim_engines, nw):
     G.test_mel_edge_lengths(shim_engines, nw)
 
 
-@pytest.mark.parametrize("knob", ["F5HIP_PP_VARIANT=0", "F5HIP_PP_VARIANT=57", "F5HIP_QKV_EPI_GENERIC=1", "F5HIP_PP_VARIANT=80"])
+@pytest.mark.parametrize("knob", ["F5HIP_PP_VARIANT=0", "F5HIP_PP_VARIANT=57", "F5HIP_PP_VARIANT=80"])
 def test_fp16m_under_the_tuning_knobs(knob):
     """The knobs INTEGRATION.md lists as 'no change of the arithmetic contract' are read once per process, so each runs in a child: a forced
-    tile that has no MX instantiation (57), 'never the pipelined kernel' (0) and the general q|k|v index path used to fail EVERY fp16m call
+    tile that has no MX instantiation (57) and 'never the pipelined kernel' (0) used to fail EVERY fp16m call
     (ADVICE r04); now the call runs in fp16x3.  A forced tile that IS instantiated for MX lines (80, the ping-pong kernel) stays in fp16m."""
     import subprocess
 

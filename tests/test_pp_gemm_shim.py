@@ -185,29 +185,6 @@ def test_pp_qkv_epilogue_on_mx_lines(emu_engine, capfd, variant):  # noqa: F811
     assert diff == 0, err
 
 
-# ---- fp16m2: the MX rows without their coarse values (96 bytes per 32 k; the k-loop derives c6 from the hi fragments) --------------------------
-MX2_CASES = [(55, 250, 160), (56, 250, 224), (59, 130, 160)]
-
-
-@pytest.mark.parametrize("variant,M,N", MX2_CASES)
-def test_pp_mx2_rows_product_close_to_the_three_term_product(emu_engine, capfd, variant, M, N):  # noqa: F811
-    from f5_tts_amd import binding, config
-
-    eng = emu_engine(config.DIT_TINY)
-    os.environ["KB_CHECK"] = "1"
-    try:
-        ms = C.c_double()
-        st = eng.bench_lib.f5hip_bench_gemm(eng._ctx, binding.PRECISIONS["fp16m2"], variant, 2, M, N, 384, 1, C.byref(ms))  # 6 k-tiles of 64 (>= 3 per k-split group)
-    finally:
-        os.environ.pop("KB_CHECK", None)
-    err = capfd.readouterr().err
-    assert st == 0, err
-    m = re.search(r"KB_CHECK fp16m variant \d+: max \|diff\| (\S+) mean (\S+) of max \|value\| (\S+)", err)
-    assert m, err
-    d, mean, v = (float(x) for x in m.groups())
-    assert v > 0 and 0 < d <= 1e-4 * v and mean <= 1e-5 * v, err
-
-
 def test_tile_grouping_covers_every_tile_with_a_ragged_last_group():
     """GemmCore::group_m (row tiles per group, row tile fastest inside a group: gemm.hip default_group_m picks 5 for the wide one-round
     launches since round 4, 4 from 8192 rows) is read from F5HIP_GEMM_GROUPM once per process, so a child process runs a few of the

@@ -124,7 +124,6 @@ mx)
     done; } > $out/kernel_bench_mx.log 2>&1
   cat $out/kernel_bench_mx.log | cut -c1-260
   for prec in fp16x3 fp16m fp16x3 fp16m; do timeout 600 python bench.py --steps 10 --warmup 3 --precision $prec --no-cpu-baseline --no-other-configs >> $out/bench_b1_ab.jsonl 2> $out/bench.err; done
-  F5HIP_MX_KSS=0 timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16m --no-cpu-baseline --no-other-configs >> $out/bench_b1_ab.jsonl 2>> $out/bench.err  # last line: without the k-step-split MX tiles
   python - $out/bench_b1_ab.jsonl <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
@@ -134,28 +133,6 @@ PY
   for prec in fp16x3 fp16m; do timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --precision $prec --no-cpu-baseline > $out/bench_b32_nfe32_$prec.json 2>> $out/bench.err; line $out/bench_b32_nfe32_$prec.json b32_$prec; done
   timeout 600 python bench.py --steps 3 --warmup 1 --batch 8 --precision fp16m --no-cpu-baseline > $out/bench_b8_fp16m.json 2>> $out/bench.err; line $out/bench_b8_fp16m.json b8_fp16m
   for prec in fp16x3 fp16m; do timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 --precision $prec --no-cpu-baseline > $out/bench_e2_b8_bigvgan_$prec.json 2>> $out/bench.err; line $out/bench_e2_b8_bigvgan_$prec.json e2_b8_$prec; done ;;
-mx2)
-  # fp16m2 (the 96-byte-per-32-k rows of the one-round launches) against fp16m's MX lines: kernel check, kernel times, parity, B=1 A/B
-  tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-  B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048;1406,2048,1024;1406,1024,2048"
-  { KB_CHECK=1 KB_SHAPES="2812,1024,1024;1406,2048,1024" KB_PRECS=fp16m2 KB_EPI=2 KB_VARIANTS=55,56,59 timeout 200 python tools/kernel_bench.py gemm 2>&1 | grep -E "KB_CHECK" | head -8
-    for epi in 1 2; do
-      KB_SHAPES=$B1 KB_PRECS=fp16m KB_EPI=$epi KB_VARIANTS=-1 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-330
-      KB_SHAPES=$B1 KB_PRECS=fp16m2 KB_EPI=$epi KB_VARIANTS=-1,55,56,59 timeout 300 python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/epi$epi /" | cut -c1-400
-    done; } > $out/kernel_bench_mx2.log 2>&1
-  cat $out/kernel_bench_mx2.log | cut -c1-260
-  F5HIP_MX2=1 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs4 or packed_rows" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m2.log; tail -30 $out/gpu_tests_fp16m2.log
-  for i in 1 2; do
-    timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16m --no-cpu-baseline --no-other-configs >> $out/bench_b1_ab.jsonl 2>> $out/bench.err
-    F5HIP_MX2=1 timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16m --no-cpu-baseline --no-other-configs >> $out/bench_b1_ab.jsonl 2>> $out/bench.err
-  done
-  python - $out/bench_b1_ab.jsonl <<'PY'
-import json, sys
-for i, l in enumerate(open(sys.argv[1])):
-    d = json.loads(l); r = d.get("roofline", {})
-    print("B=1", "lines" if i % 2 == 0 else "rows ", "ms/step", round(d["ms_per_step"], 2), "roofline.frac", round(r.get("frac", 0), 4), {k: round(v, 1) for k, v in d.get("kernel_classes_ms", {}).items() if v > 1})
-PY
-  tail -3 $out/bench.err ;;
 tests)
   timeout 1800 python -m pytest ${@:-tests -q -m gpu} 2>&1 | tail -5 ;;
 bench)
