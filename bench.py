@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--model", default="F5TTS_v1_Base")
     ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
     ap.add_argument("--bigvgan-conv-impl", type=int, default=-1, help="BigVGAN conv implementation 0 / 1 / 2 (-1 = the library default)")
+    ap.add_argument("--attn-impl", type=int, default=-1,
+                    help="engine option attn_impl (-1: the library's default; 4: scores from hi/lo-split q, k; 2: every attention operand split; 3: plain fp16 everywhere)")
     ap.add_argument("--attn-kv-split", type=int, default=1, help="key ranges per query block in the flash kernel (1 = off, the default)")
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
                     help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
@@ -260,6 +262,8 @@ def main():
     if not a.no_graph:
         eng.set_option("use_graph", 1)
     eng.set_option("branch_streams", a.branch_streams)
+    if a.attn_impl >= 0:
+        eng.set_option("attn_impl", a.attn_impl)
     if a.attn_kv_split > 1:
         eng.set_option("attn_kv_split", a.attn_kv_split)
     if big:  # the generator is a context of its own (as in the reference); every rank builds the same seeded weights

@@ -1,5 +1,6 @@
-"""Generated-mel error of the fp16x3 mode against the reference-minted goldens with the attention scores computed from hi/lo-split q, k
-(attn_impl 4, 3 MFMAs per product) and from plain fp16 q, k (attn_impl 0, the default: 1 MFMA): python tools/attn_precision_check.py  (GPU box)."""
+"""Generated-mel error of a half-precision parity mode (ATTN_PREC = fp16m (default) | fp16x3) against the reference-minted goldens with
+the attention computed from hi/lo-split q, k (attn_impl 4: 3 MFMAs per score product), from everything split (attn_impl 2) and from plain fp16 q, k,
+P, V (attn_impl 0): python tools/attn_precision_check.py [golden names]  (GPU box)."""
 import os
 import sys
 
@@ -25,11 +26,14 @@ for name in names:
     eng.load_state_dict(MG.case_weights(c))
     g = np.load(os.path.join(GOLD, name + ".npz"))["out"]
     res = []
-    for impl in (4, 0):
+    prec = os.environ.get("ATTN_PREC", "fp16m")
+    durs = duration.tolist() if torch.is_tensor(duration) else [int(duration)] * g.shape[0]
+    for impl in (4, 2, 0):
         eng.set_option("attn_impl", impl)
-        model = F5HipCFM(eng, precision="fp16x3", ode_method=c.get("method", "euler"))
+        model = F5HipCFM(eng, precision=prec, ode_method=c.get("method", "euler"))
         out, _ = model.sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
-        d = (out.cpu() - torch.from_numpy(g)).abs()
+        d = torch.cat([(out[b, :durs[b]].cpu() - torch.from_numpy(g[b, :durs[b]])).abs().reshape(-1) for b in range(g.shape[0])])
         res.append((float(d.max()), float(d.mean())))
-    print(f"{name:28s} split q,k: max {res[0][0]:.2e} mean {res[0][1]:.2e}   plain fp16 q,k: max {res[1][0]:.2e} mean {res[1][1]:.2e}   |mel| max {np.abs(g).max():.2f}", flush=True)
+    print(f"{name:28s} {prec} split q,k: max {res[0][0]:.2e} mean {res[0][1]:.2e}   all split: max {res[1][0]:.2e}   plain fp16 q,k: max {res[2][0]:.2e} mean {res[2][1]:.2e}"
+          f"   |mel| max {np.abs(g).max():.2f}", flush=True)
     eng.close()
