@@ -385,16 +385,25 @@ WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f1
   return WOp{w, it == ctx->walpha.end() ? nullptr : it->second};
 }
 
-// fp16x3 mode: are the attention SCORES computed from hi/lo-split q and k (3 MFMAs per product)?  Only on request (attn_impl 2: every
-// attention operand split; 4: q, k split, P and V plain — the default of round 1).  The default since round 2 is plain fp16 q, k, P, V:
-// measured on every reference-minted golden (tools/attn_precision_check.py) the generated mel moves from <= 1.4e-4 to
-// <= 2.9e-4 max-abs against a 1e-3 tolerance, for a third of the attention's MFMA work.
+// What the attention SCORES are computed from in the half-precision parity modes (fp16x3, fp16m):
+//   QK_PLAIN  fp16 q, k — 1 MFMA per product (attn_impl 3: the default of rounds 2-4; always in the plain fp16 mode)
+//   QK_SPLIT  hi/lo-split q and k, 3 MFMAs per product (attn_impl 4; attn_impl 2 splits P and V as well)
+//   QK_MX     fp16 hi . hi + both correction products as one MX-fp6 MFMA per 32 head channels, 1.5 MFMA-equivalents (attn_impl 0 / 5: the
+//             default since round 5) — where the q|k|v GEMM runs a pipelined kernel, whose epilogue packs the P words; else QK_SPLIT.
+// Rounds 2-4 ran plain fp16 scores after measuring <= 2.9e-4 max-abs on every golden minted from seeded Gaussian weights.  Round 5's
+// trained-like golden (heavy-tailed weights, per-channel gains: larger logits) moves by 1.1e-3 with them — over the 1e-3 tolerance — by
+// 5.8e-4 with split q, k and by 3.7e-4 with everything split (profiles/r05g_attn_precision_fp16m.log): the scores feed an
+// exponential, so their ABSOLUTE error counts, and it grows with the logits.
+enum { QK_PLAIN = 0, QK_SPLIT = 1, QK_MX = 2 };
+int qk_scheme_wanted(const f5hip_ctx* ctx, int op) {
+  if (op != OP_F16X3 || ctx->attn_impl == 3) return QK_PLAIN;
+  return ctx->attn_impl == 2 || ctx->attn_impl == 4 ? QK_SPLIT : QK_MX;
+}
 // SDPA's default 1/sqrt(dim_head) on q (modules.py:511-520).  The flash kernel takes q with log2(e) folded in as well: its exponentials are
 // base-2 (v_exp_f32) and its scores then need no multiply — and the lazy reference maximum becomes possible (attention_kernel.h LAZY).  The
 // materialised fp32 path (exact_attn) softmaxes natural-log scores.
 float attn_qscale(int dh, bool exact_attn) { return (exact_attn ? 1.0f : 1.4426950408889634f) / sqrtf((float)dh); }
 
-bool split_qk(const f5hip_ctx* ctx, int op) { return op == OP_F16X3 && (ctx->attn_impl == 2 || ctx->attn_impl == 4); }
 
 // FP16M: fp16x3 everywhere except the four block GEMMs of the DiT backbone, which read MX lines when ctx->mx_call says so (f5hip_sample)
 int op_of(int precision) { return precision == F5HIP_PREC_FP32 ? OP_F32 : precision == F5HIP_PREC_FP16 ? OP_F16 : OP_F16X3; }
@@ -889,7 +898,7 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
 
 // ---- attention over [2B * H] (batch', head) slabs of ns tokens: q/k/v were written by the QKV epilogue -------------------------------
 // S sequences starting at sequence s0 of the packed [cond | uncond] batch (o32/o_hi/o_lo/kvlen are already offset by the caller)
-int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
+int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn, int qks, const int32_t* kvlen, float* o32, f16* o_hi, f16* o_lo, int pk,
                   int64_t ldO, hipStream_t st, const int32_t* kvlen2 = nullptr, int seg2_off = 0, const int32_t* cu_rows = nullptr) {
   const auto& c = ctx->cfg;
   const int H = c.heads, dh = c.dim_head, inner = H * dh;
@@ -917,14 +926,13 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         }
         HIPCHK(launch_gemm_store(OP_F32, g, e2, S * H, st));
       } else {
-        // fp16x3 default: plain fp16 q, k, P, V (fp32 softmax statistics and accumulators) — every reference-minted golden stays within
-        // 2.8e-4 of the reference (tolerance 1e-3; profiles/r02d_attn_precision.log); attn_impl 4 splits q, k, attn_impl 2 everything
-        const bool x3 = split_qk(ctx, op);
+        // qks: what the q|k|v epilogue of this chunk left in the second planes of q and k (run_qkv) — nothing, fp16 remainders or MX P words
+        const bool x3 = qks == QK_SPLIT, all3 = x3 && ctx->attn_impl == 2, lo = qks != QK_PLAIN;
         const int ldv = (n + 7) & ~7;
         const int64_t voff = (int64_t)s0 * inner * ldv;
-        HIPCHK(launch_flash_attn(x3 ? (ctx->attn_impl == 2 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, x3 ? ctx->q16_lo.as<f16>() + qoff : nullptr,
-                                 ctx->k16.as<f16>() + qoff, x3 ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
-                                 x3 && ctx->attn_impl == 2 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
+        HIPCHK(launch_flash_attn(qks == QK_MX ? 4 : x3 ? (all3 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, lo ? ctx->q16_lo.as<f16>() + qoff : nullptr,
+                                 ctx->k16.as<f16>() + qoff, lo ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
+                                 all3 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
                                  kvlen2, seg2_off, 1, ctx->attn_part.p ? ctx->attn_kv_split : 1,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 : nullptr,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr,
@@ -938,7 +946,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
 // ---- fused to_q|to_k|to_v GEMM of one block: bias + rope + 1/sqrt(dh) + head split in the epilogue (modules.py:481-509; SDPA default
 // scale).  M rows = sequences [s0, s0 + M/ns) of ns tokens.  With qk_norm the epilogue leaves q and k raw (fp32, bias only) and
 // qk_norm_rope_kernel applies RMSNorm(dim_head) -> rope -> scale and writes what the attention kernels read (modules.py:493-509).
-int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M, int ns, int s0, int op, bool exact_attn, int wbytes,
+// *qks: what the second planes of q and k hold afterwards (QK_*: run_attention's argument)
+int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M, int ns, int s0, int op, bool exact_attn, int* qks, int wbytes,
             hipStream_t st, const uint32_t* rowinfo = nullptr, int nslab = 0) {
   const auto& c = ctx->cfg;
   const int D = c.dim, H = c.heads, dh = c.dim_head, inner = H * dh;
@@ -956,14 +965,18 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     e.ldvt = (ns + 7) & ~7;
     const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
     e.q16 = ctx->q16.as<f16>() + qoff; e.k16 = ctx->k16.as<f16>() + qoff; e.vt16 = ctx->vt16.as<f16>() + voff;
-    if (split_qk(ctx, op == OP_F16M ? OP_F16X3 : op)) {  // lo planes only for what the flash kernel will read
-      e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
-      if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
-    }
+  }
+  GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk, bw.wqkv_mx), ldA, M, 3 * inner, D));
+  *qks = exact_attn ? QK_PLAIN : qk_scheme_wanted(ctx, op == OP_F16M ? OP_F16X3 : op);
+  if (*qks == QK_MX && !gemm_qkv_takes_pp(op, g, e)) *qks = QK_SPLIT;  // the generic kernels and the qk_norm detour write fp16 remainders
+  if (*qks != QK_PLAIN) {  // second planes only for what the flash kernel will read
+    const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
+    e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
+    e.mx_qk = *qks == QK_MX;
+    if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
-    GemmCore g = (core(A, ldA, wsel(ctx, op, bw.wqkv, bw.wqkv_hi, bw.wqkv_pk, bw.wqkv_mx), ldA, M, 3 * inner, D));
     HIPCHK(launch_gemm_qkv(op, g, e, st));
   }
   if (c.qk_norm) {
@@ -1009,8 +1022,9 @@ int run_blocks_packed(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, int
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(launch_layernorm(x, D, Mp, D, 1e-6f, nullptr, nullptr, md + D, md, nullptr, a_hi, a_lo, D, st, pkb, ldAb));
     }
-    CHK(run_qkv(ctx, bw, a_hi, ldAb, Mp, n, s0, opb, false, wbytes, st, rowinfo, nb * B));
-    CHK(run_attention(ctx, S, s0, n, op, false, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pkb, ldOb, st, nullptr, 0, cu));
+    int qks = QK_PLAIN;
+    CHK(run_qkv(ctx, bw, a_hi, ldAb, Mp, n, s0, opb, false, &qks, wbytes, st, rowinfo, nb * B));
+    CHK(run_attention(ctx, S, s0, n, op, false, qks, kvlen, nullptr, o_all, pk ? o_all + 32 : nullptr, pkb, ldOb, st, nullptr, 0, cu));
     {
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(Mp, D, inner), (double)Mp * inner * wbytes + (double)inner * D * wbytes + 2.0 * Mp * D * 4);
       GemmCore g = core(o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, Mp, D, inner);
@@ -1151,8 +1165,9 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(launch_layernorm(x, D, M, D, 1e-6f, nullptr, nullptr, md + D, md, a32, a_hi, a_lo, D, st, pkb, ldAb));
     }
-    CHK(run_qkv(ctx, bw, A, ldAb, M, n, s0, opb, exact_attn, wbytes, st));
-    CHK(run_attention(ctx, S, s0, n, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
+    int qks = QK_PLAIN;
+    CHK(run_qkv(ctx, bw, A, ldAb, M, n, s0, opb, exact_attn, &qks, wbytes, st));
+    CHK(run_attention(ctx, S, s0, n, op, exact_attn, qks, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
     {  // to_out + mask + gated residual: x += gate_msa * masked(attn) (modules.py:548-556,751)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), (double)M * inner * wbytes + (double)inner * D * wbytes + 2.0 * M * D * 4);
       GemmCore g = (core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, M, D, inner));
@@ -1298,8 +1313,9 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
       Prof pr(ctx, st, KC_LNMOD, 0, ln_bytes);
       HIPCHK(launch_layernorm(x, D, M, D, 0.f, bw.g_attn, nullptr, nullptr, nullptr, a32, a_hi, a_lo, D, st, pkb, ldAb, 1));
     }
-    CHK(run_qkv(ctx, bw, A, ldAb, M, ns, s0, opb, exact_attn, wbytes, st));
-    CHK(run_attention(ctx, S, s0, ns, op, exact_attn, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
+    int qks = QK_PLAIN;
+    CHK(run_qkv(ctx, bw, A, ldAb, M, ns, s0, opb, exact_attn, &qks, wbytes, st));
+    CHK(run_attention(ctx, S, s0, ns, op, exact_attn, qks, kvlen, o32, o_hi, o_lo, pkb, ldOb, st));
     {  // x = attn(...) + x, padded rows of the attention output zero-filled (modules.py:548-556; unett.py:300)
       Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, D, inner), 0);
       GemmCore g = core(op == OP_F32 ? (const void*)o32 : (const void*)o_hi, ldOb, wsel(ctx, opb, bw.wo, bw.wo_hi, bw.wo_pk, bw.wo_mx), ldOb, M, D, inner);
@@ -1437,6 +1453,8 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
   const float* mods_step = ctx->mods.as<float>() + (int64_t)step * c.depth * 6 * D;
   const float* cmods_step = ctx->cmods.as<float>() + (int64_t)step * ((c.depth - 1) * 6 + 2) * D;
 
+  // the joint slabs are written by two launches (and the qk_norm detour): MX P words are not offered here, the precise scores are the split's
+  const int qks = exact_attn ? QK_PLAIN : (qk_scheme_wanted(ctx, op) == QK_PLAIN ? QK_PLAIN : QK_SPLIT);
   // fused q|k|v projection of one stream into the joint slabs
   auto qkv = [&](const BlockW& bw, bool text) -> int {
     const int M = text ? Mc : Mx, nseq = text ? nt : n;
@@ -1452,7 +1470,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
     } else {
       e.ldvt = (ns + 7) & ~7;
       e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>();
-      if (split_qk(ctx, op)) {
+      if (qks != QK_PLAIN) {
         e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
         if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
       }
@@ -1507,11 +1525,11 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
       Prof pr(ctx, st, KC_ELEMWISE, 0, 0);
       HIPCHK(launch_qk_norm_rope(ctx->q32.as<float>(), ctx->k32.as<float>(), bw.qn, bw.kn, ctx->rope.as<float>(), (int64_t)S * H * ns, ns, H, dh, -1,
                                  attn_qscale(dh, exact_attn), 1e-6f, exact_attn ? nullptr : ctx->q16.as<f16>(),
-                                 (!exact_attn && split_qk(ctx, op)) ? ctx->q16_lo.as<f16>() : nullptr,
+                                 (!exact_attn && qks != QK_PLAIN) ? ctx->q16_lo.as<f16>() : nullptr,
                                  exact_attn ? nullptr : ctx->k16.as<f16>(),
-                                 (!exact_attn && split_qk(ctx, op)) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));
+                                 (!exact_attn && qks != QK_PLAIN) ? ctx->k16_lo.as<f16>() : nullptr, st, n, bw.qn_c, bw.kn_c));
     }
-    CHK(run_attention(ctx, S, 0, ns, op, exact_attn, kvlen, op == OP_F32 ? reinterpret_cast<float*>(o_base) : nullptr,
+    CHK(run_attention(ctx, S, 0, ns, op, exact_attn, qks, kvlen, op == OP_F32 ? reinterpret_cast<float*>(o_base) : nullptr,
                       op != OP_F32 ? reinterpret_cast<f16*>(o_base) : nullptr, pk ? reinterpret_cast<f16*>(o_base) + 32 : nullptr, pk, ldO, st, kvlen2, n));
     if (!last) {  // text stream (modules.py:829-837)
       CHK(out_proj(true, wsel(ctx, op, bw.wo_c, bw.wo_c_hi, bw.wo_c_pk), bw.bo_c, mc + 2 * D, cs));
@@ -1822,9 +1840,9 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   CHK(scope.begin());
   const auto& c = ctx->cfg;
   const int op = op_of(precision);
-  // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 / fp16x3 -> flash attention with plain fp16 operands), 1 force materialised,
-  // 4 flash with split q, k and plain P, V (fp16x3),
-  // 2 flash with every operand split in fp16x3 mode, 3 flash with plain fp16 operands even in fp16x3 mode
+  // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 -> flash attention, plain fp16 operands; fp16x3 / fp16m -> flash attention with
+  // MX-corrected scores, qk_scheme_wanted above), 1 force materialised, 2 flash with every operand split, 3 flash with plain fp16 operands
+  // in every mode (the default of rounds 2-4), 4 flash with split q, k and plain P, V, 5 = 0 for the half-precision modes
   const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
   const int mel = c.mel_dim, D = c.dim;

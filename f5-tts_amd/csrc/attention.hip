@@ -15,8 +15,9 @@
 // fragment is read in the matching key order (two ds_read_b64 per fragment) — no cross-lane shuffles for P.
 // V arrives transposed ([BH, 64, ldv], written by the QKV epilogue) so both tiles are plain 16-byte row copies.
 //
-// NSPLIT/PVSPLIT == 3: fp16 hi/lo split operands (q, k / v, P), 3 MFMAs per product, ~fp32 accuracy (parity mode
-// "fp16x3"); == 1: plain fp16 operands.  Softmax statistics, P and O accumulate in fp32 in all variants.
+// NSPLIT/PVSPLIT == 3: fp16 hi/lo split operands (q, k / v, P), 3 MFMAs per product, ~fp32 accuracy; == 1: plain fp16 operands;
+// NSPLIT == 2: fp16 hi . hi + MX-fp6 corrections for the scores (the default of the parity modes since round 5).  Softmax statistics, P and
+// O accumulate in fp32 in all variants.
 #include "attention_kernel.h"
 
 namespace {
@@ -102,6 +103,7 @@ hipError_t init_attention_kernels() {
   hipError_t e;
   if ((e = set_attr_pipe<6, true>()) != hipSuccess) return e;
   if ((e = set_attr<1, 1>()) != hipSuccess) return e;
+  if ((e = set_attr<2, 1>()) != hipSuccess) return e;
   if ((e = set_attr<3, 1>()) != hipSuccess) return e;
   return set_attr<3, 3>();
 }
@@ -124,6 +126,10 @@ hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f1
   if (nsplit == 3) {  // hi/lo q, k, v, P
     if (!q_lo || !k_lo || !vt_lo) return hipErrorInvalidValue;
     return launch<3, 3>(a, bh, co_launches < 1 ? 1 : co_launches, s);
+  }
+  if (nsplit == 4) {  // scores = fp16 hi . hi + the two correction products as MX-fp6 (q_lo, k_lo hold P words), plain fp16 P and V
+    if (!q_lo || !k_lo || ((reinterpret_cast<uintptr_t>(q_lo) | reinterpret_cast<uintptr_t>(k_lo)) & 15)) return hipErrorInvalidValue;
+    return launch<2, 1>(a, bh, co_launches < 1 ? 1 : co_launches, s);
   }
   if (nsplit == 2) {  // hi/lo q and k (scores), plain fp16 P and V
     if (!q_lo || !k_lo) return hipErrorInvalidValue;

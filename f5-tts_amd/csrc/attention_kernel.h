@@ -100,12 +100,16 @@ __device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16
     }
 }
 
-// NSPLIT: operand split of S = QK^T (1 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
+// NSPLIT: operand split of S = QK^T (1, 2 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
 // their rounding matters ~10x more than that of P and V: NSPLIT = 3 with PVSPLIT = 1 keeps near-fp32 scores at 4 instead of 6
-// MFMAs per key-query pair.
+// MFMAs per key-query pair.  NSPLIT = 2 (round 5): the two correction products K_hi . Q_lo + K_lo . Q_hi of the split as ONE MX-fp6 MFMA per
+// 32 head channels (common.h, "fp16 + MX-fp6 corrections": the block GEMMs' scheme) — 6 MFMAs per 32 keys x 32 queries where NSPLIT = 3
+// takes 12 and plain fp16 takes 4.  The second plane of q and of k then holds, per row, the P words of its two 32-channel blocks:
+// [block 0: P_0 | P_1][block 1: P_0 | P_1], 32 bytes each, q packed as the activation and k as the weight (the QKV epilogue writes both
+// from the lane's own 16 channels, gemm_pp.h PpEpiQKV::mx_qk).
 template <int NSPLIT, int PVSPLIT>
 constexpr int flash_lds_bytes() {
-  return 2 * ((NSPLIT == 3 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
+  return 2 * ((NSPLIT >= 2 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
 }
 
 // NW: waves per workgroup = 32-row query groups per block.  4 (128 query rows, two workgroups per CU) everywhere except where 6
@@ -120,8 +124,10 @@ constexpr float LAZY_TAU = 8.0f;
 template <int NSPLIT, int PVSPLIT, int NW = 4, bool SPLIT = false, bool VSUM = false, bool LAZY = false>  // VSUM: A/B switch — row sums on the VALU (round 1)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(FlashArgs a) {
   static_assert(!(LAZY && SPLIT), "the key-split partial results carry exact maxima");
-  constexpr int NPL = NSPLIT == 3 ? 2 : 1;    // planes of q and k
+  static_assert(NSPLIT == 1 || NSPLIT == 2 || NSPLIT == 3, "operands of the scores: plain, fp16 + MX corrections, hi/lo split");
+  constexpr int NPL = NSPLIT >= 2 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
+  constexpr bool MXQK = NSPLIT == 2;          // plane 1 = P words
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
   F5_DYN_LDS(char, smem);
 
@@ -166,14 +172,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   }
   if constexpr (NPV == 2) Vr[1] = make_rsrc(a.vt_lo + (int64_t)bh * 64 * a.ldv, v_bytes);
 
-  // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]
+  // Q rows of this wave stay in registers for the whole kernel: fq[p][ks] = Q[q][16 ks + 8 hi .. +7]; MXQK: plane 1 is read as the P words
+  // of the lane's half-wave, fq[1][2 blk], fq[1][2 blk + 1] = the 32 bytes of P_hi of channel block blk
   const int qrow = qb * (32 * NW) + wave * 32 + ql;
   Frag fq[NPL][4];
 #pragma unroll
   for (int p = 0; p < NPL; ++p)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      fq[p][ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp[p] + (int64_t)qrow * 64 + ks * 16 + hi * 8) : make_uint4(0, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) {
+      const int off = MXQK && p == 1 ? (ks >> 1) * 32 + hi * 16 + (ks & 1) * 8 : ks * 16 + hi * 8;
+      fq[p][ks].u = qrow < n ? *reinterpret_cast<const uint4*>(Qp[p] + (int64_t)qrow * 64 + off) : make_uint4(0, 0, 0, 0);
+    }
 
   // thread -> 16-byte chunk c = tid + 256 i of a tile: K tile row = key (c >> 3), V^T tile row = d (c >> 3), 8 chunks per row
   uint32_t k_off[2], v_off[2];
@@ -243,17 +252,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     f32x16 s[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[0][r] = LAZY ? negm[r] : 0.f; s[1][r] = LAZY ? negm[r] : 0.f; }
+    Frag fkp;  // (MXQK) the first half of a block's P words
+    fkp.u = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         Frag fk[NPL];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) fk[p].u = *reinterpret_cast<const uint4*>(sK + p * K_PLANE + kb * 32 * K_ROWB + ks * 32);
+        for (int p = 0; p < NPL; ++p) {
+          // MXQK, plane 1: the half-wave's P words of block ks >> 1 — fetched with the fragment of the same index, used at the odd one
+          const int off = MXQK && p == 1 ? (ks >> 1) * 64 + hi * 16 + (ks & 1) * 16 : ks * 32;
+          fk[p].u = *reinterpret_cast<const uint4*>(sK + p * K_PLANE + kb * 32 * K_ROWB + off);
+        }
         Mma32<f16>::mma(s[kb], fk[0], fq[0][ks]);
-        if constexpr (NPL == 2) {
+        if constexpr (NSPLIT == 3) {
           Mma32<f16>::mma(s[kb], fk[0], fq[1][ks]);  // K_hi . Q_lo
           Mma32<f16>::mma(s[kb], fk[1], fq[0][ks]);  // K_lo . Q_hi
+        }
+        if constexpr (MXQK) {
+          if (ks & 1) mx_mma(s[kb], fkp.u, fk[1].u, fq[1][ks - 1].u, fq[1][ks].u);  // both correction products of channels 32 (ks >> 1) .. + 31
+          else fkp = fk[1];
         }
       }
 

@@ -248,8 +248,9 @@ struct f5hip_ctx {
   // options / measurement
   bool use_graph = false;
   bool profile = false;
-  int attn_impl = 0;  // 0 auto (fp32: materialised scores; fp16 / fp16x3: flash attention, plain fp16 operands), 1 materialised fp32,
-                      // 2 flash with all operands split (fp16x3), 3 = 0 for the fp16 modes, 4 flash with split q/k + plain P/V (fp16x3)
+  int attn_impl = 0;  // 0 auto (fp32: materialised scores; fp16: flash attention, plain fp16 operands; fp16x3 / fp16m: flash attention, scores
+                      // from fp16 hi . hi + MX-fp6 corrections), 1 materialised fp32, 2 flash with all operands split, 3 flash with plain
+                      // fp16 operands in every mode, 4 flash with split q, k + plain P, V, 5 = 0 (api.cpp qk_scheme_wanted)
   KStat stats[KC_COUNT];
   std::vector<ProfRec> prof;
 

@@ -150,6 +150,8 @@ struct EpiQKVT {
   // token m % nseq of sequence m / nseq — the block GEMMs then run over the VALID rows of a ragged batch only (null = padded layout).
   const uint32_t* rowinfo;
   int nslab;            // packed rows: number of sequences the q / k / V^T slabs hold (bounds of the pipelined kernel's buffer descriptors)
+  int mx_qk;            // the lo planes of q and k receive MX-fp6 P words (gemm_pp.h PpEpiQKV::mx_qk): pipelined kernels only — a launch that
+                        // cannot take one fails (ask gemm_qkv_takes_pp first)
   int fast;             // set by epi_qkv_prepare (host bookkeeping; the kernels do not read it)
   int inner_;           // heads * dh
   int dh_shift;         // log2(dh)

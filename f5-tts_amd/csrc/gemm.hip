@@ -450,29 +450,44 @@ hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& 
   return dispatch<EpiStore>(op, g, e, batch, variant, s);
 }
 hipError_t launch_gemm_qkv(int op, const GemmCore& g0, const EpiQKV& e0, hipStream_t s) { return launch_gemm_qkv_variant(op, g0, e0, -1, s); }
+namespace {
+// Does this q|k|v launch go to a pipelined kernel (half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour), and which?
+// e: prepared (epi_qkv_prepare).  Fills the tile and the sizes of the q / k and V^T slabs.
+bool qkv_pp_plan(int op, const GemmCore& g0, const EpiQKV& e, int want, GemmCore& g, int& variant, int64_t& qkb, int64_t& vtb) {
+  if (!((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
+        (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))))
+    return false;
+  g = g0;
+  if (g.group_m == 0) g.group_m = default_group_m(g);
+  variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true, op == OP_F16M, false);
+  // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
+  const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
+  qkb = bpm * e.heads * sn * 64 * 2; vtb = bpm * e.heads * 64 * e.ldvt * 2;
+  return variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000;
+}
+}  // namespace
+bool gemm_qkv_takes_pp(int op, const GemmCore& g0, const EpiQKV& e0) {
+  EpiQKV e = e0;
+  epi_qkv_prepare(e, g0.M);
+  GemmCore g; int variant; int64_t qkb, vtb;
+  return qkv_pp_plan(op, g0, e, -1, g, variant, qkb, vtb);
+}
 hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g0, const EpiQKV& e0, int want, hipStream_t s) {
   EpiQKV e = e0;
   epi_qkv_prepare(e, g0.M);  // fast = 1 when its preconditions hold (else the general division / 64-bit index path)
-  // the pipelined kernel: half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour
-  if ((want < 0 || want >= 50) && e.fast && (op == OP_F16 || op == OP_F16X3 || op == OP_F16M) && e.dh == 64 && e.nseq >= 8 && !e.qk_raw && e.q16 && !e.q32 &&
-      (op == OP_F16 ? pp_applies<1>(g0, 1) : pp_applies<3>(g0, 1))) {
-    GemmCore g = g0;
-    if (g.group_m == 0) g.group_m = default_group_m(g);
-    const int variant = want >= 50 ? want : pick_pp_variant(g, op == OP_F16 ? 1 : 2, true, op == OP_F16M, false);
-    // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
-    const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
-    const int64_t qkb = bpm * e.heads * sn * 64 * 2, vtb = bpm * e.heads * 64 * e.ldvt * 2;
-    if (variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000) {
-      PpEpiQKV p{};
-      p.bias = e.bias; p.rope_cs = e.rope_cs;
-      p.q16 = e.q16; p.k16 = e.k16; p.vt16 = e.vt16; p.q16_lo = e.q16_lo; p.k16_lo = e.k16_lo; p.vt16_lo = e.vt16_lo;
-      p.nseq = e.nseq; p.heads = e.heads; p.pe_heads = e.pe_heads; p.slab_n = e.slab_n; p.pos_off = e.pos_off; p.ldvt = (int)e.ldvt;
-      p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
-      p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb; p.rowinfo = e.rowinfo;
-      const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : op == OP_F16M ? launch_pp<2>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
-      if (r != PP_NOT_APPLICABLE) return r;
-    }
+  GemmCore g; int variant; int64_t qkb, vtb;
+  if (qkv_pp_plan(op, g0, e, want, g, variant, qkb, vtb)) {
+    if (e.mx_qk && (!e.q16_lo || !e.k16_lo)) return hipErrorInvalidValue;
+    PpEpiQKV p{};
+    p.bias = e.bias; p.rope_cs = e.rope_cs;
+    p.q16 = e.q16; p.k16 = e.k16; p.vt16 = e.vt16; p.q16_lo = e.q16_lo; p.k16_lo = e.k16_lo; p.vt16_lo = e.vt16_lo;
+    p.nseq = e.nseq; p.heads = e.heads; p.pe_heads = e.pe_heads; p.slab_n = e.slab_n; p.pos_off = e.pos_off; p.ldvt = (int)e.ldvt;
+    p.qscale = e.qscale; p.nseq_magic = e.nseq_magic; p.nseq_shift = e.nseq_shift; p.inner = e.inner_;
+    p.M = g.M; p.N = g.N; p.qk_bytes = (uint32_t)qkb; p.vt_bytes = (uint32_t)vtb; p.rowinfo = e.rowinfo; p.mx_qk = e.mx_qk;
+    const hipError_t r = op == OP_F16 ? launch_pp<1>(g, p, variant, s) : op == OP_F16M ? launch_pp<2>(g, p, variant, s) : launch_pp<3>(g, p, variant, s);
+    if (r != PP_NOT_APPLICABLE) return r;
   }
+  if (e.mx_qk) return hipErrorInvalidValue;  // P words: the pipelined kernels' epilogue only
   if (op == OP_F16M) return hipErrorInvalidValue;  // MX lines: no generic-kernel fallback
   const int gv = want >= 0 && want < 50 ? want : -1;
   if (e.fast) {

@@ -249,6 +249,10 @@ struct PpEpiQKV {
   int M, N;
   uint32_t qk_bytes, vt_bytes;  // sizes of the q / k planes and of the V^T planes in bytes (< 2^31)
   const uint32_t* rowinfo;      // packed rows: (sequence << 16) | token of GEMM row m (EpiQKVT::rowinfo); null = m / nseq, m % nseq
+  // 1: the second plane of q and of k receives, instead of the fp16 remainders, the MX-fp6 P words of the row's two 32-channel blocks
+  // ([block][half-wave h], 32 bytes each; common.h mx_pack16: q as the activation, k as the weight) — what the flash kernel's NSPLIT = 2
+  // form reads (attention_kernel.h).  The lane's 16 channels of a tile ARE the k-set of P_h: no lane exchange.
+  int mx_qk;
 
   template <int TM, int TN>
   __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
@@ -298,21 +302,36 @@ struct PpEpiQKV {
 #pragma unroll
             for (int q = 0; q < 4; ++q) cs[q] = make_float4(1.f, 0.f, 1.f, 0.f);
           }
-          uint32_t hi[4][2], lo[4][2];
+          float xs[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
-            const float a0 = x[0] * cs[q].x - x[1] * cs[q].y, a1 = x[1] * cs[q].x + x[0] * cs[q].y;
-            const float a2 = x[2] * cs[q].z - x[3] * cs[q].w, a3 = x[3] * cs[q].z + x[2] * cs[q].w;
-            x[0] = a0; x[1] = a1; x[2] = a2; x[3] = a3;
-            if (which == 0) { x[0] *= sc; x[1] *= sc; x[2] *= sc; x[3] *= sc; }
-            pp::split4(x, hi[q], lo[q]);
+            const float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+            xs[4 * q] = x[0] * cs[q].x - x[1] * cs[q].y; xs[4 * q + 1] = x[1] * cs[q].x + x[0] * cs[q].y;
+            xs[4 * q + 2] = x[2] * cs[q].z - x[3] * cs[q].w; xs[4 * q + 3] = x[3] * cs[q].z + x[2] * cs[q].w;
+            if (which == 0) { xs[4 * q] *= sc; xs[4 * q + 1] *= sc; xs[4 * q + 2] *= sc; xs[4 * q + 3] *= sc; }
           }
           const uint32_t rowb = ok ? (uint32_t)((((bp[j] * heads + hh) * sn + pos_off + pos[j]) << 6) + d0 + 8 * h) * 2u : OOB_ROW;
+          if (mx_qk) {  // (uniform over the launch)
+            uint32_t hv[8], pw[8];
+            if (which == 0) mx_pack16<false>(xs, hv, pw); else mx_pack16<true>(xs, hv, pw);
+            uint32_t h0[2] = {hv[0], hv[1]}, h1[2] = {hv[2], hv[3]}, h2[2] = {hv[4], hv[5]}, h3[2] = {hv[6], hv[7]};
+            pp::store_b128(R, rowb, pp::widen(h0, h1));  // the first plane as ever: fp16 values in channel order
+            pp::store_b128(R, rowb + 32u, pp::widen(h2, h3));
+            const uint32_t rowp = ok ? rowb + 16u * h : OOB_ROW;  // byte 64 blk + 32 h of the row: (d0 + 8 h) * 2 + 16 h
+            pp::store_b128(Rl, rowp, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+            pp::store_b128(Rl, rowp + 16u, make_uint4(pw[4], pw[5], pw[6], pw[7]));
+          } else {
+            uint32_t hi[4][2], lo[4][2];
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            pp::store_b128(R, rowb + 32u * p, pp::widen(hi[2 * p], hi[2 * p + 1]));
-            if (Pl) pp::store_b128(Rl, rowb + 32u * p, pp::widen(lo[2 * p], lo[2 * p + 1]));
+            for (int q = 0; q < 4; ++q) {
+              const float x[4] = {xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]};
+              pp::split4(x, hi[q], lo[q]);
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              pp::store_b128(R, rowb + 32u * p, pp::widen(hi[2 * p], hi[2 * p + 1]));
+              if (Pl) pp::store_b128(Rl, rowb + 32u * p, pp::widen(lo[2 * p], lo[2 * p + 1]));
+            }
           }
         }
       } else {

@@ -14,6 +14,7 @@ enum { OP_F32 = 0, OP_F16 = 1, OP_F16X3 = 2, OP_F16M = 3 };
 // batch = gridDim.z.  Tile is chosen from (M, N): 128x128, or 64x128 when the grid would underfill 256 CUs.
 hipError_t launch_gemm_store(int op, const GemmCore& g, const EpiStore& e, int batch, hipStream_t s);
 hipError_t launch_gemm_qkv(int op, const GemmCore& g, const EpiQKV& e, hipStream_t s);
+bool gemm_qkv_takes_pp(int op, const GemmCore& g, const EpiQKV& e);  // would this launch run a pipelined kernel (the only writers of EpiQKV::mx_qk)?
 hipError_t launch_gemm_qkv_variant(int op, const GemmCore& g, const EpiQKV& e, int variant, hipStream_t s);  // microbenchmarks / tests: < 0 = heuristic
 // explicit tile variant (microbenchmarks): 0 = 64x128, 1 = 128x64, 2 = 128x128 (rows x channels), -1 = heuristic
 hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& e, int batch, int variant, hipStream_t s);
@@ -104,7 +105,8 @@ hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* w
                           hipStream_t s, int out_n = 0, int out_off = 0);  // output row of (seq, m) = seq * out_n + m + out_off (out_n 0 = n)
 
 // ---- attention.hip ----------------------------------------------------------------------------
-// flash-style non-causal attention, fp16 operands (nsplit 1) or fp16 hi/lo split operands (nsplit 3), fp32 softmax+accumulate.
+// flash-style non-causal attention, fp32 softmax + accumulate.  nsplit 1: plain fp16 operands; 3: every operand hi/lo split; 2: q, k split;
+// 4: scores = fp16 hi . hi + MX-fp6 corrections (q_lo / k_lo hold the P words PpEpiQKV::mx_qk writes), P and V plain fp16.
 //   q,k [BH, n, 64] f16 (q pre-scaled); vt [BH, 64, ldv] f16 (V transposed, ldv % 8 == 0); o16(/lo) [B', n, H*64];
 //   kvlen per batch' or null.  *_lo planes are required for nsplit == 3.  o_packed: o16 is a packed fp16x3 operand
 //   (row stride 2*H*64, o16_lo == o16 + 32).

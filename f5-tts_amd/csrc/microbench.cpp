@@ -264,6 +264,9 @@ int f5hip_bench_mx_pack(f5hip_ctx* ctx, int rows, int K, double* out9) {
 // The fused q|k|v projection of one block (bias, rope, head scatter into the flash layouts) for `seqs` sequences of nseq tokens, H = 16
 // heads of 64: time of `variant`, and with check != 0 every output plane (q, k hi/lo, V^T) compared byte for byte with the generic kernel
 // of gemm.h (variant 1).  Returns the number of differing bytes in *diff (negative status on errors).
+// check == 2 (fp16x3 / fp16m): the MX-corrected scores end to end — the variant runs with EpiQKV::mx_qk, its P words are decoded on the host
+// against the generic kernel's hi + lo values (the format's bounds, mx_lines_check), and the flash kernel's NSPLIT = 2 form on those planes
+// must land on the split form's output where plain fp16 scores do not (*diff counts what is out of bounds).
 int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int nseq, int K, int iters, int check, double* avg_ms, int64_t* diff) {
   if (!ctx || !avg_ms || seqs <= 0 || nseq <= 1 || iters <= 0 || precision == F5HIP_PREC_FP32 || (K % 32)) return F5HIP_ERR_INVALID;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -306,9 +309,13 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
   g.A = ah; g.W = wh; g.lda = (int64_t)K * pl; g.ldw = (int64_t)K * pl; g.M = M; g.N = N; g.K = K; g.a_rows = M; g.w_rows = N;
   GemmCore gm = g;  // the launch under test: MX lines in fp16m mode (same strides)
   if (mx) { gm.A = am; gm.W = wm; }
+  const bool mxqk = check == 2;
+  if (mxqk && !x3) return F5HIP_ERR_INVALID;
   auto epi = [&](int which) {
     EpiQKV e{};
-    e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = getenv("KB_QKV_PE") ? atoi(getenv("KB_QKV_PE")) : -1; e.qscale = 0.125f; e.ldvt = ldv;
+    e.bias = bias; e.rope_cs = rope; e.nseq = nseq; e.heads = H; e.dh = dh; e.pe_heads = getenv("KB_QKV_PE") ? atoi(getenv("KB_QKV_PE")) : -1; e.ldvt = ldv;
+    e.qscale = mxqk ? 6.0f : 0.125f;  // (mxqk: logits of tens, so that the rounding of the scores shows in the output)
+    e.mx_qk = mxqk && which == 1;
     e.q16 = out[which][0]; e.k16 = out[which][2]; e.vt16 = out[which][4];
     if (x3) { e.q16_lo = out[which][1]; e.k16_lo = out[which][3]; e.vt16_lo = out[which][5]; }
     return e;
@@ -324,6 +331,50 @@ int f5hip_bench_qkv(f5hip_ctx* ctx, int precision, int variant, int seqs, int ns
     // the VALUE of every output (hi + lo in fp16x3) must agree to fp32 rounding: the two kernels contract the rope arithmetic differently
     // (an fma here, a mul + add there), which flips a last bit of `hi` now and then and is absorbed by `lo`; anything above 4e-6 of the
     // plane's largest value is a real difference.  V (no rope) is compared byte for byte as well.
+    if (mxqk) {
+      for (int pl3 = 0; pl3 < 2; ++pl3) {  // q (packed as the activation), k (as the weight)
+        std::vector<f16> ah(nq), al(nq), bh(nq), bp(nq), lines(nq * 2);
+        if (hipMemcpy(ah.data(), out[0][2 * pl3], nq * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(al.data(), out[0][2 * pl3 + 1], nq * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(bh.data(), out[1][2 * pl3], nq * 2, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(bp.data(), out[1][2 * pl3 + 1], nq * 2, hipMemcpyDeviceToHost) != hipSuccess)
+          return F5HIP_ERR_HIP;
+        std::vector<float> xref(nq);
+        for (size_t j = 0; j < nq; ++j) xref[j] = (float)ah[j] + (float)al[j];
+        for (size_t r = 0; r < nq / 64; ++r)
+          for (int blk = 0; blk < 2; ++blk) {  // the line mx_lines_check reads: [32 hi | P_0 | P_1]
+            memcpy(&lines[(r * 2 + blk) * 64], &bh[r * 64 + blk * 32], 64);
+            memcpy(&lines[(r * 2 + blk) * 64 + 32], &bp[r * 64 + blk * 32], 64);
+          }
+        double wc = 0, wl = 0, mv = 0;
+        size_t nbad = 0, hd = 0;
+        mx_lines_check(lines.data(), xref.data(), (int64_t)(nq / 64), 64, pl3 == 1, 0.51, 1.5, &wc, &wl, &nbad, &hd, &mv);
+        fprintf(stderr, "QKV_CHECK variant %d %s P words: coarse / remainder errors %.3f / %.3f block steps, %zu out of bounds, %zu of %zu hi halves differ, max |value| %.3g\n",
+                variant, pl3 == 0 ? "q" : "k", wc, wl, nbad, hd, nq, mv);
+        bad += (int64_t)nbad + (hd > nq / 8 ? (int64_t)hd : 0);
+      }
+      if (init_attention_kernels() != hipSuccess) return F5HIP_ERR_HIP;
+      f16* o[3];
+      std::vector<f16> oh[3];
+      for (int w = 0; w < 3; ++w) {  // split q, k (the reference's planes) / MX-corrected / plain fp16 (the variant's planes)
+        o[w] = t.get<f16>(nq);
+        if (!o[w]) return F5HIP_ERR_HIP;
+        const int src = w == 0 ? 0 : 1;
+        if (launch_flash_attn(w == 0 ? 2 : w == 1 ? 4 : 1, out[src][0], w < 2 ? out[src][1] : nullptr, out[src][2], w < 2 ? out[src][3] : nullptr, out[src][4], nullptr, ldv,
+                              seqs, H, nseq, nullptr, o[w], nullptr, s, 0, nullptr, 0, 1, 1, nullptr, nullptr, /*log2q*/ 1) != hipSuccess)
+          return F5HIP_ERR_HIP;
+        oh[w].resize(nq);
+        if (hipMemcpyAsync(oh[w].data(), o[w], nq * 2, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return F5HIP_ERR_HIP;
+      }
+      double dm = 0, dp = 0, sm = 0, sp = 0, vmax = 0;
+      for (size_t j = 0; j < nq; ++j) {
+        const double a = (float)oh[0][j], m = (float)oh[1][j], pv = (float)oh[2][j];
+        dm = std::max(dm, fabs(m - a)); dp = std::max(dp, fabs(pv - a)); sm += fabs(m - a); sp += fabs(pv - a); vmax = std::max(vmax, fabs(a));
+      }
+      fprintf(stderr, "QKV_CHECK variant %d attention on the MX planes against split q, k: max |diff| %.3g mean %.3g; plain fp16 scores: max %.3g mean %.3g; max |value| %.3g\n",
+              variant, dm, sm / nq, dp, sp / nq, vmax);
+      if (!(sm < 0.35 * sp) || !(dm < 0.02 * vmax)) ++bad;
+      if (diff) *diff = bad;
+      return time_it([&] { return launch_gemm_qkv_variant(op, gm, epi(1), variant, s); }, iters, s, avg_ms);
+    }
     for (int pl3 = 0; pl3 < 3; ++pl3) {
       const size_t n = (pl3 < 2 ? nq : nv);
       std::vector<f16> ah(n), bh(n), al(x3 ? n : 0), bl(x3 ? n : 0);

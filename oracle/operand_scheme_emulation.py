@@ -179,14 +179,35 @@ class Schemes:
         # the engine's default: plain fp16 q (pre-scaled), k, P, V; fp32 softmax and accumulators
         if self.attn == "fp32":
             return TF.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
-        rq = r16 if self.attn in ("fp16", "qk") else (lambda t: t)
-        rp = r16 if self.attn in ("fp16", "pv") else (lambda t: t)
-        q = rq(q * (q.shape[-1] ** -0.5))
-        k = rq(k)
-        s = q @ k.transpose(-1, -2)
+        mode = self.attn
+        rp = r16 if mode in ("fp16", "pv", "qkm", "qkc", "q1", "qks") else (lambda t: t)
+        q = q * (q.shape[-1] ** -0.5)
+        if mode == "qkc":   # softmax is invariant under a shift of every key by one vector: centre the keys of a sequence before rounding them
+            if attn_mask is not None:
+                w = attn_mask[:, :1, :1, :].transpose(-1, -2).to(k.dtype)   # [B,1,N,1] valid keys
+                k = k - (k * w).sum(-2, keepdim=True) / w.sum(-2, keepdim=True)
+            else:
+                k = k - k.mean(-2, keepdim=True)
+        if mode in ("fp16", "qk", "qkc"):
+            s = r16(q) @ r16(k).transpose(-1, -2)
+        elif mode == "qks":  # attn_impl 4: hi/lo-split q and k, three fp16 products
+            qh, kh = r16(q), r16(k)
+            ql, kl = r16(q - qh), r16(k - kh)
+            s = qh @ kh.transpose(-1, -2) + (ql @ kh.transpose(-1, -2) + qh @ kl.transpose(-1, -2))
+        elif mode == "q1":   # q split only (the operand a flash kernel holds in registers), k rounded
+            qh, kh = r16(q), r16(k)
+            s = qh @ kh.transpose(-1, -2) + r16(q - qh) @ kh.transpose(-1, -2)
+        elif mode == "qkm":  # hi.hi in fp16, the two correction products as MX-fp6 over blocks of 32 head dims (what the block GEMMs do)
+            qh, kh = r16(q), r16(k)
+            ql, kl = q - qh, k - kh
+            s = qh @ kh.transpose(-1, -2) + (mx_quant(ql, "e2m3") @ mx_quant(kh, "e2m3").transpose(-1, -2)
+                                             + mx_quant(qh, "e2m3") @ mx_quant(kl, "e2m3").transpose(-1, -2))
+        else:
+            s = q @ k.transpose(-1, -2)
         if attn_mask is not None:
             s = s.masked_fill(~attn_mask, float("-inf"))
         m = s.amax(-1, keepdim=True)
+        self.max_logit = max(getattr(self, "max_logit", 0.0), float(s[torch.isfinite(s)].abs().max()))
         e = torch.exp(s - m)
         e16 = rp(e)
         return (e16 @ rp(v)) / e16.sum(-1, keepdim=True)
@@ -222,7 +243,7 @@ def main():
     lens_l = lens.tolist() if lens is not None else [ref_len] * gold.shape[0]
     for spec, attn in zip(specs, attns):
         t0 = time.perf_counter()
-        O.F = Schemes(sd, parse_run(spec), attn)
+        O_F = O.F = Schemes(sd, parse_run(spec), attn)
         try:
             out, _ = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, **c["kw"])
         finally:
@@ -230,7 +251,8 @@ def main():
         d = torch.cat([(out[b, lens_l[b]:durs[b]] - gold[b, lens_l[b]:durs[b]]).abs().reshape(-1) for b in range(gold.shape[0])])  # the generated frames of every row
         spec = f"{spec} attn={attn}"
         res[spec] = dict(max_abs=d.max().item(), mean_abs=d.mean().item(), rms=d.pow(2).mean().sqrt().item())
-        print(f"{a.case:16s} {spec:34s} max-abs {res[spec]['max_abs']:.3e}  mean-abs {res[spec]['mean_abs']:.3e}  rms {res[spec]['rms']:.3e}"
+        tag = spec + (f" |s|max {O_F.max_logit:.0f}" if hasattr(O_F, "max_logit") else "")
+        print(f"{a.case:16s} {tag:44s} max-abs {res[spec]['max_abs']:.3e}  mean-abs {res[spec]['mean_abs']:.3e}  rms {res[spec]['rms']:.3e}"
               f"   ({time.perf_counter() - t0:.0f} s)", flush=True)
         if a.out:
             json.dump(res, open(a.out, "w"), indent=1)

@@ -157,12 +157,12 @@ def test_mx_pack_and_layernorm_rows_against_the_format(emu_engine, rows, K):  # 
         assert bad == 0 and 0.2 < wc <= 0.5001 and 0.1 < wl <= 0.27, (which, wc, wl, bad)  # (remainders stay below 4 block steps: their top binade rounds to 0.125)
 
 
-def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128):
+def run_qkv(make_engine, capfd, prec, variant, seqs, nseq, K=128, check=1):
     from f5_tts_amd import binding, config
 
     eng = make_engine(config.DIT_TINY)
     ms, diff = C.c_double(), C.c_int64()
-    st = eng.bench_lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS[prec], variant, seqs, nseq, K, 1, 1, C.byref(ms), C.byref(diff))
+    st = eng.bench_lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS[prec], variant, seqs, nseq, K, 1, check, C.byref(ms), C.byref(diff))
     err = capfd.readouterr().err
     assert st == 0, err
     return diff.value, err
@@ -183,6 +183,20 @@ def test_pp_qkv_epilogue_on_mx_lines(emu_engine, capfd, variant):  # noqa: F811
     form, so values — the index scheme itself is the byte-for-byte test above)."""
     diff, err = run_qkv(emu_engine, capfd, "fp16m", variant, 3, 150, K=256)
     assert diff == 0, err
+
+
+@pytest.mark.parametrize("prec,variant", [("fp16x3", CASES[0][0]), ("fp16x3", CASES[-1][0]), ("fp16m", MX_CASES[0][0]), ("fp16m", 80)])
+def test_qkv_epilogue_packs_the_score_corrections_and_the_flash_kernel_reads_them(emu_engine, capfd, prec, variant):  # noqa: F811
+    """Round 5's attention default: the q|k|v epilogue leaves MX-fp6 P words in the second planes of q and k (EpiQKV::mx_qk) and the flash
+    kernel adds both correction products of the scores as one MX MFMA per 32 head channels.  The P words are decoded against the generic
+    kernel's hi + lo values with the format's bounds, and at logits of tens the output must follow the split-q,k kernel's where plain fp16
+    scores visibly do not."""
+    diff, err = run_qkv(emu_engine, capfd, prec, variant, 2, 150, K=256, check=2)
+    assert diff == 0, err[-3000:]
+    m = re.search(r"attention on the MX planes against split q, k: max \|diff\| (\S+) mean (\S+); plain fp16 scores: max (\S+) mean (\S+);", err)
+    assert m, err[-3000:]
+    print(err.strip().splitlines()[-3:])
+    assert float(m.group(2)) < 0.35 * float(m.group(4)) and float(m.group(4)) > 0, m.group(0)
 
 
 def test_tile_grouping_covers_every_tile_with_a_ragged_last_group():
