@@ -201,6 +201,35 @@ def test_no_packed_fp32_in_the_form_that_loses_an_operand(code_objects):
     assert packed == 0, f"{packed} packed-fp32 instructions outside the reproducer: was the library built without -packed-fp32-ops?"
 
 
+FP6_PACK = re.compile(r"v_cvt_scalef32_2xpk16_fp6_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v(\d+)")
+
+
+def test_fp6_pack_never_has_its_scale_inside_its_destination(code_objects):
+    """v_cvt_scalef32_2xpk16_fp6_f32 (common.h mx_pack16: the P words of the MX operand lines) converts 32 values in several passes and
+    reads its scale register in each.  The compiler may place the scale in a destination register (it is dead behind the instruction); the
+    hardware then scales everything behind the first pass by payload bits.  Round 5: all 53 q|k|v kernels had scale == first destination
+    dword and wrote noise on the GPU (profiles/r05h_mxqk_check_scale_overlap.log) while the host shim, which has no register file, was
+    right; the round-4 kernels had happened to be allocated otherwise.  mx_pack16 now keeps the scale alive behind the conversion."""
+    seen, bad = 0, []
+    for co in code_objects:
+        dis = subprocess.run([TOOLS[2], "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+        name = None
+        for ln in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+            if m:
+                name = m.group(1)
+                continue
+            m = FP6_PACK.search(ln)
+            if not m:
+                continue
+            seen += 1
+            d0, d1, a0, a1, b0, b1, sc = map(int, m.groups())
+            if d0 <= sc <= d1:  # (the SOURCES may overlap it — 222 of the GPU-proven round-4 instructions have dst = the first six registers
+                bad.append((name[:100], ln.split("//")[0].strip()))  # of src0: dword k is written after the elements it replaces were read)
+    assert seen > 300, seen  # the act16 / attention / q|k|v epilogues of every tile, the LayerNorm and pack kernels
+    assert not bad, (len(bad), bad[:4])
+
+
 def _regs(tok):
     """('v' | 'a', {numbers}) of an operand like v12, v[10:13], a[0:15]; None for anything else."""
     m = re.match(r"^([va])(\d+)$", tok) or re.match(r"^([va])\[(\d+):(\d+)\]$", tok)
