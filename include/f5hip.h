@@ -241,7 +241,13 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
 
 /* ---- engine options / measurement ---------------------------------------------------------------- */
 /* key/value options: "use_graph" (0/1: replay the NFE loop as a hipGraph), "profile" (0/1: time each kernel
- * class with hipEvents on the launch stream; forces eager launches), "attn_impl" (attention variant),
+ * class with hipEvents on the launch stream; forces eager launches),
+ * "attn_impl" (what F.scaled_dot_product_attention, model/modules.py:511-520, is computed from — 0 (default): FP32 -> materialised fp32
+ * scores; FP16 -> flash attention on plain fp16 q, k, P, V; FP16X3 / FP16M -> flash attention whose SCORES are fp16 hi . hi + both correction
+ * products as one MX-fp6 matrix instruction per 32 head channels, P and V plain fp16 (DESIGN.md sections 2, 4.3: plain fp16 scores moved a
+ * golden with trained-like weight statistics by 1.1e-3); 1: materialised fp32 scores in every mode; 2: flash, every operand hi/lo split;
+ * 3: flash on plain fp16 operands in every mode (the default of ABI v5-v8 builds); 4: flash, q and k hi/lo split (3 MFMAs per score
+ * product), P and V plain; 5 = 0 for the half-precision modes),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
  * "packed_rows" (0 off (default) / 1: a ragged batch — use_mask with durations below n — of a DiT with attn_mask_enabled runs its block
  * loop over the VALID rows only: the reference's varlen attention path, model/modules.py:522-543, extended to the row-wise layers.  Rows past a
