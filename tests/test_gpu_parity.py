@@ -1085,6 +1085,28 @@ def test_pp_qkv_epilogue_equals_generic_kernel_on_the_gpu(engines, variant, seqs
         assert st == 0 and diff.value == 0, (variant, seqs, st, diff.value)
 
 
+@pytest.mark.parametrize("prec,variant", [("fp16m", -1), ("fp16m", 50), ("fp16m", 59), ("fp16m", 61), ("fp16m", 68), ("fp16m", 80), ("fp16x3", -1), ("fp16x3", 57)])
+@pytest.mark.parametrize("seqs,nseq", [(2, 150), (2, 1406), (8, 1024)])
+def test_qkv_epilogue_score_corrections_on_the_gpu(engines, capfd, prec, variant, seqs, nseq):
+    """The MX-fp6 correction words the q|k|v epilogue leaves for the attention scores (round 5's default), decoded on the host against the
+    generic kernel's hi + lo values with the format's bounds, and the flash kernel's NSPLIT = 2 form on them against the split-q,k form at
+    logits of tens.  This is the test that separates the GPU from the host shim: with the conversion's scale register allocated inside its
+    destination every word was out of bounds here and nowhere else."""
+    import ctypes as C
+
+    from f5_tts_amd import binding
+
+    eng = engines("tiny", 1)
+    ms, diff = C.c_double(), C.c_int64()
+    st = eng.bench_lib.f5hip_bench_qkv(eng._ctx, binding.PRECISIONS[prec], variant, seqs, nseq, 1024, 1, 2, C.byref(ms), C.byref(diff))
+    err = capfd.readouterr().err
+    if prec == "fp16x3" and variant < 0 and seqs * nseq < 512:  # the heuristic sends a handful of row tiles to the generic kernel, which
+        assert st == 2, (st, err[-500:])                        # writes no correction words: the launch must refuse (the engine asks
+        return                                                  # gemm_qkv_takes_pp first and falls back to split q, k)
+    assert st == 0 and diff.value == 0, (st, diff.value, err[-1500:])
+    assert "attention on the MX planes" in err
+
+
 @pytest.mark.parametrize("variant", [55, 59, 65, 66, 67, 69, 70])
 @pytest.mark.parametrize("epi,M,N,K", [(1, 2812, 2048, 1024), (2, 2812, 1024, 2048), (2, 1406, 1024, 1024)])
 def test_pp_store_epilogues_equal_generic_kernel_on_the_gpu(engines, capfd, variant, epi, M, N, K):
