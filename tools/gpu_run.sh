@@ -149,10 +149,12 @@ evidence)
   Q="--no-cpu-baseline --no-other-configs"
   timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16x3 $Q > $out/bench_b1_fp16x3.json 2> /dev/null
   timeout 600 python bench.py --steps 10 --warmup 3 --precision fp16 $Q > $out/bench_b1_fp16.json 2> /dev/null
+  timeout 600 python bench.py --steps 10 --warmup 3 --attn-impl 3 $Q > $out/bench_b1_plain_scores.json 2> /dev/null  # the attention of rounds 2-4 (plain fp16 q, k): outside the tolerance on the trained-like golden
   timeout 600 python bench.py --steps 10 --warmup 3 --branch-streams 1 $Q > $out/bench_b1_two_chains.json 2> /dev/null  # the cond / uncond halves as two concurrent chains of 1406 rows
   timeout 600 python bench.py --steps 3 --warmup 1 --batch 4 --nfe 32 $Q > $out/bench_b4_nfe32.json 2> /dev/null
   timeout 600 python bench.py --steps 3 --warmup 1 --batch 8 $Q > $out/bench_b8.json 2> /dev/null
   timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/bench_b32_nfe32.json 2> /dev/null
+  timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --attn-impl 3 $Q > $out/bench_b32_nfe32_plain_scores.json 2> /dev/null
   timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 --precision fp16x3 $Q > $out/bench_b32_nfe32_fp16x3.json 2> /dev/null
   timeout 600 python bench.py --model E2TTS_Base --batch 8 --vocoder bigvgan --steps 3 --warmup 1 $Q > $out/bench_e2_b8_bigvgan.json 2> /dev/null
   for f in $out/bench_*.json; do line $f $(basename $f .json); done
