@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
       default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
     }
     wr("out.bin", out);
-  } else if (mode == "attn") {  // nsplit(1|2|3) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU]
+  } else if (mode == "attn") {  // nsplit(1|2|3; 4 = MX-corrected scores) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU; with nsplit 4: 40 / 60 = the lazy 4- / 6-wave forms]
     const int nsplit = A(0), Bp = A(1), heads = A(2), n = A(3), kvs = A(4), o_packed = A(5), has_kvlen = A(6), pipe = argc > 10 ? A(7) : 0;
     const int bh = Bp * heads, ldv = (n + 7) & ~7;
     auto q = rd<f16>("q.bin"), ql = rd<f16>("q_lo.bin", true), k = rd<f16>("k.bin"), kl = rd<f16>("k_lo.bin", true);
@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
     };
     using I1 = std::integral_constant<int, 1>;
     using I3 = std::integral_constant<int, 3>;
-    if (pipe) {  // the software-pipelined kernel: plain fp16 operands, q carries log2(e)
+    if (pipe && nsplit != 4) {  // the software-pipelined kernel: plain fp16 operands, q carries log2(e)
       const int nw = pipe % 10, lds = flash_lds_bytes<1, 1>();
       a.log2q = 1;
       a.nqb = (n + 32 * nw - 1) / (32 * nw); a.nwg = bh * a.nqb;
@@ -159,6 +159,43 @@ int main(int argc, char** argv) {
       else if (pipe == 14) hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_pipe_kernel<4, true>(a); });
       else if (pipe == 6) hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_pipe_kernel<6, false>(a); });
       else hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_pipe_kernel<6, true>(a); });
+    } else if (nsplit == 4) {
+      // MX-corrected scores (flash_attn_kernel<2, 1>): the fp16 remainders of q_lo / k_lo become the P words PpEpiQKV::mx_qk writes — per row
+      // [block][half-wave] x 32 bytes, the half-wave's 16 channels 32 blk + 8 (t / 4) + 4 h + t % 4, q as the activation, k as the weight
+      auto pack = [&](const std::vector<f16>& hi, std::vector<f16>& lo, bool weight) {
+        std::vector<f16> P(lo.size());
+        for (size_t r = 0; r < hi.size() / 64; ++r)
+          for (int blk = 0; blk < 2; ++blk)
+            for (int h = 0; h < 2; ++h) {
+              float v[16];
+              for (int t = 0; t < 16; ++t) {
+                const size_t c = r * 64 + blk * 32 + 8 * (t / 4) + 4 * h + (t % 4);
+                v[t] = (float)hi[c] + (float)lo[c];
+              }
+              uint32_t hv[8], pw[8];
+              if (weight) mx_pack16<true>(v, hv, pw); else mx_pack16<false>(v, hv, pw);
+              memcpy(reinterpret_cast<char*>(&P[r * 64]) + blk * 64 + h * 32, pw, 32);
+            }
+        lo.swap(P);
+      };
+      pack(q, ql, false);
+      pack(k, kl, true);
+      a.q_lo = ql.data(); a.k_lo = kl.data();
+      const int lds = flash_lds_bytes<2, 1>();
+      if (pipe == 60) {  // the one-round launch of a single utterance: 192-row blocks, row sums on the VALU, lazy reference maximum
+        a.log2q = 1;
+        a.nqb = (n + 191) / 192; a.nwg = bh * a.nqb;
+        hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_attn_kernel<2, 1, 6, false, true, true>(a); });
+      } else if (pipe == 40) {  // many workgroups per CU: 128-row blocks, row sums on the matrix pipe, lazy reference maximum
+        a.log2q = 1;
+        hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<2, 1, 4, false, false, true>(a); });
+      } else if (kvs > 1) {
+        hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<2, 1, 4, true>(a); });
+        const int64_t rows = (int64_t)bh * n;
+        hipemu::launch(dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, [&] { flash_combine_kernel(a, rows); });
+      } else {
+        hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<2, 1, 4, false>(a); });
+      }
     } else if (nsplit == 3) go(I3{}, I3{});
     else if (nsplit == 2) go(I3{}, I1{});
     else go(I1{}, I1{});

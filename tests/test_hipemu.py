@@ -328,9 +328,9 @@ def test_emulated_library_rejects_what_the_real_one_rejects(emu_lib):
 
 
 # ---- flash attention (csrc/attention_kernel.h): the GPU-proven kernel through the shim, then its key-split variant ---------------------
-def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None, log2q=False):
+def _attn_case(rng, Bp, heads, n, nsplit, kvlen=None, log2q=False, qgain=1.0):
     bh = Bp * heads
-    q = (rng.standard_normal((bh, n, 64)) * 0.5 / 8.0).astype(np.float32)  # pre-scaled by 1/sqrt(64), as the QKV epilogue leaves it
+    q = (rng.standard_normal((bh, n, 64)) * 0.5 * qgain / 8.0).astype(np.float32)  # pre-scaled by 1/sqrt(64), as the QKV epilogue leaves it
     if log2q:
         q *= np.float32(np.log2(np.e))  # ... and by log2(e): the kernel's scores are base-2 logarithms
     k = (rng.standard_normal((bh, n, 64)) * 1.5).astype(np.float32)
@@ -371,6 +371,27 @@ def test_flash_attention_kernel_and_its_key_split_variant(exe, tmp_path, nsplit,
     got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
     tol = 3e-3 if nsplit < 3 else 2e-5  # P (and V) rounded to fp16 in the PV product unless everything is split
     assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("form,kvs,n,kvlen", [(0, 1, 200, None), (0, 1, 130, [130, 77]), (0, 3, 333, None), (40, 1, 450, [450, 301]), (60, 1, 450, None), (60, 1, 130, [1, 130])])
+def test_flash_attention_with_mx_corrected_scores(exe, tmp_path, form, kvs, n, kvlen):
+    """flash_attn_kernel<2, 1> (round 5's default in the parity modes): scores = fp16 hi . hi + both correction products as one MX-fp6 MFMA
+    per 32 head channels, from P words packed the way the q|k|v epilogue packs them.  Logits of tens, so a slip in the P-word layout (or in
+    which half-wave reads which word) shows: the output must follow the softmax of the SPLIT values where plain fp16 q, k are ~10x off.
+    Forms: the exact-maximum kernel, its key-split variant + merge, and the lazy 4- / 6-wave forms the engine launches."""
+    rng = np.random.default_rng(n + kvs + form)
+    Bp, heads = 2, 2
+    files, want = _attn_case(rng, Bp, heads, n, 2, kvlen, log2q=form != 0, qgain=8.0)
+    run(exe, tmp_path, "attn", 4, Bp, heads, n, kvs, 1, int(kvlen is not None), form, **files)
+    got = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
+    err_mx = np.abs(got - want).mean()
+    plain_form = {0: (), 40: (4,), 60: (16,)}[form]  # plain fp16 scores in the same units: the exact-maximum kernel / the pipelined lazy forms (log2q)
+    run(exe, tmp_path, "attn", 1, Bp, heads, n, kvs, 1, int(kvlen is not None), *plain_form, **{k: v for k, v in files.items() if not k.endswith("_lo")})
+    plain = decode_operand(open(os.path.join(tmp_path, "out.bin"), "rb").read(), Bp * n, heads * 64, OP_F16X3).reshape(Bp, n, heads * 64)
+    err_plain = np.abs(plain - want).mean()
+    assert np.abs(got - want).max() < 3e-3 * max(1.0, np.abs(want).max())
+    print(f"mean |error| against the split-value softmax: MX-corrected {err_mx:.2e}, plain fp16 scores {err_plain:.2e}")
+    assert err_mx < 0.5 * err_plain, (err_mx, err_plain)
 
 
 @pytest.mark.parametrize("pipe,n,kvlen", [(4, 200, None), (14, 70, None), (6, 450, [450, 301]), (16, 130, [130, 77]), (4, 64, None), (4, 333, [1, 333])])
