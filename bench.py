@@ -331,6 +331,11 @@ def main():
              ("E2TTS_Base", 8, 16, "bigvgan", 1): 4}.get((a.model, B, a.nfe, a.vocoder, world))
     notes = ["the time-embedding / AdaLN tables of a time grid are computed once per (grid, weights) and reused by later calls (4 small GEMMs, "
              "~0.3 ms, that the reference runs in every call): the timed calls after the warm-up hit that cache, as a server's would"]
+    if a.precision in ("fp16m", "fp16x3"):
+        notes.append({-1: "attention scores: fp16 hi.hi + both hi/lo correction products as one MX-fp6 MFMA per 32 head channels (the parity modes' default "
+                          "since round 5; plain fp16 scores, `--attn-impl 3`, are ~5 % faster and move the trained-like golden by 1.1e-3 > the 1e-3 tolerance)",
+                      0: "attention scores: the default (MX-corrected)", 3: "attention scores: PLAIN fp16 q, k (--attn-impl 3): outside the parity tolerance on the "
+                          "trained-like golden (DESIGN.md section 2) - an A/B line, not the headline"}.get(a.attn_impl, f"attention: attn_impl {a.attn_impl}"))
     if big:
         notes.append("BigVGAN generator: source and checkpoint absent from the reference tree (un-vendored submodule) — restated from the "
                      "published algorithm, PARITY UNPINNED; this line is a throughput measurement of that restatement, not a reference-verified result")
