@@ -13,6 +13,8 @@ import sys
 
 def klass(name):
     # the block GEMMs: the pipelined kernel (gemm_pp.h) and the generic one (gemm.h), by operand mode
+    if "gemm_p8_kernel" in name:  # the ping-pong 256x256 kernel (gemm_p8.h): NSPLIT 1 = plain fp16 rows, 2 = MX lines
+        return "gemm_fp16m" if ("gemm_p8_kernelILi2E" in name or "gemm_p8_kernel<2," in name) else "gemm_fp16"
     if "gemm_pp_kernel" in name or ("gemm_kernel" in name and ("EpiQKV" in name or "EpiStore" in name)):
         if "DF16_Li3" in name or "_Float16, 3" in name:
             return "gemm_fp16x3"
