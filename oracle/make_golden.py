@@ -116,6 +116,11 @@ FULL_CASES = {
     # the Small model with the key-padding mask on a ragged batch of four (lengths 500 / 431 / 333 / 250): packed rows at a real width
     "small_mask_ragged_b4": dict(preset="F5TTS_v1_Small_mask", wseed=0, nw=256 * 200, wavseed=0, batch=4, nt=80, tseed=0, duration=[500, 431, 333, 250],
                                  lens=[201, 160, 130, 101], pad_from=50, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # the same kind of batch (three sequences, 460 / 380 / 250 frames, key-padding mask) on the Small model with trained-checkpoint weight
+    # STATISTICS (round 5): the attention-score arithmetic under large logits AND masked tails / packed rows
+    "small_mask_ragged_b3_trained_like": dict(preset="F5TTS_v1_Small_mask", wseed=2, trained=True, nw=256 * 190, wavseed=4, batch=3, nt=70, tseed=6,
+                                              duration=[460, 380, 250], lens=[181, 150, 101], pad_from=50,
+                                              kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     # BASELINE.json configs[4] backbone at full size: E2-TTS Base (UNetT, depth 24, ff_mult 4), same prompt/duration as config 1
     "e2_base_cfg5": dict(preset="E2TTS_Base", wseed=0, nw=120000, wavseed=0, batch=1, nt=220, tseed=0, duration=1406, lens=None,
                          kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),

@@ -948,6 +948,40 @@ def test_packed_rows_small_model_golden():
         eng.close()
 
 
+def test_ragged_masked_batch_on_trained_like_weights():
+    """Round 5: the Small model with the key-padding mask on a ragged batch of three (460 / 380 / 250 frames) whose weights carry a trained
+    checkpoint's statistics (synth.trained_like_dit_state_dict) - larger logits than any Gaussian golden, masked key tails, and the packed-row
+    layout on top.  Golden minted by the reference's own CFM.sample.  Asserted in both half-precision modes, padded and packed; the plain-fp16
+    attention scores of rounds 2-4 are measured next to the default for the record."""
+    from f5_tts_amd.engine import F5HipCFM, F5HipEngine
+
+    c = MG.FULL_CASES["small_mask_ragged_b3_trained_like"]
+    cfg, wav, text, duration, lens = MG.case_inputs(c)
+    eng = F5HipEngine(cfg, None, device=0)
+    eng.load_state_dict(MG.case_weights(c))
+    g = gold("small_mask_ragged_b3_trained_like")["out"]
+
+    def err(out):  # generated frames of every row
+        return max(maxerr(out[b, int(lens[b]):d], g[b, int(lens[b]):d]) for b, d in enumerate(duration.tolist()))
+
+    try:
+        for packed in (0, 1):
+            eng.set_option("packed_rows", packed)
+            for prec in ("fp16m", "fp16x3"):
+                out, _ = F5HipCFM(eng, precision=prec).sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+                e = err(out)
+                print(f"trained-like ragged batch of 3, {'packed' if packed else 'padded'} rows, {prec}: {e:.2e}")
+                assert e < 7e-4
+        eng.set_option("packed_rows", 0)
+        eng.set_option("attn_impl", 3)
+        out, _ = F5HipCFM(eng, precision="fp16m").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+        print(f"  with plain fp16 scores (attn_impl 3), padded, fp16m: {err(out):.2e}")
+        out, _ = F5HipCFM(eng, precision="fp32").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
+        assert err(out) < TIGHT
+    finally:
+        eng.close()
+
+
 def test_configs2_shaped_batch_golden():
     """BASELINE.json configs[2] / [3] shape (a batch of fixed-length prompts through the packed cond | uncond schedule, NFE 32) at the full
     model size: 4 distinct utterances against the golden minted by the reference's own CFM.sample (oracle/make_golden.py base_v1_cfg3_b4),
