@@ -976,8 +976,11 @@ def test_ragged_masked_batch_on_trained_like_weights():
         eng.set_option("attn_impl", 3)
         out, _ = F5HipCFM(eng, precision="fp16m").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
         print(f"  with plain fp16 scores (attn_impl 3), padded, fp16m: {err(out):.2e}")
+        eng.set_option("attn_impl", 0)
         out, _ = F5HipCFM(eng, precision="fp32").sample(wav.cuda(), text, duration, lens=lens, **c["kw"])
-        assert err(out) < TIGHT
+        e32 = err(out)
+        print(f"  fp32: {e32:.2e}")
+        assert e32 < TIGHT
     finally:
         eng.close()
 
