@@ -1,3 +1,7 @@
+"""The q|k|v epilogue's MX-fp6 score-correction words and the flash kernel that reads them, on the GPU, for every tile family and three
+shapes in both half-precision modes (f5hip_bench_qkv check = 2: P words decoded on the host against the generic kernel's hi + lo values,
+attention on the MX planes against the split-q,k kernel): python tools/mxqk_check.py  ->  one `status 0 diff 0` line per case
+(profiles/r05h_mxqk_check_scale_overlap.log: before the register fix of DESIGN.md section 4.6; r05j_mxqk_check.log: after)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.getcwd())
 import torch
