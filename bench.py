@@ -251,6 +251,12 @@ def main():
         sd = synth.synth_dit_state_dict(cfg, seed=0)
         vsd = {} if big else synth.synth_vocos_state_dict(vcfg, seed=0)
         eng.load_state_dict({**sd, **vsd}, finalize=False)
+    # the multi-GPU guard: every rank says which physical device it sits on (all-gather over the group the broadcast uses); N ranks that do
+    # not name N distinct devices (a launcher that gave two ranks one LOCAL_RANK, a masked HIP_VISIBLE_DEVICES) never print an N-GPU line
+    census = fdist.device_census(fdist.device_identity(local, DEVICE_TYPE))
+    why = fdist.check_census(census, world)
+    if why is not None:
+        raise SystemExit(f"bench.py: --gpus {a.gpus}: {why}; refusing to print a line for a job that is not {world} GPUs")
     weights_via = "rccl broadcast of the packed blob from rank 0" if world > 1 else "local (single rank)"
     if world > 1:
         torch.distributed.barrier()
@@ -354,6 +360,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
                    "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via,
                    "rccl_ranks": world if world > 1 else 0, "rccl_ranks_seen": seen if world > 1 else 0,
+                   "rccl_devices": [f"rank {d['rank']}: {d['host']} cuda:{d['device_index']} pci {d['pci_bus_id']}" for d in census] if world > 1 else [],
                    "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                    "host_numa_pinning": [{k: v for k, v in n.items() if v is not None} for n in numa_all],
                    "weight_broadcast_plus_finalize_s": round(bcast_s, 4),

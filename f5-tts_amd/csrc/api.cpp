@@ -655,6 +655,23 @@ int finalize_impl(f5hip_ctx* ctx) {
         }
       }
     }
+    // the support of every triangle: the mel kernel sums a channel over [first, last + 1) only (same terms, same order as the dense product)
+    auto ranges = [&](const std::vector<float>& tab) {
+      std::vector<int> r(2 * (size_t)nmel, 0);
+      for (int m = 0; m < nmel; ++m) {
+        int lo = nbin, hi = 0;
+        for (int k = 0; k < nbin; ++k)
+          if (tab[(size_t)k * nmel + m] != 0.0f) { lo = std::min(lo, k); hi = k + 1; }
+        r[2 * m] = std::min(lo, hi);
+        r[2 * m + 1] = hi;
+      }
+      return r;
+    };
+    const std::vector<int> rg = ranges(fb), rgs = ranges(fbs);
+    HIPCHK(ctx->melrange.ensure(rg.size() * sizeof(int)));
+    HIPCHK(ctx->melrange_slaney.ensure(rgs.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(ctx->melrange.p, rg.data(), rg.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->melrange_slaney.p, rgs.data(), rgs.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(ctx->melfb_slaney.ensure(fbs.size() * sizeof(float)));
     HIPCHK(hipMemcpy(ctx->melfb_slaney.p, fbs.data(), fbs.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx->twiddle.ensure(tw.size() * sizeof(float)));
@@ -1669,12 +1686,12 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->cond_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
                     &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
-                    &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
+                    &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->melfb_slaney, &ctx->melrange, &ctx->melrange_slaney, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
                     &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->traj_buf, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
-                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->vframes, &ctx->attn_part};
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->attn_part};
   for (DevBuf* b : bufs) b->release();
   ctx->stage.release();
   if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
@@ -1813,7 +1830,8 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float*
   {
     Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
     HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(),
-                      mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(), ctx->cfg.mel_dim, frame_major, pad,
+                      mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(),
+                      mel_type == 1 ? ctx->melrange_slaney.as<int>() : ctx->melrange.as<int>(), ctx->cfg.mel_dim, frame_major, pad,
                       mel_type == 1 ? 1e-9f : 0.f, out, st));
   }
   CHK(scope.finish());
@@ -2053,7 +2071,7 @@ int f5hip_debug_tensor(f5hip_ctx* ctx, int which, float* dst, int64_t numel, voi
 // ---- vocoder -------------------------------------------------------------------------------------
 }  // extern "C"
 namespace {
-// head.out Linear -> exp / clip(1e2) / cos / sin -> inverse STFT (frames + overlap-add); workspace vlogits / vframes sized by the caller
+// head.out Linear -> exp / clip(1e2) / cos / sin -> inverse STFT (one kernel: transform + overlap-add); workspace vlogits sized by the caller
 int vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* out, hipStream_t st) {
   const auto& v = ctx->vcfg;
   const int C = v.dim, nout = v.n_fft + 2, npad = (nout + 3) & ~3;
@@ -2064,9 +2082,8 @@ int vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* out, hi
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->vlogits.as<float>(), npad, ctx->vhead_b.as<float>()), 1, st));
   }
   {
-    Prof pr(ctx, st, KC_ISTFT, 0, (double)R * npad * 4 + 2.0 * R * v.n_fft * 4 + (double)B * 256.0 * (T - 1) * 4);
-    HIPCHK(launch_istft_frames(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
-    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
+    Prof pr(ctx, st, KC_ISTFT, 0, (double)R * npad * 4 + (double)B * 256.0 * (T - 1) * 4);  // logits once, samples once
+    HIPCHK(launch_istft(ctx->vlogits.as<float>(), npad, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), out, st));
   }
   return F5HIP_OK;
 }
@@ -2091,7 +2108,6 @@ int f5hip_vocos_decode(f5hip_ctx* ctx, const float* melp, int B, int T, int chan
   HIPCHK(ctx->va.ensure((size_t)R * C * 4));
   HIPCHK(ctx->vh.ensure((size_t)R * I * 4));
   HIPCHK(ctx->vlogits.ensure((size_t)R * npad * 4));
-  HIPCHK(ctx->vframes.ensure((size_t)R * v.n_fft * 4));
   float* vx = ctx->vx.as<float>();
   {  // embed Conv1d(100 -> C, k=7, pad 3) as im2col + GEMM, then LayerNorm
     Prof pr(ctx, st, KC_VOCOS_OTHER, 0, 0);
@@ -2145,7 +2161,6 @@ int f5hip_vocos_head(f5hip_ctx* ctx, const float* hidden, int B, int T, float* o
   CHK(scope.begin());
   const int npad = (ctx->vcfg.n_fft + 2 + 3) & ~3;
   HIPCHK(ctx->vlogits.ensure((size_t)B * T * npad * 4));
-  HIPCHK(ctx->vframes.ensure((size_t)B * T * ctx->vcfg.n_fft * 4));
   CHK(vocos_head(ctx, hidden, B, T, out, st));
   CHK(scope.finish());
   collect_prof(ctx, st);
@@ -2160,11 +2175,9 @@ int f5hip_istft(f5hip_ctx* ctx, const float* logits, int64_t ld, int B, int T, f
   hipStream_t st = (hipStream_t)stream;
   CallScope scope(ctx, st);
   CHK(scope.begin());
-  HIPCHK(ctx->vframes.ensure((size_t)B * T * 1024 * 4));
   {
-    Prof pr(ctx, st, KC_ISTFT, 0, (double)B * T * ld * 4 + 2.0 * B * T * 1024 * 4 + (double)B * 256.0 * (T - 1) * 4);
-    HIPCHK(launch_istft_frames(logits, ld, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), ctx->vframes.as<float>(), st));
-    HIPCHK(launch_istft_ola(ctx->vframes.as<float>(), ctx->window.as<float>(), B, T, out, st));
+    Prof pr(ctx, st, KC_ISTFT, 0, (double)B * T * ld * 4 + (double)B * 256.0 * (T - 1) * 4);
+    HIPCHK(launch_istft(logits, ld, B, T, ctx->twiddle.as<float>(), ctx->window.as<float>(), out, st));
   }
   CHK(scope.finish());
   collect_prof(ctx, st);

@@ -17,6 +17,7 @@
 #endif
 
 typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -109,13 +110,14 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float act_silu(float x) { return x * fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float act_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float act_gelu_tanh(float x) {
-  // torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3);  0.5*(1+tanh(u)) = 1 - 1/(1+e^{2u})  (no cancellation: the
-  // result is >= 0.5 for u >= 0 and e^{2u}/(1+e^{2u}) is formed directly for u < 0)
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  const float e = fast_exp(-2.0f * fabsf(u));           // in (0, 1]
-  const float s = fast_rcp(1.0f + e);                    // sigmoid(2|u|)
-  return x * (u >= 0.f ? s : e * s);                     // sigmoid(2u)
+  // torch: 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715*x^3);  0.5*(1+tanh(u)) = sigmoid(2u) = 1 / (1 + 2^z), z = -2 u log2(e) = x (c0 + c1 x^2).
+  // 1 / (1 + 2^z) has no cancellation on either side (z -> +inf: 2^z = inf, rcp = 0, result -0 like torch; z -> -inf: 2^z = 0, result x), so the
+  // form needs no |u| / select dance: 4 full-rate VALU instructions + the two quarter-rate transcendentals per element (round 6: the epilogue of
+  // FeedForward's first linear is VALU-bound - 128 outputs per lane at 90 cycles each were 30 % of a many-round launch; now 58)
+  const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+  const float p = __builtin_fmaf(x * x, c1, c0);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * fast_rcp(1.0f + e);
 }
 __device__ __forceinline__ float act_mish(float x) {
   // x * tanh(softplus(x)); with e = e^x: tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2), n = e*(e+2).
@@ -186,10 +188,9 @@ __device__ __forceinline__ void mx_pack16(const float (&v)[16], uint32_t (&hi)[8
   f32x16 c, l;
 #pragma unroll
   for (int t = 0; t < 16; t += 2) {
-    const f16 h0 = (f16)v[t], h1 = (f16)v[t + 1];
-    union { f16 h[2]; uint32_t u; } pk;
-    pk.h[0] = h0; pk.h[1] = h1;
-    hi[t >> 1] = pk.u;
+    const f16x2 hp = {(f16)v[t], (f16)v[t + 1]};  // a vector of two: one v_cvt_pk_f16_f32
+    const f16 h0 = hp[0], h1 = hp[1];
+    hi[t >> 1] = __builtin_bit_cast(uint32_t, hp);
     c[t] = v[t]; c[t + 1] = v[t + 1];
     l[t] = (v[t] - (float)h0) * 2048.0f;  // exact: the remainder has <= 13 significant bits, 2^11 is a power of two
     l[t + 1] = (v[t + 1] - (float)h1) * 2048.0f;

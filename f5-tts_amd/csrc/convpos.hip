@@ -28,11 +28,25 @@ struct ConvCfg {
 template <typename T, int NPL, int CPG>
 __global__ __launch_bounds__(256) void convpos_kernel(const float* __restrict__ x, const T* __restrict__ w, const T* __restrict__ w_lo,
                                                       const float* __restrict__ bias, const uint8_t* __restrict__ rowvalid,
-                                                      const float* __restrict__ residual, int n, int D, int K, float* out, int out_n, int out_off) {
+                                                      const float* __restrict__ residual, int n, int D, int K, float* out, int out_n, int out_off,
+                                                      int mtiles, int S) {
   using C = ConvCfg<T, NPL, CPG>;
   F5_DYN_LDS(char, smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * C::BMR, g = blockIdx.y, s = blockIdx.z;
+  // XCD-aware placement (round 6): workgroup b runs on XCD b % 8, and each XCD has its own L2.  With the plain (frame tile, group, sequence) grid
+  // every XCD saw every group, so each of the eight L2s fetched the whole 31-tap weight set of all 16 groups (PMC: 90 MB per B = 1 launch for
+  // 11.5 MB of activations + 8 MB of weights).  Here an XCD takes a CONTIGUOUS run of the order (group, sequence, frame tile): a group's
+  // weights are fetched by one L2 (two at a run boundary).  Bijective for any grid size, as in the GEMM and attention kernels.
+  int m0, g, s;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int per_g = S * mtiles;
+    g = L / per_g;
+    const int rem = L - g * per_g;
+    s = rem / mtiles;
+    m0 = (rem - s * mtiles) * C::BMR;
+  }
   const int halo = K / 2;
   const int xrows = C::BMR + K - 1;
   const int xplane = xrows * C::ROWB;
@@ -173,8 +187,8 @@ hipError_t launch_cfg(const float* x, const T* w, const T* w_lo, const float* bi
   const int lds = NPL * (C::BMR + K - 1) * C::ROWB + 2 * C::WSTAGE;
   auto kern = convpos_kernel<T, NPL, CPG>;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  dim3 grid((n + C::BMR - 1) / C::BMR, groups, S);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, w, w_lo, bias, rowvalid, residual, n, D, K, out, out_n, out_off);
+  const int mtiles = (n + C::BMR - 1) / C::BMR;
+  hipLaunchKernelGGL(kern, dim3(mtiles * groups * S), dim3(256), lds, s, x, w, w_lo, bias, rowvalid, residual, n, D, K, out, out_n, out_off, mtiles, S);
   return hipGetLastError();
 }
 

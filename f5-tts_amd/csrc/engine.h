@@ -206,6 +206,7 @@ struct f5hip_ctx {
   DevBuf freqs_cis;                    // [8192, text_dim]
   DevBuf inv_freq;                     // [dh/2]
   DevBuf vhead_w, vhead_b;             // padded vocos head [1028, C], [1028]
+  DevBuf melrange, melrange_slaney;              // per mel channel: [first, one past last) bin of its filterbank triangle
   DevBuf twiddle, window, melfb, melfb_slaney;  // audio tables (HTK filterbank of the Vocos-type mel, slaney one of the BigVGAN type)
   const float *adaln_w = nullptr, *adaln_b = nullptr;  // [depth*6D, D], [depth*6D]
 
@@ -243,7 +244,7 @@ struct f5hip_ctx {
   DevBuf vel, rope, dbg_vel, ymid;     // ymid: scratch ODE state of the midpoint solver
   int nb = 2;                          // packed branches per utterance: 2 = cond + uncond (CFG), 1 = cond only (cfg_strength < 1e-5)
   // vocos workspace
-  DevBuf vcol, vx, va, vh, vlogits, vframes;
+  DevBuf vcol, vx, va, vh, vlogits;
 
   // options / measurement
   bool use_graph = false;

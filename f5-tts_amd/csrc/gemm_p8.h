@@ -265,7 +265,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
 #ifndef F5_HIPEMU
     asm volatile("" : "+v"(lane_e));
 #endif
-    pp_unscale<TM, TN>(acc, g, n0 + wn * 64, lane_e);
-    epi.template tile<TM, TN>(acc, m0 + grp * 128, n0 + wn * 64, lane_e);
+    pp_finish<TM, TN>(acc, g, epi, m0 + grp * 128, n0 + wn * 64, lane_e);
   }
 }

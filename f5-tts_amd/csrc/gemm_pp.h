@@ -89,13 +89,16 @@ __device__ __forceinline__ uint32_t pack2(f16 a, f16 b) {
   x.h[1] = b;
   return x.u;
 }
-// 4 floats -> 4 halves (hi) and the 4 halves of the remainders (lo), each as two packed dwords
+// 4 floats -> 4 halves (hi) and the 4 halves of the remainders (lo), each as two packed dwords.  The pairs are built as VECTORS of two halves:
+// gfx950 then converts a pair with one v_cvt_pk_f16_f32 (the union form above compiled to a conversion per half plus a shift and an or)
 __device__ __forceinline__ void split4(const float (&x)[4], uint32_t (&hi)[2], uint32_t (&lo)[2]) {
-  f16 h[4], l[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) split_f16(x[e], h[e], l[e]);
-  hi[0] = pack2(h[0], h[1]); hi[1] = pack2(h[2], h[3]);
-  lo[0] = pack2(l[0], l[1]); lo[1] = pack2(l[2], l[3]);
+  for (int e = 0; e < 4; e += 2) {
+    const f16x2 h = {(f16)x[e], (f16)x[e + 1]};
+    const f16x2 l = {(f16)(x[e] - (float)h[0]), (f16)(x[e + 1] - (float)h[1])};
+    hi[e >> 1] = __builtin_bit_cast(uint32_t, h);
+    lo[e >> 1] = __builtin_bit_cast(uint32_t, l);
+  }
 }
 // The four register quads q = 0..3 of a 32x32 accumulator tile hold, per lane, channels 8q + 4h + 0..3 (h = lane >> 5) of one row.
 // After swapping quads (2p, 2p+1) between the half-waves, lanes 0-31 hold channels 16p + 0..7 and lanes 32-63 channels 16p + 8..15
@@ -121,17 +124,27 @@ struct PpEpiAct16 {
   f16* out;          // [M, ld] halves: PK: [N/32][32 hi | 32 lo], ld = 2N;  plain: [N], ld = N
   int64_t ld;
   int M, N;
+  // the weight conditioning's per-channel 2^-e[n] (GemmCore::w_alpha, or null) rides in the bias FMA: acc * 2^-e is exact, so fma(acc, 2^-e, bias)
+  // rounds exactly as pp_unscale's product followed by the bias add did — one instruction instead of two per output
+  static constexpr bool FUSES_UNSCALE = true;
   template <int TM, int TN>
-  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
+  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane, const float* alpha) const {
     const BufRsrc R = make_rsrc(out, (uint32_t)((int64_t)M * ld * 2));
     const int h = lane >> 5, r = lane & 31;
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
       const int nb = n_w + 32 * i;
       if (nb >= N) continue;  // wave-uniform
-      float4 b[4];
+      float4 b[4], al[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q) {
+        b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+        al[q] = alpha ? *reinterpret_cast<const float4*>(alpha + nb + 8 * q + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);  // wave-uniform choice
+      }
+      auto pre = [&](int j, int q, int e) {  // acc * 2^-e[n] + bias[n]
+        const float a = e == 0 ? al[q].x : e == 1 ? al[q].y : e == 2 ? al[q].z : al[q].w, bb = e == 0 ? b[q].x : e == 1 ? b[q].y : e == 2 ? b[q].z : b[q].w;
+        return __builtin_fmaf(acc[j][i][4 * q + e], a, bb);
+      };
       const uint32_t col = PK ? (uint32_t)(nb >> 5) * 128u : (uint32_t)nb * 2u;  // byte offset of the tile's 32 channels in a row
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
@@ -141,7 +154,7 @@ struct PpEpiAct16 {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[4 * q + e] = apply_act(ACT, acc[j][i][4 * q + e] + (e == 0 ? b[q].x : e == 1 ? b[q].y : e == 2 ? b[q].z : b[q].w));
+            for (int e = 0; e < 4; ++e) x[4 * q + e] = apply_act(ACT, pre(j, q, e));
           uint32_t hv[8], pw[8];
           mx_pack16<false>(x, hv, pw);
 #pragma unroll
@@ -156,8 +169,7 @@ struct PpEpiAct16 {
         uint32_t hi[4][2], lo[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float x[4] = {apply_act(ACT, acc[j][i][4 * q] + b[q].x), apply_act(ACT, acc[j][i][4 * q + 1] + b[q].y),
-                              apply_act(ACT, acc[j][i][4 * q + 2] + b[q].z), apply_act(ACT, acc[j][i][4 * q + 3] + b[q].w)};
+          const float x[4] = {apply_act(ACT, pre(j, q, 0)), apply_act(ACT, pre(j, q, 1)), apply_act(ACT, pre(j, q, 2)), apply_act(ACT, pre(j, q, 3))};
           pp::split4(x, hi[q], lo[q]);
         }
 #pragma unroll
@@ -395,6 +407,21 @@ __device__ __forceinline__ void pp_unscale(f32x16 (&acc)[TM][TN], const GemmCore
         acc[j][i][4 * q] *= a.x; acc[j][i][4 * q + 1] *= a.y; acc[j][i][4 * q + 2] *= a.z; acc[j][i][4 * q + 3] *= a.w;
       }
     }
+  }
+}
+
+// the wave-tile epilogue of a finished accumulator tile: the conditioning's 2^-e[n] first, inside the epilogue's own arithmetic where it fuses
+template <typename Epi, typename = void>
+struct pp_fuses_unscale : std::false_type {};
+template <typename Epi>
+struct pp_fuses_unscale<Epi, std::enable_if_t<Epi::FUSES_UNSCALE>> : std::true_type {};
+template <int TM, int TN, typename Epi>
+__device__ __forceinline__ void pp_finish(f32x16 (&acc)[TM][TN], const GemmCore& g, const Epi& epi, int m_w, int n_w, int lane) {
+  if constexpr (pp_fuses_unscale<Epi>::value) {
+    epi.template tile<TM, TN>(acc, m_w, n_w, lane, g.w_alpha);
+  } else {
+    pp_unscale<TM, TN>(acc, g, n_w, lane);
+    epi.template tile<TM, TN>(acc, m_w, n_w, lane);
   }
 }
 
@@ -645,8 +672,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
   } else if constexpr (KSP * KSS == 1) {
-    pp_unscale<TM, TN>(acc, g, n0 + wn * 32 * TN, lane);
-    epi.template tile<TM, TN>(acc, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+    pp_finish<TM, TN>(acc, g, epi, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   } else {
     // The two groups hold partial sums of the same tiles.  Tile t = j * TN + i is FINISHED by group (t < NT0 ? 0 : 1): every wave parks the
     // tiles it does not finish in the (now idle) ring — [wave][tile][quad][lane] float4, one conflict-free 1 KB run per store — and adds its
@@ -687,8 +713,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
             one[0][0][4 * q + 2] = o.z + acc[j][i][4 * q + 2]; one[0][0][4 * q + 3] = o.w + acc[j][i][4 * q + 3];
           }
         }
-        pp_unscale<1, 1>(one, g, n0 + wn * 32 * TN + 32 * i, lane);
-        epi.template tile<1, 1>(one, m0 + wm * 32 * TM + 32 * j, n0 + wn * 32 * TN + 32 * i, lane);
+        pp_finish<1, 1>(one, g, epi, m0 + wm * 32 * TM + 32 * j, n0 + wn * 32 * TN + 32 * i, lane);
       }
     });
   }

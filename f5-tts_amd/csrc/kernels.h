@@ -130,13 +130,12 @@ struct AudioTables {
   const float* melfb;     // [513, 100] HTK triangles
   const float* env_inv;   // unused (envelope computed per call)
 };
+// melrange [nmel][2]: first bin and one past the last bin with a non-zero filterbank weight, per mel channel
 hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
-                      const float* melfb, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s);
-// head logits [B*T, ld] (log-mag | phase) -> windowed time frames [B, T, 1024]
-hipError_t launch_istft_frames(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window,
-                               float* frames, hipStream_t s);
-// overlap-add + envelope normalisation + centre trim: frames [B, T, 1024] -> wav [B, 256*(T-1)]
-hipError_t launch_istft_ola(const float* frames, const float* window, int B, int T, float* wav, hipStream_t s);
+                      const float* melfb, const int* melrange, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s);
+// head logits [B*T, ld] (log-mag | phase) -> inverse real transform, window, overlap-add, envelope normalisation, centre trim ->
+// wav [B, 256*(T-1)]: one kernel, no intermediate in HBM
+hipError_t launch_istft(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window, float* wav, hipStream_t s);
 
 // ---- bigvgan.hip ------------------------------------------------------------------------------
 // BigVGAN generator path, channels-last fp32 activations [B, L, C] (see bigvgan.hip for the formulas each kernel evaluates).

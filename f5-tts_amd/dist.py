@@ -124,6 +124,46 @@ def pin_to_gpu_numa(local_rank: int) -> dict:
     return info
 
 
+def device_identity(local_rank: int, device_type: str = "cuda") -> dict:
+    """What THIS rank computes on: host name, the device index it set, and the PCI address (plus the UUID where torch exposes one) of that
+    device — the key two ranks must not share.  ``bench.py`` refuses a line whose ranks do not name N distinct devices."""
+    import socket
+
+    ident = {"rank": int(os.environ.get("RANK", "0")), "host": socket.gethostname(), "device_index": int(local_rank), "pci_bus_id": None, "uuid": None}
+    if device_type == "cuda" and torch.cuda.is_available():
+        p = torch.cuda.get_device_properties(local_rank)
+        bus = getattr(p, "pci_bus_id", None)
+        ident["pci_bus_id"] = bus.lower() if isinstance(bus, str) else "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0) or 0, bus or 0, getattr(p, "pci_device_id", 0) or 0)
+        if getattr(p, "uuid", None) is not None:
+            ident["uuid"] = str(p.uuid)
+        ident["device_index"] = int(torch.cuda.current_device())  # the device the rank's context REALLY sits on, not what it was told
+    return ident
+
+
+def device_census(ident: dict) -> List[dict]:
+    """All-gather of every rank's ``device_identity`` over the job's process group (the group the weight broadcast used), in rank order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [ident]
+    box: List[dict | None] = [None] * dist.get_world_size()
+    dist.all_gather_object(box, ident)
+    return sorted(box, key=lambda d: d["rank"])  # type: ignore[arg-type, index]
+
+
+def distinct_devices(census: Sequence[dict]) -> int:
+    """How many different physical devices a census names: (host, PCI address) where known, (host, device index) otherwise."""
+    return len({(d["host"], d["pci_bus_id"] or d["uuid"] or ("index", d["device_index"])) for d in census})
+
+
+def check_census(census: Sequence[dict], world: int) -> str | None:
+    """None if the census is ``world`` ranks 0 .. world-1 on ``world`` distinct devices, else the reason a bench line must not be printed."""
+    if sorted(d["rank"] for d in census) != list(range(world)):
+        return f"the census holds ranks {sorted(d['rank'] for d in census)}, not 0..{world - 1}"
+    n = distinct_devices(census)
+    if n != world:
+        return (f"{world} ranks name only {n} distinct device(s): " + ", ".join(f"rank {d['rank']} -> {d['host']}:{d['pci_bus_id'] or d['device_index']}" for d in census))
+    return None
+
+
 def ranks_seen(device) -> int:
     """An all-reduce of ones over the job's process group: how many ranks actually took part in a collective (1 without a group)."""
     if not dist.is_initialized():

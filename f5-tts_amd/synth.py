@@ -13,6 +13,7 @@ Everything is drawn from one CPU ``torch.Generator`` in a fixed order, so the sa
 from __future__ import annotations
 
 import math
+import re
 from typing import Dict
 
 import torch
@@ -284,6 +285,17 @@ def trained_like_dit_state_dict(sd: Dict[str, torch.Tensor], cfg: DiTConfig, see
             out[k] = w * float(v.std() / w.std())  # the tensor keeps its overall scale: the model stays in its operating range
         elif v.ndim == 1 and k.endswith(".bias"):
             out[k] = student_t(v.shape) * float(v.std())
+    return out
+
+
+def sharpen_attention_state_dict(sd: Dict[str, torch.Tensor], s: float) -> Dict[str, torch.Tensor]:
+    """Every query and key projection (``to_q`` / ``to_k`` and MMDiT's ``to_q_c`` / ``to_k_c``: weight AND bias) multiplied by ``s``, so every
+    attention logit is multiplied by ``s * s`` — the sharpness sweep of DESIGN.md section 2: how the half-precision modes' error moves as a
+    checkpoint's softmax rows approach one-hot.  Same keys, same shapes."""
+    out = {k: v.clone() for k, v in sd.items()}
+    for k in sd:
+        if re.search(r"\.to_[qk](_c)?\.(weight|bias)$", k):
+            out[k] = out[k] * float(s)
     return out
 
 

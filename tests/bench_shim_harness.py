@@ -42,6 +42,11 @@ def install():
         self.device = torch.device("cpu")
 
     E.F5HipEngine.__init__ = init_on_cpu
+    if os.environ.get("SHIM_RANKS_SHARE_ONE_DEVICE"):  # the refuse case of bench.py's device census: every rank reports the first rank's device
+        from f5_tts_amd import dist as fdist
+
+        real = fdist.device_identity
+        fdist.device_identity = lambda local, device_type="cuda": dict(real(local, device_type), device_index=0, pci_bus_id="0000:05:00.0")
     import bench
 
     bench.DEVICE_TYPE = "cpu"

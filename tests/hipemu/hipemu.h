@@ -38,6 +38,10 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
+struct int2 { int x, y; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }

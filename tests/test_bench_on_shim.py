@@ -53,6 +53,8 @@ def test_plain_gpus_2_command_launches_its_own_two_ranks(engine_emu_lib):  # noq
     assert d["config"]["graph"] is True  # the NFE loop is captured and replayed (stream capture emulated by the shim)
     assert d["value"] > 0 and "cpu_baseline" not in d  # the CPU baseline is a single-rank leg
     assert d["config"]["rccl_ranks_seen"] == 2 and len(d["config"]["host_numa_pinning"]) == 2  # the all-reduce census and every rank's pinning report
+    devs = d["config"]["rccl_devices"]  # the device census: one line per rank, two different devices
+    assert len(devs) == 2 and devs[0].startswith("rank 0:") and devs[1].startswith("rank 1:") and "cuda:0" in devs[0] and "cuda:1" in devs[1]
 
 
 def test_eight_ranks_name_the_sharded_configuration(engine_emu_lib):  # noqa: F811
@@ -62,6 +64,7 @@ def test_eight_ranks_name_the_sharded_configuration(engine_emu_lib):  # noqa: F8
             OMP_NUM_THREADS="1")
     assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == d["config"]["rccl_ranks_seen"] == 8
     assert len(d["config"]["per_rank_ms_per_step"]) == 8 and d["config"]["global_batch"] == 8
+    assert len(set(x.split(": ", 1)[1] for x in d["config"]["rccl_devices"])) == 8
 
 
 def test_under_the_drivers_launcher(engine_emu_lib):  # noqa: F811
@@ -75,3 +78,13 @@ def test_a_launch_of_the_wrong_size_is_refused(engine_emu_lib):  # noqa: F811
     out = run([sys.executable, HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib, expect_fail=True,
               WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     assert "refusing" in out
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_ranks_that_share_a_device_are_refused(engine_emu_lib, n):  # noqa: F811
+    """N ranks whose census names ONE device (a launcher that handed every rank the same LOCAL_RANK / a masked visible-device list) must not
+    print an N-GPU line: every rank sees the same all-gathered census and exits before any measurement."""
+    out = run([sys.executable, HARNESS, "--gpus", str(n), "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0"], engine_emu_lib, expect_fail=True,
+              timeout=1200, SHIM_RANKS_SHARE_ONE_DEVICE="1", OMP_NUM_THREADS="1")
+    assert "refusing" in out and f"{n} ranks name only 1 distinct device" in out
+    assert not [ln for ln in out.splitlines() if ln.startswith("{")]

@@ -34,6 +34,25 @@ def test_shard_balanced():
     assert abs(loads[0] - loads[1]) <= 4
 
 
+def test_census_check_names_distinct_devices():
+    """bench.py's multi-GPU guard (dist.check_census): N ranks must name N distinct (host, PCI address) pairs."""
+    from f5_tts_amd.dist import check_census, device_identity, distinct_devices
+
+    def ident(rank, idx, pci, host="box"):
+        return {"rank": rank, "host": host, "device_index": idx, "pci_bus_id": pci, "uuid": None}
+
+    good = [ident(r, r, "0000:%02x:00.0" % (5 + 8 * r)) for r in range(8)]
+    assert distinct_devices(good) == 8 and check_census(good, 8) is None
+    same = [ident(r, 0, "0000:05:00.0") for r in range(8)]  # eight ranks on one GPU
+    assert distinct_devices(same) == 1 and "8 ranks name only 1 distinct device" in check_census(same, 8)
+    assert "only 7" in check_census(good[:7] + [ident(7, 6, good[6]["pci_bus_id"])], 8)  # two ranks share the seventh
+    assert check_census([ident(0, 0, "a"), ident(0, 1, "b")], 2).startswith("the census holds ranks [0, 0]")  # a duplicated rank
+    assert check_census([ident(0, 3, "0000:05:00.0", "n0"), ident(1, 3, "0000:05:00.0", "n1")], 2) is None  # same slot on two hosts: distinct
+    assert check_census([ident(0, 0, None), ident(1, 1, None)], 2) is None and check_census([ident(0, 0, None), ident(1, 0, None)], 2)  # index fallback
+    me = device_identity(0, "cpu")
+    assert me["device_index"] == 0 and me["pci_bus_id"] is None and me["host"]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import f5_tts_amd  # noqa: F401

@@ -21,6 +21,8 @@
 #   pkprobe <tag>                       tools/probes/pk_opsel_probe (the standalone reproducer of the packed-fp32 operand fault) and
 #                                       tools/probes/pk_opsel_sweep (every operand selection), with and without partner waves
 #   ragged <tag> [frame budgets]        48 ragged synthetic utterances: bucketed / list order padded / list order packed rows
+#   ab <tag> [baseline]                 round 6: this build against tools/.ab/<baseline>/ on one box (GEMM tiles, q|k|v, bench.py B = 1 / B = 32)
+#   sweep <tag>                         round 6: tools/sharpness_sweep.py (error of every operand mode against goldens with logits x 1 .. 4)
 #   mx <tag>                            round 4: the fp16m mode (MX-fp6 correction lines) against fp16x3 in one call — GPU parity tests of the
 #                                       mode, the GEMM tiles on the B = 1 / B = 8 / B = 32 shapes in both modes, bench.py lines in both modes
 set -u
@@ -66,6 +68,37 @@ pmc() {  # counter passes (separate runs: counters only, never with tracing) + a
 }
 
 case $recipe in
+ab)
+  # round 6: the CURRENT build against a baseline build of libf5hip.so / libf5hip_bench.so kept under tools/.ab/<name>/ (git-ignored; made in the
+  # build container from `git archive <commit> f5-tts_amd/csrc include`), alternating on ONE box: GEMM tiles on the B = 1 and many-round shapes
+  # (KB_EPI 1 = the FeedForward GELU epilogue, 2 = gate + residual), the q|k|v launch, bench.py steps at B = 1 and B = 32
+  tag=${1:?tag}; base=${2:-base}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
+  BASE="F5HIP_LIB=$R/tools/.ab/$base/libf5hip.so F5HIP_BENCH_LIB=$R/tools/.ab/$base/libf5hip_bench.so"
+  B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048"
+  MID="11248,2048,1024;22496,2048,1024;89984,2048,1024;89984,1024,2048;89984,1024,1024"
+  { for which in base new base new; do
+      pre=""; [ $which = base ] && pre="env $BASE"
+      for epi in 1 2; do
+        KB_SHAPES=$B1 KB_PRECS=fp16m,fp16 KB_EPI=$epi KB_VARIANTS=-1 timeout 300 $pre python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/$which epi$epi /" | cut -c1-200
+        KB_SHAPES=$MID KB_PRECS=fp16m,fp16 KB_EPI=$epi KB_VARIANTS=-1 timeout 400 $pre python tools/kernel_bench.py gemm 2>&1 | grep ^gemm | sed "s/^/$which epi$epi /" | cut -c1-200
+      done
+      for sq in "2 1406" "64 1406"; do timeout 300 $pre python tools/kernel_bench.py qkv fp16m $sq -1 20 2>&1 | grep -E "^qkv" | awk 'NR%3==0' | sed "s/^/$which /"; done
+    done; } > $out/kernel_bench_ab.log 2>&1
+  cat $out/kernel_bench_ab.log | cut -c1-220
+  Q="--no-cpu-baseline --no-other-configs"
+  for i in 1 2 3; do
+    env $BASE timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_base_$i.json 2>> $out/bench.err; line $out/b1_base_$i.json b1_base_$i
+    timeout 600 python bench.py --steps 10 --warmup 3 $Q > $out/b1_new_$i.json 2>> $out/bench.err; line $out/b1_new_$i.json b1_new_$i
+  done
+  for i in 1 2; do
+    env $BASE timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/b32_base_$i.json 2>> $out/bench.err; line $out/b32_base_$i.json b32_base_$i
+    timeout 900 python bench.py --steps 2 --warmup 1 --batch 32 --nfe 32 $Q > $out/b32_new_$i.json 2>> $out/bench.err; line $out/b32_new_$i.json b32_new_$i
+  done
+  tail -3 $out/bench.err ;;
+sweep)
+  # round 6: the sharpness sweep (tools/sharpness_sweep.py) and the per-golden attention-score table in both half-precision modes
+  tag=${1:?tag}; out=gpurun_out/$tag; mkdir -p $out
+  timeout 1500 python tools/sharpness_sweep.py > $out/sharpness_sweep.md 2> $out/sharpness_sweep.err; cat $out/sharpness_sweep.md; tail -3 $out/sharpness_sweep.err ;;
 p8)
   # round 5: the ping-pong 256x256 kernel (csrc/gemm_p8.h, tile id 80) against the lockstep 256x256 tile (50) and the heuristic's choice:
   # value checks on the GPU, times on the many-round shapes with ablations, hipBLASLt yardstick, counters, B = 32 / B = 8 step A/B
