@@ -395,6 +395,8 @@ WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f1
 // 5.8e-4 with split q, k and by 3.7e-4 with everything split (profiles/r05g_attn_precision_fp16m.log): the scores feed an
 // exponential, so their ABSOLUTE error counts, and it grows with the logits.
 enum { QK_PLAIN = 0, QK_SPLIT = 1, QK_MX = 2 };
+// attn_impl 2, 6, 7 read V as hi + lo halves (the q|k|v epilogue writes the second V^T plane for them)
+inline bool attn_v_split(const f5hip_ctx* ctx) { return ctx->attn_impl == 2 || ctx->attn_impl == 6 || ctx->attn_impl == 7; }
 int qk_scheme_wanted(const f5hip_ctx* ctx, int op) {
   if (op != OP_F16X3 || ctx->attn_impl == 3) return QK_PLAIN;
   return ctx->attn_impl == 2 || ctx->attn_impl == 4 ? QK_SPLIT : QK_MX;
@@ -897,7 +899,7 @@ int run_text_embed(f5hip_ctx* ctx, int B, int n, const int64_t* text, int nt, co
     HIPCHK(launch_dwconv7_ln(tx, 2 * B, n, T, tb.dw7, tb.dw_b, tb.ln_w, tb.ln_b, 1e-6f, ctx->ta.as<float>(), st));
     GemmCore g = core(ctx->ta.p, T, tb.pw1_w, T, (int)M, 2 * T, T);
     HIPCHK(launch_gemm_store(OP_F32, g, epi_store(ctx->th.as<float>(), 2 * T, tb.pw1_b, ACT_GELU_ERF), 1, st));
-    HIPCHK(launch_grn_sumsq(ctx->th.as<float>(), 2 * B, n, 2 * T, ctx->sumsq.as<float>(), ctx->sumsq.as<float>() + (int64_t)2 * B * 2 * T, st));
+    HIPCHK(launch_grn_stats(ctx->th.as<float>(), 2 * B, n, 2 * T, ctx->sumsq.as<float>(), ctx->sumsq.as<float>() + (int64_t)2 * B * 2 * T, st));
     HIPCHK(launch_grn_apply(ctx->th.as<float>(), ctx->sumsq.as<float>(), tb.gamma, tb.beta, 2 * B, n, 2 * T, ctx->tg.as<float>(), st));
     g = core(ctx->tg.p, 2 * T, tb.pw2_w, 2 * T, (int)M, T, 2 * T);
     EpiStore e = epi_store(tx, T, tb.pw2_b);
@@ -944,12 +946,16 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         HIPCHK(launch_gemm_store(OP_F32, g, e2, S * H, st));
       } else {
         // qks: what the q|k|v epilogue of this chunk left in the second planes of q and k (run_qkv) — nothing, fp16 remainders or MX P words
-        const bool x3 = qks == QK_SPLIT, all3 = x3 && ctx->attn_impl == 2, lo = qks != QK_PLAIN;
+        // (split scores: where the q|k|v launch cannot write P words — MMDiT, qk_norm, tiny row counts — attn_impl 6 / 7 run the everything-split form)
+        const bool x3 = qks == QK_SPLIT, all3 = x3 && attn_v_split(ctx), lo = qks != QK_PLAIN;
         const int ldv = (n + 7) & ~7;
         const int64_t voff = (int64_t)s0 * inner * ldv;
-        HIPCHK(launch_flash_attn(qks == QK_MX ? 4 : x3 ? (all3 ? 3 : 2) : 1, ctx->q16.as<f16>() + qoff, lo ? ctx->q16_lo.as<f16>() + qoff : nullptr,
+        // kernel form: 1 plain, 2 split q k, 3 everything split, 4 MX-corrected scores, 5 / 6 the same with V / V and P as hi + lo halves
+        const bool vlo = all3 || (qks == QK_MX && (ctx->attn_impl == 6 || ctx->attn_impl == 7));
+        const int form = qks == QK_MX ? (ctx->attn_impl == 6 ? 5 : ctx->attn_impl == 7 ? 6 : 4) : x3 ? (all3 ? 3 : 2) : 1;
+        HIPCHK(launch_flash_attn(form, ctx->q16.as<f16>() + qoff, lo ? ctx->q16_lo.as<f16>() + qoff : nullptr,
                                  ctx->k16.as<f16>() + qoff, lo ? ctx->k16_lo.as<f16>() + qoff : nullptr, ctx->vt16.as<f16>() + voff,
-                                 all3 ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
+                                 vlo ? ctx->vt16_lo.as<f16>() + voff : nullptr, ldv, S, H, n, kvlen, o_hi, o_lo, st, pk,
                                  kvlen2, seg2_off, 1, ctx->attn_part.p ? ctx->attn_kv_split : 1,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 : nullptr,
                                  ctx->attn_part.p ? ctx->attn_part.as<float>() + (int64_t)s0 * H * n * ctx->attn_kv_split * 66 + (int64_t)S * H * n * ctx->attn_kv_split * 64 : nullptr,
@@ -990,7 +996,7 @@ int run_qkv(f5hip_ctx* ctx, const BlockW& bw, const void* A, int64_t ldA, int M,
     const int64_t voff = rowinfo ? 0 : (int64_t)s0 * inner * e.ldvt;
     e.q16_lo = ctx->q16_lo.as<f16>() + qoff; e.k16_lo = ctx->k16_lo.as<f16>() + qoff;
     e.mx_qk = *qks == QK_MX;
-    if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
+    if (attn_v_split(ctx)) e.vt16_lo = ctx->vt16_lo.as<f16>() + voff;
   }
   {
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
@@ -1489,7 +1495,7 @@ int run_step_mmdit(f5hip_ctx* ctx, int B, int n, int nt, const Stage& sg, int op
       e.q16 = ctx->q16.as<f16>(); e.k16 = ctx->k16.as<f16>(); e.vt16 = ctx->vt16.as<f16>();
       if (qks != QK_PLAIN) {
         e.q16_lo = ctx->q16_lo.as<f16>(); e.k16_lo = ctx->k16_lo.as<f16>();
-        if (ctx->attn_impl == 2) e.vt16_lo = ctx->vt16_lo.as<f16>();
+        if (attn_v_split(ctx)) e.vt16_lo = ctx->vt16_lo.as<f16>();
       }
     }
     Prof pr(ctx, st, KC_GEMM_BLOCK, gemm_flops(M, 3 * inner, D), (double)M * D * wbytes + 3.0 * inner * D * wbytes + (double)M * 3 * inner * wbytes);
@@ -1860,7 +1866,8 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
   const int op = op_of(precision);
   // attn_impl: 0 auto (fp32 -> materialised fp32 scores; fp16 -> flash attention, plain fp16 operands; fp16x3 / fp16m -> flash attention with
   // MX-corrected scores, qk_scheme_wanted above), 1 force materialised, 2 flash with every operand split, 3 flash with plain fp16 operands
-  // in every mode (the default of rounds 2-4), 4 flash with split q, k and plain P, V, 5 = 0 for the half-precision modes
+  // in every mode (the default of rounds 2-4), 4 flash with split q, k and plain P, V, 5 = 0 for the half-precision modes, 6 / 7 = 0 with V / V
+  // and P as hi + lo halves (round 6: the margin against sharper attention than any golden's)
   const bool exact_attn = ctx->attn_impl == 1 || (ctx->attn_impl == 0 && (precision == F5HIP_PREC_FP32 || !flash_attn_available()));
   if (!exact_attn && precision == F5HIP_PREC_FP32) FAIL(F5HIP_ERR_INVALID, "flash attention needs an fp16 precision mode");
   const int mel = c.mel_dim, D = c.dim;
@@ -1955,7 +1962,7 @@ int f5hip_sample(f5hip_ctx* ctx, int B, int n, const float* cond, const uint8_t*
       // (2 B inner ldv halves: microseconds)
       const int64_t ldv = (n + 7) & ~7;
       HIPCHK(hipMemsetAsync(ctx->vt16.p, 0, (size_t)((int64_t)2 * B * c.heads * c.dim_head * ldv * 2), st));
-      if (ctx->vt16_lo.p && ctx->attn_impl == 2) HIPCHK(hipMemsetAsync(ctx->vt16_lo.p, 0, (size_t)((int64_t)2 * B * c.heads * c.dim_head * ldv * 2), st));
+      if (ctx->vt16_lo.p && attn_v_split(ctx)) HIPCHK(hipMemsetAsync(ctx->vt16_lo.p, 0, (size_t)((int64_t)2 * B * c.heads * c.dim_head * ldv * 2), st));
     }
   }
   {

@@ -58,11 +58,11 @@ hipError_t launch(FlashArgs a, int bh, int co, hipStream_t s) {
 #define F5_FLASH(NWV, VS, LZ, THREADS) hipLaunchKernelGGL((flash_attn_kernel<NSPLIT, PVSPLIT, NWV, false, VS, LZ>), dim3(a.nwg), dim3(THREADS), lds, s, a)
   if (six) {
     a.nqb = nqb6; a.nwg = bh * nqb6;
-    if (vsum && PVSPLIT == 1) { if (lazy) F5_FLASH(6, true, true, 384); else F5_FLASH(6, true, false, 384); }
+    if (vsum && PVSPLIT != 3) { if (lazy) F5_FLASH(6, true, true, 384); else F5_FLASH(6, true, false, 384); }
     else { if (lazy) F5_FLASH(6, false, true, 384); else F5_FLASH(6, false, false, 384); }
   } else {
     a.nqb = nqb4; a.nwg = bh * nqb4;
-    if (vsum && PVSPLIT == 1) { if (lazy) F5_FLASH(4, true, true, 256); else F5_FLASH(4, true, false, 256); }
+    if (vsum && PVSPLIT != 3) { if (lazy) F5_FLASH(4, true, true, 256); else F5_FLASH(4, true, false, 256); }
     else { if (lazy) F5_FLASH(4, false, true, 256); else F5_FLASH(4, false, false, 256); }
   }
 #undef F5_FLASH
@@ -81,7 +81,7 @@ hipError_t set_attr() {  // every instantiation launch() can pick
   if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, false, true>()) != hipSuccess) return e;
   if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, false, false>()) != hipSuccess) return e;
   if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, false, true>()) != hipSuccess) return e;
-  if constexpr (PVSPLIT == 1) {
+  if constexpr (PVSPLIT != 3) {
     if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, true, false>()) != hipSuccess) return e;
     if ((e = set_attr_one<NSPLIT, PVSPLIT, 4, false, true, true>()) != hipSuccess) return e;
     if ((e = set_attr_one<NSPLIT, PVSPLIT, 6, false, true, false>()) != hipSuccess) return e;
@@ -104,6 +104,8 @@ hipError_t init_attention_kernels() {
   if ((e = set_attr_pipe<6, true>()) != hipSuccess) return e;
   if ((e = set_attr<1, 1>()) != hipSuccess) return e;
   if ((e = set_attr<2, 1>()) != hipSuccess) return e;
+  if ((e = set_attr<2, 2>()) != hipSuccess) return e;
+  if ((e = set_attr<2, 3>()) != hipSuccess) return e;
   if ((e = set_attr<3, 1>()) != hipSuccess) return e;
   return set_attr<3, 3>();
 }
@@ -130,6 +132,10 @@ hipError_t launch_flash_attn(int nsplit, const f16* q, const f16* q_lo, const f1
   if (nsplit == 4) {  // scores = fp16 hi . hi + the two correction products as MX-fp6 (q_lo, k_lo hold P words), plain fp16 P and V
     if (!q_lo || !k_lo || ((reinterpret_cast<uintptr_t>(q_lo) | reinterpret_cast<uintptr_t>(k_lo)) & 15)) return hipErrorInvalidValue;
     return launch<2, 1>(a, bh, co_launches < 1 ? 1 : co_launches, s);
+  }
+  if (nsplit == 5 || nsplit == 6) {  // MX-corrected scores; V as hi + lo halves (5), P as well (6)
+    if (!q_lo || !k_lo || !vt_lo || ((reinterpret_cast<uintptr_t>(q_lo) | reinterpret_cast<uintptr_t>(k_lo)) & 15)) return hipErrorInvalidValue;
+    return nsplit == 5 ? launch<2, 2>(a, bh, co_launches < 1 ? 1 : co_launches, s) : launch<2, 3>(a, bh, co_launches < 1 ? 1 : co_launches, s);
   }
   if (nsplit == 2) {  // hi/lo q and k (scores), plain fp16 P and V
     if (!q_lo || !k_lo) return hipErrorInvalidValue;

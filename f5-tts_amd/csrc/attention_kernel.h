@@ -100,16 +100,19 @@ __device__ __forceinline__ void flash_store_row(const FlashArgs& a, const f32x16
     }
 }
 
-// NSPLIT: operand split of S = QK^T (1, 2 or 3); PVSPLIT: of O = PV (1 or 3, <= NSPLIT).  The scores feed an exponential, so
+// NSPLIT: operand split of S = QK^T (1, 2 or 3); PVSPLIT: of O = PV (1, 2 or 3).  The scores feed an exponential, so
 // their rounding matters ~10x more than that of P and V: NSPLIT = 3 with PVSPLIT = 1 keeps near-fp32 scores at 4 instead of 6
-// MFMAs per key-query pair.  NSPLIT = 2 (round 5): the two correction products K_hi . Q_lo + K_lo . Q_hi of the split as ONE MX-fp6 MFMA per
+// MFMAs per key-query pair.  PVSPLIT = 2 (round 6): V as hi + lo halves, P plain — O = V_hi P + V_lo P, one more fp16 MFMA per product.
+// The sharpness sweep showed that the error of plain fp16 P . V GROWS with the logits — under near one-hot rows the
+// output is one V row and nothing averages its 2^-12 rounding away — and the CPU decomposition (oracle/operand_scheme_emulation.py
+// --attn v16 / p16 / vs) that V carries 2.6x the error of P; PVSPLIT = 3 adds V_hi P_lo as well.  NSPLIT = 2 (round 5): the two correction products K_hi . Q_lo + K_lo . Q_hi of the split as ONE MX-fp6 MFMA per
 // 32 head channels (common.h, "fp16 + MX-fp6 corrections": the block GEMMs' scheme) — 6 MFMAs per 32 keys x 32 queries where NSPLIT = 3
 // takes 12 and plain fp16 takes 4.  The second plane of q and of k then holds, per row, the P words of its two 32-channel blocks:
 // [block 0: P_0 | P_1][block 1: P_0 | P_1], 32 bytes each, q packed as the activation and k as the weight (the QKV epilogue writes both
 // from the lane's own 16 channels, gemm_pp.h PpEpiQKV::mx_qk).
 template <int NSPLIT, int PVSPLIT>
 constexpr int flash_lds_bytes() {
-  return 2 * ((NSPLIT >= 2 ? 2 : 1) * K_PLANE + (PVSPLIT == 3 ? 2 : 1) * V_PLANE);
+  return 2 * ((NSPLIT >= 2 ? 2 : 1) * K_PLANE + (PVSPLIT >= 2 ? 2 : 1) * V_PLANE);
 }
 
 // NW: waves per workgroup = 32-row query groups per block.  4 (128 query rows, two workgroups per CU) everywhere except where 6
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   static_assert(!(LAZY && SPLIT), "the key-split partial results carry exact maxima");
   static_assert(NSPLIT == 1 || NSPLIT == 2 || NSPLIT == 3, "operands of the scores: plain, fp16 + MX corrections, hi/lo split");
   constexpr int NPL = NSPLIT >= 2 ? 2 : 1;    // planes of q and k
-  constexpr int NPV = PVSPLIT == 3 ? 2 : 1;   // planes of v and P
+  constexpr int NPV = PVSPLIT >= 2 ? 2 : 1;   // planes of v
+  constexpr int NPP = PVSPLIT == 3 ? 2 : 1;   // planes of P
   constexpr bool MXQK = NSPLIT == 2;          // plane 1 = P words
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
   F5_DYN_LDS(char, smem);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   // wave), and 32 of those VALU are the adds of the row sum.  A V^T fragment of ones turns them into 4 MFMAs per tile on the pipe that
   // has the slack: every accumulator row then holds sum_k P[q][k] over the 16 keys of a group — of BOTH half-waves, so the final
   // lane ^ 32 exchange goes too.  The sum is that of the fp16 P the O product uses (numerator and denominator see the same weights).
-  constexpr bool MSUM = NPV == 1 && !VSUM;
+  constexpr bool MSUM = NPP == 1 && !VSUM;
   Frag ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones.h[e] = (f16)1.0f;
@@ -335,13 +339,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     for (int r = 0; r < 16; ++r) rsum[r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {  // 16-key groups of the tile; P registers 8*(g&1) .. +7 of s[g>>1]
-      Frag fp[NPV];
+      Frag fp[NPP];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float p = s[g >> 1][8 * (g & 1) + e];
         const f16 ph = (f16)p;
         fp[0].h[e] = ph;
-        if constexpr (NPV == 2) fp[1].h[e] = (f16)(p - (float)ph);
+        if constexpr (NPP == 2) fp[1].h[e] = (f16)(p - (float)ph);
       }
       if constexpr (MSUM) Mma32<f16>::mma(rsum, ones, fp[0]);
 #pragma unroll
@@ -355,10 +359,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
           fv[p].u = make_uint4(v0.x, v0.y, v1.x, v1.y);
         }
         Mma32<f16>::mma(o[db], fv[0], fp[0]);
-        if constexpr (NPV == 2) {
-          Mma32<f16>::mma(o[db], fv[0], fp[1]);  // V_hi . P_lo
-          Mma32<f16>::mma(o[db], fv[1], fp[0]);  // V_lo . P_hi
-        }
+        if constexpr (NPP == 2) Mma32<f16>::mma(o[db], fv[0], fp[1]);  // V_hi . P_lo
+        if constexpr (NPV == 2) Mma32<f16>::mma(o[db], fv[1], fp[0]);  // V_lo . P_hi
       }
     }
     if constexpr (MSUM) l_run = l_run * alpha + rsum[0];  // the whole row: both half-waves' keys

@@ -136,8 +136,27 @@ __device__ __forceinline__ float apply_act(int act, float x) {
   }
 }
 
+// Two floats -> two halves as ONE packed conversion (v_cvt_pk_f16_f32) of two MATERIALISED fp32 values.  Why the inputs are made opaque
+// (round 6): where a value is a product x * r, hipcc is free (-ffp-contract=fast) to form a half as v_fma_mixlo_f16(x, r, 0) — the EXACT
+// product rounded once — in one place and as the conversion of the fp32-ROUNDED product in another: for the stored half and for the half a
+// remainder v - (float)hi is taken from, or in one unrolled copy of an epilogue and not in the next.  The two agree except where the product
+// sits within an fp32 ulp of a half-way point (tools/probes/cvt_pk_f16_probe.hip: 144 of 2 M products).  Seen on the GPU, never on the host
+// shim (one conversion): hi + lo off by one fp16 ulp in 0.007 % of the operand elements (the stored hi and the remainder's hi derived
+// apart), and identical utterances of one batch 6e-5 apart (rows in different 32-row tiles of a wave rounded by different instructions).
+// With the inputs pinned to fp32 registers every half is RNE16(fl32(value)) wherever and however often it is derived.
+__device__ __forceinline__ f16x2 pack_f16x2(float a, float b) {
+#ifndef F5_HIPEMU
+  asm volatile("" : "+v"(a), "+v"(b));
+#endif
+  const f16x2 h = {(f16)a, (f16)b};
+  return h;
+}
+
 // fp16 hi/lo split: v ~= hi + lo with 22 significant bits
 __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
+#ifndef F5_HIPEMU
+  asm volatile("" : "+v"(v));  // v as ONE fp32 value: the stored half and the half the remainder is taken from cannot be derived apart (pack_f16x2)
+#endif
   hi = (f16)v;
   lo = (f16)(v - (float)hi);
 }
@@ -188,22 +207,35 @@ __device__ __forceinline__ void mx_pack16(const float (&v)[16], uint32_t (&hi)[8
   f32x16 c, l;
 #pragma unroll
   for (int t = 0; t < 16; t += 2) {
-    const f16x2 hp = {(f16)v[t], (f16)v[t + 1]};  // a vector of two: one v_cvt_pk_f16_f32
-    const f16 h0 = hp[0], h1 = hp[1];
-    hi[t >> 1] = __builtin_bit_cast(uint32_t, hp);
-    c[t] = v[t]; c[t + 1] = v[t + 1];
-    l[t] = (v[t] - (float)h0) * 2048.0f;  // exact: the remainder has <= 13 significant bits, 2^11 is a power of two
-    l[t + 1] = (v[t + 1] - (float)h1) * 2048.0f;
-  }
-  const u32x6 r = WEIGHT ? __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(l, c, S) : __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(c, l, S);
+    float va = v[t], vb = v[t + 1];  // pinned to fp32 registers: halves, coarse values and remainders all come off the same two values
 #ifndef F5_HIPEMU
-  // The conversion's scale register must not be one of its six destination registers.  The compiler allows it (the scale is dead behind the
-  // instruction), the hardware converts in several passes and reads the scale in each: with the scale in the first destination dword every
-  // element behind the first pass is scaled by payload bits.  Round 5: the q|k|v epilogue's P words, where the allocator chose exactly that
-  // in all 53 kernels, decoded to noise on the GPU and correctly on the host shim (profiles/r05h_mxqk_check_scale_overlap.log); the
-  // round-4 epilogues happened to keep the scale elsewhere.  Keeping S alive behind the conversion makes the two interfere;
-  // tests/test_isa_hazards.py scans every built kernel for the overlap.
-  asm volatile("" ::"v"(S));
+    asm volatile("" : "+v"(va), "+v"(vb));
+#endif
+    const f16x2 hp = {(f16)va, (f16)vb};  // one v_cvt_pk_f16_f32
+    hi[t >> 1] = __builtin_bit_cast(uint32_t, hp);
+    c[t] = va; c[t + 1] = vb;
+    l[t] = (va - (float)hp[0]) * 2048.0f;  // exact: the remainder has <= 13 significant bits, 2^11 is a power of two
+    l[t + 1] = (vb - (float)hp[1]) * 2048.0f;
+  }
+#ifdef F5_HIPEMU
+  const u32x6 r = WEIGHT ? __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(l, c, S) : __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(c, l, S);
+#else
+  // v_cvt_scalef32_2xpk16_fp6_f32 converts its 16 + 16 values in passes of 4 + 4 (1.5 destination dwords each) and reads scale and sources
+  // in every pass, so its DESTINATION must overlap neither.  Two hazards of the register allocator's freedom, both found on the GPU with the
+  // host shim (no register file) clean:
+  //  * round 5: the scale in the first destination dword (it is dead behind the instruction) — everything behind the first pass scaled by
+  //    payload bits: the q|k|v epilogue's P words decoded to noise in all 53 kernels (profiles/r05h_mxqk_check_scale_overlap.log);
+  //  * round 6: the destination INSIDE a source tuple at a positive offset (v[6:11] <- v[2:17], v[18:33]: layernorm_mx_kernel, whenever the
+  //    code around the pack changed a little) — destination dword k is written in pass k / 1.5, source dword j is read in pass j / 4, so
+  //    source dwords 4, 5 are payload by the time their pass reads them: one or two of a block's 16 coarse values wrong, every format check
+  //    green (2 of 32 fp6 elements at 2^-11 of the product), the trained-like golden at 1.0e-3 instead of 4.9e-4 (bisected over five library
+  //    builds, profiles/r06f_fp6_dst_in_src_bisect.log).  A destination at offset 0 of a source is safe and was the common case.
+  // Keeping the inputs alive behind the builtin (an empty asm that reads them) stopped the first but not the second: the allocator still
+  // split the source tuple.  The instruction is therefore issued as inline asm with an EARLY-CLOBBER destination — no overlap with any input by
+  // construction; tests/test_isa_hazards.py scans every instance in the built library for both forms.
+  u32x6 r;
+  if constexpr (WEIGHT) asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(l), "v"(c), "v"(S));
+  else asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(r) : "v"(c), "v"(l), "v"(S));
 #endif
 #pragma unroll
   for (int i = 0; i < 6; ++i) p[i] = r[i];

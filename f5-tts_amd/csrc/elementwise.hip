@@ -328,59 +328,97 @@ __global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 // GRN
 // ---------------------------------------------------------------------------------------------
-// grid (C/64, S): block of 256 = 4 row-phases x 64 channels
-// Two passes: blockIdx.z cuts the sequence into gridDim.z slices whose partial sums land in part[(s * RS + z) * C + c]; the finish kernel adds
-// them in slice order (deterministic).  One pass over a whole sequence per 64 channels (round 1) kept 32 workgroups busy for 100 us.
+// Round 6 (grn_apply at 22 % / 46 % of HBM peak, the finish kernel 8.8 us for 300 KB).  Three kernels per GRN:
+//   grn_sumsq_kernel   grid (slices, S): a workgroup sums h^2 over its slice of rows for ALL channels — whole 4 KB rows per load instruction
+//                      (the round-1 form read 256-byte pieces of a row per workgroup) — into part[(s * RS + z) * C + c];
+//   grn_finish_kernel  grid S: adds the slices in slice order (all loads issued before the first add: the serial form paid one L2 round trip
+//                      per slice), takes Gx = sqrt, the channel mean once per SEQUENCE (the round-1 apply kernel re-reduced it in every wave,
+//                      4 KB of L2 reads and C square roots per row) and writes nx[s, c] = Gx / (mean_c(Gx) + 1e-6);
+//   grn_apply_kernel   a wave keeps nx, gamma, beta of its channels in registers over GRN_ROWS rows of one sequence: per row 4 KB in, 4 KB out.
+constexpr int GRN_MAX_SLICES = 32;
+constexpr int GRN_ROWS = 8;  // rows per wave of grn_apply_kernel
 __global__ __launch_bounds__(256) void grn_sumsq_kernel(const float* __restrict__ h, int n, int C, float* part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int ph = threadIdx.x >> 6;
-  const int s = blockIdx.y, RS = gridDim.z, z = blockIdx.z;
+  const int s = blockIdx.y, RS = gridDim.x, z = blockIdx.x;
   const int r0 = (int)((int64_t)n * z / RS), r1 = (int)((int64_t)n * (z + 1) / RS);
-  float acc = 0.f;
-  if (c < C) {
-    const float* p = h + (int64_t)s * n * C + c;
-    for (int r = r0 + ph; r < r1; r += 4) {
-      const float v = p[(int64_t)r * C];
-      acc += v * v;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    const float* p = h + ((int64_t)s * n + r0) * C + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = r0;
+    for (; r + 4 <= r1; r += 4, p += 4 * (int64_t)C) {  // four rows in flight
+      const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + C);
+      const float4 d = *reinterpret_cast<const float4*>(p + 2 * (int64_t)C), e = *reinterpret_cast<const float4*>(p + 3 * (int64_t)C);
+      acc.x += a.x * a.x; acc.y += a.y * a.y; acc.z += a.z * a.z; acc.w += a.w * a.w;
+      acc.x += b.x * b.x; acc.y += b.y * b.y; acc.z += b.z * b.z; acc.w += b.w * b.w;
+      acc.x += d.x * d.x; acc.y += d.y * d.y; acc.z += d.z * d.z; acc.w += d.w * d.w;
+      acc.x += e.x * e.x; acc.y += e.y * e.y; acc.z += e.z * e.z; acc.w += e.w * e.w;
     }
+    for (; r < r1; ++r, p += C) {
+      const float4 a = *reinterpret_cast<const float4*>(p);
+      acc.x += a.x * a.x; acc.y += a.y * a.y; acc.z += a.z * a.z; acc.w += a.w * a.w;
+    }
+    *reinterpret_cast<float4*>(part + ((int64_t)s * RS + z) * C + c) = acc;
   }
-  red[ph][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (ph == 0 && c < C) part[((int64_t)s * RS + z) * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void grn_sumsq_finish_kernel(const float* __restrict__ part, int RS, int64_t SC, int C, float* sumsq) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // s * C + c
-  if (i >= SC) return;
-  const int64_t s = i / C, c = i - s * C;
-  float acc = 0.f;
-  for (int z = 0; z < RS; ++z) acc += part[(s * RS + z) * C + c];
-  sumsq[i] = acc;
+// one workgroup per sequence: nx[s, c] = sqrt(sum_z part) / (mean_c sqrt(.) + 1e-6)
+__global__ __launch_bounds__(256) void grn_finish_kernel(const float* __restrict__ part, int RS, int C, float* nx) {
+  __shared__ float red[4];
+  const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float local = 0.f;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    float4 v[GRN_MAX_SLICES];
+#pragma unroll
+    for (int z = 0; z < GRN_MAX_SLICES; ++z)
+      v[z] = z < RS ? *reinterpret_cast<const float4*>(part + ((int64_t)s * RS + z) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int z = 0; z < GRN_MAX_SLICES; ++z) { acc.x += v[z].x; acc.y += v[z].y; acc.z += v[z].z; acc.w += v[z].w; }
+    const float4 g = make_float4(sqrtf(acc.x), sqrtf(acc.y), sqrtf(acc.z), sqrtf(acc.w));
+    *reinterpret_cast<float4*>(nx + (int64_t)s * C + c) = g;  // Gx for now: divided below, by the threads that wrote it
+    local += (g.x + g.y) + (g.z + g.w);
+  }
+  local = wave_sum(local);
+  if (lane == 0) red[wave] = local;
+  __syncthreads();
+  const float denom = ((red[0] + red[1]) + (red[2] + red[3])) / (float)C + 1e-6f;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    float4 g = *reinterpret_cast<const float4*>(nx + (int64_t)s * C + c);
+    g.x /= denom; g.y /= denom; g.z /= denom; g.w /= denom;
+    *reinterpret_cast<float4*>(nx + (int64_t)s * C + c) = g;
+  }
 }
 
-// one wave per row; every wave first reduces mean_c(sqrt(sumsq[s,:])) (C floats, L2-resident)
-__global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ h, const float* __restrict__ sumsq,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int S, int n,
-                                                         int C, float* out) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= (int64_t)S * n) return;
-  const int s = (int)(row / n);
-  const float* ss = sumsq + (int64_t)s * C;
-  float part = 0.f;
-  for (int c = lane; c < C; c += 64) part += sqrtf(ss[c]);
-  const float denom = wave_sum(part) / (float)C + 1e-6f;
-  for (int c = lane * 4; c < C; c += 256) {
-    const float4 hv = *reinterpret_cast<const float4*>(h + row * C + c);
-    const float4 sv = *reinterpret_cast<const float4*>(ss + c);
-    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 b = *reinterpret_cast<const float4*>(beta + c);
-    float4 o;
-    o.x = g.x * (hv.x * (sqrtf(sv.x) / denom)) + b.x + hv.x;
-    o.y = g.y * (hv.y * (sqrtf(sv.y) / denom)) + b.y + hv.y;
-    o.z = g.z * (hv.z * (sqrtf(sv.z) / denom)) + b.z + hv.z;
-    o.w = g.w * (hv.w * (sqrtf(sv.w) / denom)) + b.w + hv.w;
-    *reinterpret_cast<float4*>(out + row * C + c) = o;
+// grid (ceil(n / (4 GRN_ROWS)), S): wave w of a block takes rows [GRN_ROWS (4 blockIdx.x + w), + GRN_ROWS) of sequence blockIdx.y.
+// VPL float4 per lane cover C <= 1024 VPL / 4 channels.
+template <int VPL>
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ h, const float* __restrict__ nx,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int n, int C, float* out) {
+  const int lane = threadIdx.x & 63, s = blockIdx.y;
+  const int r0 = (blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * GRN_ROWS;
+  if (r0 >= n) return;
+  float4 sv[VPL], g[VPL], b[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const bool in = c < C;
+    sv[i] = in ? *reinterpret_cast<const float4*>(nx + (int64_t)s * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    g[i] = in ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b[i] = in ? *reinterpret_cast<const float4*>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int r1 = r0 + GRN_ROWS < n ? r0 + GRN_ROWS : n;
+  for (int r = r0; r < r1; ++r) {
+    const int64_t row = (int64_t)s * n + r;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c >= C) continue;
+      const float4 hv = *reinterpret_cast<const float4*>(h + row * C + c);
+      float4 o;
+      o.x = g[i].x * (hv.x * sv[i].x) + b[i].x + hv.x;
+      o.y = g[i].y * (hv.y * sv[i].y) + b[i].y + hv.y;
+      o.z = g[i].z * (hv.z * sv[i].z) + b[i].z + hv.z;
+      o.w = g[i].w * (hv.w * sv[i].w) + b[i].w + hv.w;
+      *reinterpret_cast<float4*>(out + row * C + c) = o;
+    }
   }
 }
 
@@ -632,23 +670,24 @@ hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w
   return hipGetLastError();
 }
 
-int grn_sumsq_slices(int n) { return n >= 256 ? 32 : 1; }
-hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, float* part, hipStream_t s) {
-  const int RS = grn_sumsq_slices(n);  // part: S * RS * C floats (may alias sumsq when RS == 1)
-  if (RS == 1) {
-    hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S, 1), dim3(256), 0, s, h, n, C, sumsq);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(grn_sumsq_kernel, dim3((C + 63) / 64, S, RS), dim3(256), 0, s, h, n, C, part);
-  const int64_t SC = (int64_t)S * C;
-  hipLaunchKernelGGL(grn_sumsq_finish_kernel, dim3((unsigned)((SC + 255) / 256)), dim3(256), 0, s, part, RS, SC, C, sumsq);
+int grn_sumsq_slices(int n) { return n >= 256 ? GRN_MAX_SLICES : 1; }
+// nx [S, C] <- Gx / (mean_c Gx + 1e-6); part: S * slices * C floats of scratch
+hipError_t launch_grn_stats(const float* h, int S, int n, int C, float* nx, float* part, hipStream_t s) {
+  if (C % 4) return hipErrorInvalidValue;
+  const int RS = grn_sumsq_slices(n);
+  hipLaunchKernelGGL(grn_sumsq_kernel, dim3(RS, S), dim3(256), 0, s, h, n, C, part);
+  hipLaunchKernelGGL(grn_finish_kernel, dim3(S), dim3(256), 0, s, part, RS, C, nx);
   return hipGetLastError();
 }
-hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,
+hipError_t launch_grn_apply(const float* h, const float* nx, const float* gamma, const float* beta, int S, int n, int C,
                             float* out, hipStream_t s) {
-  if (C % 4) return hipErrorInvalidValue;
-  const int64_t rows = (int64_t)S * n;
-  hipLaunchKernelGGL(grn_apply_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, h, sumsq, gamma, beta, S, n, C, out);
+  if (C % 4 || C > 4096) return hipErrorInvalidValue;
+  const dim3 grid((n + WAVES_PER_BLOCK * GRN_ROWS - 1) / (WAVES_PER_BLOCK * GRN_ROWS), S);
+  if (C <= 256) hipLaunchKernelGGL(grn_apply_kernel<1>, grid, dim3(256), 0, s, h, nx, gamma, beta, n, C, out);
+  else if (C <= 512) hipLaunchKernelGGL(grn_apply_kernel<2>, grid, dim3(256), 0, s, h, nx, gamma, beta, n, C, out);
+  else if (C <= 1024) hipLaunchKernelGGL(grn_apply_kernel<4>, grid, dim3(256), 0, s, h, nx, gamma, beta, n, C, out);
+  else if (C <= 2048) hipLaunchKernelGGL(grn_apply_kernel<8>, grid, dim3(256), 0, s, h, nx, gamma, beta, n, C, out);
+  else hipLaunchKernelGGL(grn_apply_kernel<16>, grid, dim3(256), 0, s, h, nx, gamma, beta, n, C, out);
   return hipGetLastError();
 }
 hipError_t launch_zero_rows(float* x, const uint8_t* mask, int64_t rows, int C, hipStream_t s) {

@@ -451,6 +451,18 @@ hipError_t launch_gemm_store_variant(int op, const GemmCore& g, const EpiStore& 
 }
 hipError_t launch_gemm_qkv(int op, const GemmCore& g0, const EpiQKV& e0, hipStream_t s) { return launch_gemm_qkv_variant(op, g0, e0, -1, s); }
 namespace {
+// is tile id instantiated for this operand split?  (launch_pp's switch: 80 = the ping-pong kernel, plain rows and MX lines only; MX lines: the
+// F5_MX_TILES set; otherwise 50 .. 70)
+bool pp_tile_exists(int nsplit, int id) {
+  if (id == 80) return nsplit == 1 || nsplit == 2;
+  if (nsplit == 2) {
+#define F5_IS(ID) if (id == ID) return true;
+    F5_MX_TILES(F5_IS)
+#undef F5_IS
+    return false;
+  }
+  return id >= 50 && id <= 70;
+}
 // Does this q|k|v launch go to a pipelined kernel (half-precision outputs of the flash layouts, dim_head 64, no qk_norm detour), and which?
 // e: prepared (epi_qkv_prepare).  Fills the tile and the sizes of the q / k and V^T slabs.
 bool qkv_pp_plan(int op, const GemmCore& g0, const EpiQKV& e, int want, GemmCore& g, int& variant, int64_t& qkb, int64_t& vtb) {
@@ -463,7 +475,9 @@ bool qkv_pp_plan(int op, const GemmCore& g0, const EpiQKV& e, int want, GemmCore
   // sequences the slabs hold: all of the padded rows, or (packed rows) what the caller says — M no longer determines it
   const int64_t sn = e.slab_n ? e.slab_n : e.nseq, bpm = e.rowinfo ? e.nslab : (g.M + e.nseq - 1) / e.nseq;
   qkb = bpm * e.heads * sn * 64 * 2; vtb = bpm * e.heads * 64 * e.ldvt * 2;
-  return variant >= 50 && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000;
+  // a tile id forced by a tuning knob that this operand split does not instantiate (e.g. 80 in fp16x3) is "not a pipelined launch": the
+  // engine then asks for split remainders instead of P words and the generic kernel takes the call
+  return variant >= 50 && pp_tile_exists(op == OP_F16 ? 1 : op == OP_F16M ? 2 : 3, variant) && qkb < (int64_t)0x7ff00000 && vtb < (int64_t)0x7ff00000;
 }
 }  // namespace
 bool gemm_qkv_takes_pp(int op, const GemmCore& g0, const EpiQKV& e0) {

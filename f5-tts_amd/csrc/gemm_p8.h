@@ -246,6 +246,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
   pp::wg_barrier();
   if (grp == 1) pp::wg_barrier();  // half a phase behind group 0 from here on
   read_w(LO{}, B0{});
+  // Group 1 issues this first weight read one barrier before group 0 starts refilling the same quarter (E1's issue_w(LO, B0, t + 2)) and would
+  // otherwise wait for it only in its first matrix half, behind that barrier: in steady state every read of a quarter has been waited for
+  // before its refill is issued, here not.  An LDS-DMA round trip is an order of magnitude longer than a ds_read, so this is a window in
+  // principle only; one wait per launch closes it.
+  if (grp == 1) pp::lds_wait();
   for (int t = 0; t < nkt - 2; t += 2) pair(IC<0>{}, t);
   pair(IC<1>{}, nkt - 2);
 
@@ -265,6 +270,6 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmCore g, Epi epi) {
 #ifndef F5_HIPEMU
     asm volatile("" : "+v"(lane_e));
 #endif
-    pp_finish<TM, TN>(acc, g, epi, m0 + grp * 128, n0 + wn * 64, lane_e);
+    pp_finish<TM, TN, Epi, !MX>(acc, g, epi, m0 + grp * 128, n0 + wn * 64, lane_e);
   }
 }

@@ -94,8 +94,12 @@ __device__ __forceinline__ uint32_t pack2(f16 a, f16 b) {
 __device__ __forceinline__ void split4(const float (&x)[4], uint32_t (&hi)[2], uint32_t (&lo)[2]) {
 #pragma unroll
   for (int e = 0; e < 4; e += 2) {
-    const f16x2 h = {(f16)x[e], (f16)x[e + 1]};
-    const f16x2 l = {(f16)(x[e] - (float)h[0]), (f16)(x[e + 1] - (float)h[1])};
+    float xa = x[e], xb = x[e + 1];  // pinned to fp32 registers (common.h pack_f16x2): stored halves and remainders off the same values
+#ifndef F5_HIPEMU
+    asm volatile("" : "+v"(xa), "+v"(xb));
+#endif
+    const f16x2 h = {(f16)xa, (f16)xb};
+    const f16x2 l = {(f16)(xa - (float)h[0]), (f16)(xb - (float)h[1])};
     hi[e >> 1] = __builtin_bit_cast(uint32_t, h);
     lo[e >> 1] = __builtin_bit_cast(uint32_t, l);
   }
@@ -266,8 +270,9 @@ struct PpEpiQKV {
   // form reads (attention_kernel.h).  The lane's 16 channels of a tile ARE the k-set of P_h: no lane exchange.
   int mx_qk;
 
+  static constexpr bool FUSES_UNSCALE = true;  // the conditioning's 2^-e[n] inside the bias FMA (exact: see PpEpiAct16)
   template <int TM, int TN>
-  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane) const {
+  __device__ __forceinline__ void tile(f32x16 (&acc)[TM][TN], int m_w, int n_w, int lane, const float* alpha) const {
     const int h = lane >> 5, r = lane & 31;
     const int sn = slab_n ? slab_n : nseq;
     int bp[TM], pos[TM];
@@ -292,9 +297,12 @@ struct PpEpiQKV {
       if (nb >= N) continue;
       const int which = (nb >= inner ? 1 : 0) + (nb >= 2 * inner ? 1 : 0);
       const int c0 = nb - which * inner, hh = c0 >> 6, d0 = c0 & 63;  // head, first channel of the tile inside the head (0 or 32)
-      float4 b[4];
+      float4 b[4], al[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+      for (int q = 0; q < 4; ++q) {
+        b[q] = *reinterpret_cast<const float4*>(bias + nb + 8 * q + 4 * h);
+        al[q] = alpha ? *reinterpret_cast<const float4*>(alpha + nb + 8 * q + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);  // wave-uniform choice
+      }
       if (which < 2) {
         const bool rope = pe_heads < 0 || hh < pe_heads;
         f16* P = which == 0 ? q16 : k16;
@@ -317,7 +325,8 @@ struct PpEpiQKV {
           float xs[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+            const float x[4] = {__builtin_fmaf(acc[j][i][4 * q], al[q].x, b[q].x), __builtin_fmaf(acc[j][i][4 * q + 1], al[q].y, b[q].y),
+                                __builtin_fmaf(acc[j][i][4 * q + 2], al[q].z, b[q].z), __builtin_fmaf(acc[j][i][4 * q + 3], al[q].w, b[q].w)};
             xs[4 * q] = x[0] * cs[q].x - x[1] * cs[q].y; xs[4 * q + 1] = x[1] * cs[q].x + x[0] * cs[q].y;
             xs[4 * q + 2] = x[2] * cs[q].z - x[3] * cs[q].w; xs[4 * q + 3] = x[3] * cs[q].z + x[2] * cs[q].w;
             if (which == 0) { xs[4 * q] *= sc; xs[4 * q + 1] *= sc; xs[4 * q + 2] *= sc; xs[4 * q + 3] *= sc; }
@@ -355,7 +364,8 @@ struct PpEpiQKV {
           const int tokp = pos_off + pos[j];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float x[4] = {acc[j][i][4 * q] + b[q].x, acc[j][i][4 * q + 1] + b[q].y, acc[j][i][4 * q + 2] + b[q].z, acc[j][i][4 * q + 3] + b[q].w};
+            const float x[4] = {__builtin_fmaf(acc[j][i][4 * q], al[q].x, b[q].x), __builtin_fmaf(acc[j][i][4 * q + 1], al[q].y, b[q].y),
+                                __builtin_fmaf(acc[j][i][4 * q + 2], al[q].z, b[q].z), __builtin_fmaf(acc[j][i][4 * q + 3], al[q].w, b[q].w)};
             uint32_t hv[2], lv[2];
             pp::split4(x, hv, lv);
             const int d = d0 + 8 * q + 4 * h;
@@ -415,10 +425,15 @@ template <typename Epi, typename = void>
 struct pp_fuses_unscale : std::false_type {};
 template <typename Epi>
 struct pp_fuses_unscale<Epi, std::enable_if_t<Epi::FUSES_UNSCALE>> : std::true_type {};
-template <int TM, int TN, typename Epi>
+// FUSE = false: the scale as a pass of its own even where the epilogue could fuse it — the MX form of the ping-pong kernel sits at 256 registers,
+// and the 16 more that hold the scale vectors next to the biases sent it to scratch (52 / 144 bytes; tests/test_isa_hazards.py)
+template <int TM, int TN, typename Epi, bool FUSE = true>
 __device__ __forceinline__ void pp_finish(f32x16 (&acc)[TM][TN], const GemmCore& g, const Epi& epi, int m_w, int n_w, int lane) {
-  if constexpr (pp_fuses_unscale<Epi>::value) {
+  if constexpr (pp_fuses_unscale<Epi>::value && FUSE) {
     epi.template tile<TM, TN>(acc, m_w, n_w, lane, g.w_alpha);
+  } else if constexpr (pp_fuses_unscale<Epi>::value) {
+    pp_unscale<TM, TN>(acc, g, n_w, lane);
+    epi.template tile<TM, TN>(acc, m_w, n_w, lane, nullptr);
   } else {
     pp_unscale<TM, TN>(acc, g, n_w, lane);
     epi.template tile<TM, TN>(acc, m_w, n_w, lane);
@@ -672,7 +687,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KSP * KSS) void gemm_pp_kernel(Gem
         for (int r = 0; r < 16; r += 4) asm volatile("" ::"v"(acc[j][i][r]), "v"(acc[j][i][r + 1]), "v"(acc[j][i][r + 2]), "v"(acc[j][i][r + 3]));
 #endif
   } else if constexpr (KSP * KSS == 1) {
-    pp_finish<TM, TN>(acc, g, epi, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+    // (MX lines on the 8-tile wave layout run at the 256-register limit: the scale stays a pass of its own there, see pp_finish)
+    pp_finish<TM, TN, Epi, !(NSPLIT == 2 && TM * TN >= 8)>(acc, g, epi, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
   } else {
     // The two groups hold partial sums of the same tiles.  Tile t = j * TN + i is FINISHED by group (t < NT0 ? 0 : 1): every wave parks the
     // tiles it does not finish in the (now idle) ring — [wave][tile][quad][lane] float4, one conflict-free 1 KB run per store — and adds its

@@ -46,11 +46,11 @@ hipError_t launch_text_embed(const int32_t* tok, const uint8_t* valid, const flo
 //   w7 [7, C] (tap-major), C % 256 == 0 or C <= 2048 with C % 4 == 0
 hipError_t launch_dwconv7_ln(const float* x, int S, int n, int C, const float* w7, const float* cbias, const float* ln_w,
                              const float* ln_b, float eps, float* out, hipStream_t s);
-// GRN (reference model/modules.py:242-245): sumsq[s, c] = sum_n h[s,n,c]^2 ; then
-//   out = gamma * (h * Gx / (mean_c(Gx) + 1e-6)) + beta + h
+// GRN (reference model/modules.py:242-245): Gx[s, c] = sqrt(sum_n h[s,n,c]^2), nx = Gx / (mean_c(Gx) + 1e-6) (launch_grn_stats); then
+//   out = gamma * (h * nx) + beta + h (launch_grn_apply)
 int grn_sumsq_slices(int n);  // sequence slices of the two-pass reduction; `part` holds S * slices * C floats
-hipError_t launch_grn_sumsq(const float* h, int S, int n, int C, float* sumsq, float* part, hipStream_t s);
-hipError_t launch_grn_apply(const float* h, const float* sumsq, const float* gamma, const float* beta, int S, int n, int C,
+hipError_t launch_grn_stats(const float* h, int S, int n, int C, float* nx, float* part, hipStream_t s);
+hipError_t launch_grn_apply(const float* h, const float* nx, const float* gamma, const float* beta, int S, int n, int C,
                             float* out, hipStream_t s);
 // zero rows where mask[row] != 0 (masked_fill), x [rows, C]
 hipError_t launch_zero_rows(float* x, const uint8_t* mask, int64_t rows, int C, hipStream_t s);

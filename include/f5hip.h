@@ -247,7 +247,9 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
  * products as one MX-fp6 matrix instruction per 32 head channels, P and V plain fp16 (DESIGN.md sections 2, 4.3: plain fp16 scores moved a
  * golden with trained-like weight statistics by 1.1e-3); 1: materialised fp32 scores in every mode; 2: flash, every operand hi/lo split;
  * 3: flash on plain fp16 operands in every mode (the default of ABI v5-v8 builds); 4: flash, q and k hi/lo split (3 MFMAs per score
- * product), P and V plain; 5 = 0 for the half-precision modes),
+ * product), P and V plain; 5 = 0 for the half-precision modes; 6: the default's MX-corrected scores with V read as fp16 hi + lo halves
+ * (O = V_hi P + V_lo P), 7: P split as well — the margin against attention sharper than the trained-like goldens': DESIGN.md section 2,
+ * "sharpness sweep"),
  * "branch_streams" (-1 auto / 0 / 1: run the cond and uncond branches of the CFG batch as two concurrent kernel chains),
  * "packed_rows" (0 off (default) / 1: a ragged batch — use_mask with durations below n — of a DiT with attn_mask_enabled runs its block
  * loop over the VALID rows only: the reference's varlen attention path, model/modules.py:522-543, extended to the row-wise layers.  Rows past a

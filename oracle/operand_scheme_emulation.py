@@ -20,7 +20,8 @@ the planes the kernel would multiply), with the attention operands rounded to fp
     exact the fp32 product (isolates the other error sources)
 
 `--attn` chooses what the attention products round (round 5, the error decomposition of VERDICT r04 item 4): fp16 (the engine's default:
-q, k, P, V in fp16), fp32 (nothing), qk (q and k only), pv (P and V only).
+q, k, P, V in fp16), fp32 (nothing), qk (q and k only), pv (P and V only); round 6: p16 / v16 (P only / V only), vs (P fp16, V as hi + lo),
+vmx (P fp16, the V_lo P term as MX-fp6 over blocks of 32 keys).
 
     python oracle/operand_scheme_emulation.py --case base_v1_cfg1 --runs "all=x3;qkv=ahi;qkv=whi;out=ahi;all=mx6"
 
@@ -181,6 +182,11 @@ class Schemes:
             return TF.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
         mode = self.attn
         rp = r16 if mode in ("fp16", "pv", "qkm", "qkc", "q1", "qks") else (lambda t: t)
+        # round 6 (the sharpness sweep: the error of fp16 P.V grows with the logits): which of the two operands carries it?
+        #   p16  P rounded to fp16 (numerator and row sum over the rounded values), V exact     v16  V rounded, P exact
+        #   vs   P rounded, V as hi + lo halves (V_hi P + V_lo P: one more fp16 MFMA per product)   vmx  the V_lo P term as MX-fp6 over 32 keys
+        rP = r16 if mode in ("p16", "vs", "vmx") else rp
+        rV = r16 if mode == "v16" else rp
         q = q * (q.shape[-1] ** -0.5)
         if mode == "qkc":   # softmax is invariant under a shift of every key by one vector: centre the keys of a sequence before rounding them
             if attn_mask is not None:
@@ -209,8 +215,18 @@ class Schemes:
         m = s.amax(-1, keepdim=True)
         self.max_logit = max(getattr(self, "max_logit", 0.0), float(s[torch.isfinite(s)].abs().max()))
         e = torch.exp(s - m)
-        e16 = rp(e)
-        return (e16 @ rp(v)) / e16.sum(-1, keepdim=True)
+        e16 = rP(e)
+        if mode == "vs":
+            vh = r16(v)
+            return (e16 @ vh + e16 @ r16(v - vh)) / e16.sum(-1, keepdim=True)
+        if mode == "vmx":  # blocks of 32 consecutive keys share a scale (P block of a query row; V block of a channel)
+            vh = r16(v)
+            n = e16.shape[-1]
+            pad = (-n) % 32
+            ep = TF.pad(e16, (0, pad))
+            vl = TF.pad((v - vh).transpose(-1, -2), (0, pad))  # [.., d, keys]
+            return (e16 @ vh + mx_quant(ep, "e2m3") @ mx_quant(vl, "e2m3").transpose(-1, -2)) / e16.sum(-1, keepdim=True)
+        return (e16 @ rV(v)) / e16.sum(-1, keepdim=True)
 
 
 def parse_run(spec):

@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
       default: run_gemm_tile<f16, 3>(conv, tile, g, tp, e, batch); break;
     }
     wr("out.bin", out);
-  } else if (mode == "attn") {  // nsplit(1|2|3; 4 = MX-corrected scores) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU; with nsplit 4: 40 / 60 = the lazy 4- / 6-wave forms]
+  } else if (mode == "attn") {  // nsplit(1|2|3; 4 = MX-corrected scores) Bp heads n kv_split o_packed has_kvlen [pipe: 0 | 4 | 6 waves, +10 = row sums on the VALU; with nsplit 4: 40 / 60 = the lazy 4- / 6-wave forms, 42 / 43 / 62 = V / V and P as hi + lo halves]
     const int nsplit = A(0), Bp = A(1), heads = A(2), n = A(3), kvs = A(4), o_packed = A(5), has_kvlen = A(6), pipe = argc > 10 ? A(7) : 0;
     const int bh = Bp * heads, ldv = (n + 7) & ~7;
     auto q = rd<f16>("q.bin"), ql = rd<f16>("q_lo.bin", true), k = rd<f16>("k.bin"), kl = rd<f16>("k_lo.bin", true);
@@ -186,6 +186,15 @@ int main(int argc, char** argv) {
         a.log2q = 1;
         a.nqb = (n + 191) / 192; a.nwg = bh * a.nqb;
         hipemu::launch(dim3(a.nwg), dim3(384), lds, [&] { flash_attn_kernel<2, 1, 6, false, true, true>(a); });
+      } else if (pipe == 42 || pipe == 43 || pipe == 62) {  // round 6: the same scores with V (42, 62) / V and P (43) as hi + lo halves (vt_lo.bin)
+        if (!a.vt_lo) return 2;
+        a.log2q = 1;
+        if (pipe == 42) hipemu::launch(dim3(a.nwg), dim3(256), flash_lds_bytes<2, 2>(), [&] { flash_attn_kernel<2, 2, 4, false, false, true>(a); });
+        else if (pipe == 43) hipemu::launch(dim3(a.nwg), dim3(256), flash_lds_bytes<2, 3>(), [&] { flash_attn_kernel<2, 3, 4, false, false, true>(a); });
+        else {
+          a.nqb = (n + 191) / 192; a.nwg = bh * a.nqb;
+          hipemu::launch(dim3(a.nwg), dim3(384), flash_lds_bytes<2, 2>(), [&] { flash_attn_kernel<2, 2, 6, false, true, true>(a); });
+        }
       } else if (pipe == 40) {  // many workgroups per CU: 128-row blocks, row sums on the matrix pipe, lazy reference maximum
         a.log2q = 1;
         hipemu::launch(dim3(a.nwg), dim3(256), lds, [&] { flash_attn_kernel<2, 1, 4, false, false, true>(a); });

@@ -23,9 +23,9 @@ def gold(name):
     return np.load(os.path.join(GOLD, name + ".npz"))
 
 
-@pytest.mark.parametrize("name", sorted(MG.CASES))
+@pytest.mark.parametrize("name", sorted({**MG.CASES, **MG.SWEEP_CASES}))
 def test_oracle_matches_reference_golden(name):
-    c = MG.CASES[name]
+    c = {**MG.CASES, **MG.SWEEP_CASES}[name]
     cfg, wav, text, duration, lens = MG.case_inputs(c)
     sd = MG.case_weights(c)
     out, traj = O.cfm_sample(sd, cfg, wav, text, duration, lens=lens, method=c.get("method", "euler"), **c["kw"])
@@ -39,7 +39,17 @@ def test_oracle_matches_reference_golden(name):
 
 def test_pins_recorded():
     pins = json.load(open(os.path.join(GOLD, "pins.json")))
-    for name in list(MG.CASES) + list(MG.FULL_CASES):
+    for name, c in {**MG.CASES, **MG.SWEEP_CASES, **MG.FULL_CASES}.items():
+        if c.get("sharp", 1.0) > 1.9 and name in MG.FULL_CASES:
+            # the far end of the sharpness sweep: the fp32 restatement and the fp32 reference differ by 3e-4 .. 1.3e-3 at logits x 4 and by O(10)
+            # at logits x 16 — the FLOOR of those goldens (tools/sharpness_sweep.py prints it next to every mode), recorded, not bounded;
+            # the chaotic points keep no fixture at all
+            assert pins[name]["oracle_vs_reference_out"] > TOL
+            assert os.path.exists(os.path.join(GOLD, name + ".npz")) != bool(c.get("record_only"))
+            continue
+        if c.get("sharp", 1.0) > 1.5 and name in MG.FULL_CASES:  # logits x 2.8: the floor has begun to rise (2.8e-5)
+            assert pins[name]["oracle_vs_reference_out"] < 5e-5
+            continue
         assert pins[name]["oracle_vs_reference_out"] < TOL
     for name in ("real_example_chunk0", "real_example_chunk1", "vocos_head_ref", "vocos_head_ref_tiny"):  # minted from the reference, oracle checked there
         assert pins[name].get("oracle_vs_reference_out", pins[name].get("oracle_vs_reference")) < TOL

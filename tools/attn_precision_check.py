@@ -16,7 +16,7 @@ from f5_tts_amd.engine import F5HipCFM, F5HipEngine  # noqa: E402
 from oracle import make_golden as MG  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-cases = {**MG.CASES, **MG.FULL_CASES}
+cases = {**MG.CASES, **MG.SWEEP_CASES, **MG.FULL_CASES}
 names = sys.argv[1:] or sorted(cases)
 for name in names:
     c = cases[name]

@@ -141,7 +141,7 @@ PY
   tail -3 $out/bench.err ;;
 mx)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-  timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs2 or configs4 or packed_rows or ping_pong" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m.log; tail -25 $out/gpu_tests_fp16m.log
+  timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "fp16m or full_size or stress_golden or reference_example or small_models or configs2 or configs4 or packed_rows or trained_like or qkv_epilogue_score_corrections or sharpness" -s 2>&1 | grep -E "max-abs|passed|failed|rror" | cut -c1-220 > $out/gpu_tests_fp16m.log; tail -25 $out/gpu_tests_fp16m.log
   B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048;1406,2048,1024;1406,1024,2048"
   BIG="11248,2048,1024;22496,1024,2048;89984,2048,1024;89984,1024,2048"
   { for epi in 1 2; do

@@ -30,7 +30,7 @@ def klass(name):
     if "convpos_kernel" in name:
         return "convpos"
     # the memory-bound kernels north_star names (ConvNeXt text blocks, Vocos blocks, mel front-end, iSTFT) and the per-step update
-    for key in ("dwconv7_ln_kernel", "grn_sumsq_finish_kernel", "grn_sumsq_kernel", "grn_apply_kernel", "text_embed_kernel", "mel_kernel",
+    for key in ("dwconv7_ln_kernel", "grn_finish_kernel", "grn_sumsq_kernel", "grn_apply_kernel", "text_embed_kernel", "mel_kernel",
                 "istft_fused_kernel", "cfg_euler_kernel", "im2col7_kernel"):
         if key in name:
             return key[: -len("_kernel")]

@@ -26,8 +26,8 @@ FAMILIES = {
                                                                                   "small_mask_ragged_b3_trained_like_sharp2", "small_mask_ragged_b3_trained_like_sharp4"],
     "tiny_v1_trained_like (tiny DiT, NFE 16)": ["tiny_v1_trained_like", "tiny_v1_trained_like_sharp2", "tiny_v1_trained_like_sharp4"],
 }
-MODES = [("fp32", -1), ("fp16x3", 0), ("fp16m", 0), ("fp16x3", 2), ("fp16m", 2), ("fp16m", 4), ("fp16m", 3)]
-cases = {**MG.CASES, **MG.FULL_CASES}
+MODES = [("fp32", -1), ("fp16x3", 0), ("fp16m", 0), ("fp16x3", 6), ("fp16m", 6), ("fp16x3", 7), ("fp16m", 7), ("fp16x3", 2), ("fp16m", 2), ("fp16m", 3)]
+cases = {**MG.CASES, **MG.SWEEP_CASES, **MG.FULL_CASES}
 only = set(sys.argv[1:])
 
 
