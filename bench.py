@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--branch-streams", type=int, default=-1, help="-1 auto / 0 / 1: cond and uncond branches on two streams")
     ap.add_argument("--bigvgan-conv-impl", type=int, default=-1, help="BigVGAN conv implementation 0 / 1 / 2 (-1 = the library default)")
     ap.add_argument("--attn-impl", type=int, default=-1,
-                    help="engine option attn_impl (-1: the library's default; 4: scores from hi/lo-split q, k; 2: every attention operand split; 3: plain fp16 everywhere)")
+                    help="engine option attn_impl (-1: the library's default; 6 / 7: the default's scores with V / V and P as fp16 hi + lo halves; 4: scores from hi/lo-split q, k; "
+                         "2: every attention operand split; 3: plain fp16 everywhere)")
     ap.add_argument("--attn-kv-split", type=int, default=1, help="key ranges per query block in the flash kernel (1 = off, the default)")
     ap.add_argument("--vocoder", default="vocos", choices=["vocos", "bigvgan"],
                     help="bigvgan: BigVGAN-type mel front-end + the BigVGAN-v2 generator (BASELINE.json configs[4] pairs it with E2TTS_Base)")
@@ -341,7 +342,10 @@ def main():
         notes.append({-1: "attention scores: fp16 hi.hi + both hi/lo correction products as one MX-fp6 MFMA per 32 head channels (the parity modes' default "
                           "since round 5; plain fp16 scores, `--attn-impl 3`, are ~5 % faster and move the trained-like golden by 1.1e-3 > the 1e-3 tolerance)",
                       0: "attention scores: the default (MX-corrected)", 3: "attention scores: PLAIN fp16 q, k (--attn-impl 3): outside the parity tolerance on the "
-                          "trained-like golden (DESIGN.md section 2) - an A/B line, not the headline"}.get(a.attn_impl, f"attention: attn_impl {a.attn_impl}"))
+                          "trained-like golden (DESIGN.md section 2) - an A/B line, not the headline",
+                      6: "attention: the default's MX-corrected scores with V read as fp16 hi + lo halves (--attn-impl 6): the margin against attention "
+                         "sharper than the trained-like goldens' (DESIGN.md section 2, sharpness sweep)",
+                      7: "attention: MX-corrected scores, V and P as fp16 hi + lo halves (--attn-impl 7)"}.get(a.attn_impl, f"attention: attn_impl {a.attn_impl}"))
     if big:
         notes.append("BigVGAN generator: source and checkpoint absent from the reference tree (un-vendored submodule) — restated from the "
                      "published algorithm, PARITY UNPINNED; this line is a throughput measurement of that restatement, not a reference-verified result")

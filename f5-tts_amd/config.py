@@ -155,6 +155,7 @@ PRESETS = {
     "F5TTS_Small": F5TTS_SMALL,
     "E2TTS_Small": E2TTS_SMALL,
     "tiny48": replace(DIT_TINY, dim=768, heads=12),  # 48 channels per conv group (768 / 16), like the Small models, at depth 2
+    "tiny1024": replace(DIT_TINY, dim=1024, heads=16),  # 64 channels per conv group (1024 / 16), like the Base models, at depth 2: the MX conv-position kernel
     "tiny_inner512": replace(DIT_TINY, heads=8),  # attention width heads*dim_head = 512 != dim = 256 (modules.py:397-400)
     "tiny_flags": DIT_TINY_FLAGS,
     "tiny_mask": replace(DIT_TINY, attn_mask_enabled=True),  # key-padding mask alone: what the packed-row path (option "packed_rows") needs

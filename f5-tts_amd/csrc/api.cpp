@@ -385,6 +385,11 @@ WOp wsel(const f5hip_ctx* ctx, int op, const float* w32, const f16* hi, const f1
   return WOp{w, it == ctx->walpha.end() ? nullptr : it->second};
 }
 
+// the conv-position weights as MX lines for THIS call: fp16m calls (mx_call) whose conv runs in the split mode and whose tiles were packed
+inline const f16* conv_mx(const f5hip_ctx* ctx, int op, int j) {
+  return ctx->mx_call && op == OP_F16X3 && ctx->conv_wmx[j].p ? ctx->conv_wmx[j].as<f16>() : nullptr;
+}
+
 // What the attention SCORES are computed from in the half-precision parity modes (fp16x3, fp16m):
 //   QK_PLAIN  fp16 q, k — 1 MFMA per product (attn_impl 3: the default of rounds 2-4; always in the plain fp16 mode)
 //   QK_SPLIT  hi/lo-split q and k, 3 MFMAs per product (attn_impl 4; attn_impl 2 splits P and V as well)
@@ -540,6 +545,12 @@ int finalize_impl(f5hip_ctx* ctx) {
     HIPCHK(ctx->conv_wlo[j].ensure(n * sizeof(f16)));
     HIPCHK(launch_convpos_pack(W(ctx, p + (mmdit ? "audio_embed" : "input_embed") + ".conv_pos_embed.conv1d." + std::to_string(2 * j) + ".weight"), (int)D, cpg,
                                c.conv_pos_kernel, ctx->conv_w32[j].as<float>(), ctx->conv_whi[j].as<f16>(), ctx->conv_wlo[j].as<f16>(), st));
+    if (ctx->mx_ok && cpg == 64) {  // fp16m: rows (group, tap, co) of 64 input channels -> two MX lines each (convpos_mx_kernel)
+      HIPCHK(ctx->conv_wmx[j].ensure(2 * n * sizeof(f16)));
+      HIPCHK(launch_pack_mx_rows(ctx->conv_w32[j].as<float>(), cpg, n / cpg, cpg, nullptr, ctx->conv_wmx[j].as<f16>(), 1, st));
+    } else {
+      ctx->conv_wmx[j].release();
+    }
   }
   // depthwise weights [C,1,7] -> [7,C]
   const int64_t vC = ctx->has_vocos ? ctx->vcfg.dim : 0;
@@ -670,6 +681,20 @@ int finalize_impl(f5hip_ctx* ctx) {
       return r;
     };
     const std::vector<int> rg = ranges(fb), rgs = ranges(fbs);
+    // ... and the weights of each support as one contiguous, zero-padded run (what mel_kernel reads): [nmel][ld], ld = widest support up to 4
+    auto compact = [&](const std::vector<float>& tab, const std::vector<int>& r, int& ld) {
+      ld = 4;
+      for (int m = 0; m < nmel; ++m) ld = std::max(ld, (r[2 * m + 1] - r[2 * m] + 3) & ~3);
+      std::vector<float> w((size_t)nmel * ld, 0.0f);
+      for (int m = 0; m < nmel; ++m)
+        for (int k = r[2 * m]; k < r[2 * m + 1]; ++k) w[(size_t)m * ld + (k - r[2 * m])] = tab[(size_t)k * nmel + m];
+      return w;
+    };
+    const std::vector<float> cw = compact(fb, rg, ctx->melw_ld), cws = compact(fbs, rgs, ctx->melw_slaney_ld);
+    HIPCHK(ctx->melw.ensure(cw.size() * sizeof(float)));
+    HIPCHK(ctx->melw_slaney.ensure(cws.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(ctx->melw.p, cw.data(), cw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->melw_slaney.p, cws.data(), cws.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(ctx->melrange.ensure(rg.size() * sizeof(int)));
     HIPCHK(ctx->melrange_slaney.ensure(rgs.size() * sizeof(int)));
     HIPCHK(hipMemcpy(ctx->melrange.p, rg.data(), rg.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1133,10 +1158,10 @@ int run_step(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool exact_a
     Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops(M, D, (int64_t)cpg * c.conv_pos_kernel) * (npl == 3 ? 1 : 1), 0);
     HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), rowvalid, nullptr, S, n, D, c.conv_pos_groups,
-                          c.conv_pos_kernel, c1, st));
+                          c.conv_pos_kernel, c1, st, 0, 0, conv_mx(ctx, op, 0)));
     HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), rowvalid, h, S, n, D, c.conv_pos_groups,
-                          c.conv_pos_kernel, x, st));
+                          c.conv_pos_kernel, x, st, 0, 0, conv_mx(ctx, op, 1)));
   }
   // Packed rows (option "packed_rows"; tables built by f5hip_sample): from here to the velocity the rows are the VALID rows of this call's
   // sequences, gathered once — the block GEMMs, LayerNorms and the attention cost sum(lengths), not sequences x longest (the reference's varlen
@@ -1304,10 +1329,10 @@ int run_step_unett(f5hip_ctx* ctx, int B, int n, const Stage& sg, int op, bool e
     Prof pr(ctx, st, KC_CONVPOS, 2 * gemm_flops((int64_t)S * n, D, (int64_t)cpg * c.conv_pos_kernel), 0);
     HIPCHK(launch_convpos(op, h, ctx->conv_w32[0].as<float>(), ctx->conv_whi[0].as<f16>(), ctx->conv_wlo[0].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.0.bias"), nullptr, nullptr, S, n, D, c.conv_pos_groups, c.conv_pos_kernel,
-                          c1, st));
+                          c1, st, 0, 0, conv_mx(ctx, op, 0)));
     HIPCHK(launch_convpos(op, c1, ctx->conv_w32[1].as<float>(), ctx->conv_whi[1].as<f16>(), ctx->conv_wlo[1].as<f16>(),
                           W(ctx, p + "input_embed.conv_pos_embed.conv1d.2.bias"), nullptr, h, S, n, D, c.conv_pos_groups, c.conv_pos_kernel, x, st,
-                          ns, 1));
+                          ns, 1, conv_mx(ctx, op, 1)));
     HIPCHK(launch_set_token_rows(x, ctx->temb.as<float>() + (int64_t)step * D, S, ns, D, st));  // unett.py:272
   }
 
@@ -1691,8 +1716,8 @@ int f5hip_destroy(f5hip_ctx* ctx) {
   if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->ev_fork); (void)hipEventDestroy(ctx->ev_join); }
   DevBuf* bufs[] = {&ctx->half_pool, &ctx->cond_pool, &ctx->conv_w32[0], &ctx->conv_w32[1], &ctx->conv_whi[0], &ctx->conv_whi[1], &ctx->conv_wlo[0],
-                    &ctx->conv_wlo[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
-                    &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->melfb_slaney, &ctx->melrange, &ctx->melrange_slaney, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
+                    &ctx->conv_wlo[1], &ctx->conv_wmx[0], &ctx->conv_wmx[1], &ctx->wp_hi, &ctx->wp_pk, &ctx->dwpack, &ctx->freqs_cis, &ctx->inv_freq, &ctx->vhead_w, &ctx->vhead_b,
+                    &ctx->twiddle, &ctx->window, &ctx->melfb, &ctx->melfb_slaney, &ctx->melrange, &ctx->melrange_slaney, &ctx->melw, &ctx->melw_slaney, &ctx->t_dev, &ctx->dt_dev, &ctx->cfg_dev, &ctx->tsin, &ctx->th1, &ctx->tsilu,
                     &ctx->mods, &ctx->fmods, &ctx->temb, &ctx->skipcat, &ctx->ymid, &ctx->traj_buf, &ctx->tok, &ctx->valid, &ctx->textkeep, &ctx->rowvalid, &ctx->condmask, &ctx->kvlen, &ctx->tx,
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
@@ -1836,8 +1861,9 @@ int f5hip_mel(f5hip_ctx* ctx, const float* wav, int batch, int64_t nsamp, float*
   {
     Prof pr(ctx, st, KC_MEL, 0, (double)batch * (nsamp * 4.0 + (double)frames * ctx->cfg.mel_dim * 4.0));
     HIPCHK(launch_mel(wav, batch, nsamp, frames, ctx->twiddle.as<float>(), ctx->window.as<float>(),
-                      mel_type == 1 ? ctx->melfb_slaney.as<float>() : ctx->melfb.as<float>(),
-                      mel_type == 1 ? ctx->melrange_slaney.as<int>() : ctx->melrange.as<int>(), ctx->cfg.mel_dim, frame_major, pad,
+                      mel_type == 1 ? ctx->melw_slaney.as<float>() : ctx->melw.as<float>(),
+                      mel_type == 1 ? ctx->melrange_slaney.as<int>() : ctx->melrange.as<int>(), mel_type == 1 ? ctx->melw_slaney_ld : ctx->melw_ld,
+                      ctx->cfg.mel_dim, frame_major, pad,
                       mel_type == 1 ? 1e-9f : 0.f, out, st));
   }
   CHK(scope.finish());

@@ -12,8 +12,8 @@
 //     twiddles) = a radix-2 stage + four radix-4 stages of 128 butterflies, twiddle table and data in LDS: a workgroup of 256 threads
 //     carries TWO frames side by side (128 threads each).  Frames are never paired into one complex transform: a quiet frame would inherit
 //     the rounding noise of a loud neighbour, and the mel of silence is a logarithm;
-//   * the filterbank product walks each mel bin's own support [lo, hi) (api.cpp builds the ranges with the table): same terms, same order
-//     as the dense sum;
+//   * the filterbank product walks each mel bin's own support [lo, hi) — api.cpp builds the ranges and a compact [mel][support] copy of the
+//     weights next to the table: same terms, same order as the dense sum;
 //   * the inverse transform and the overlap-add are one kernel: a workgroup owns G consecutive output hops, transforms the G + 3 frames
 //     that touch them (two at a time; 3 of them recomputed by the neighbour: 23 % at G = 13), adds them in ascending frame order into an LDS
 //     strip (the summation order of the old two-kernel form) and writes finished samples — logits read once (x 1.23), samples written
@@ -79,7 +79,7 @@ __device__ __forceinline__ void fft512(float2* z, const float2* tw, int t) {
 // Workgroup = frames 2 blockIdx.x (threads 0-127) and 2 blockIdx.x + 1 (threads 128-255) of utterance blockIdx.y.
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, int64_t nsamp, int frames, const float2* __restrict__ tw_g,
                                                    const float* __restrict__ window, const float* __restrict__ melfb,
-                                                   const int2* __restrict__ melrange, int nmel, int frame_major, int pad, float mag_eps,
+                                                   const int2* __restrict__ melrange, int melw_ld, int nmel, int frame_major, int pad, float mag_eps,
                                                    float* out) {
   __shared__ float2 z[2][ZLEN];
   __shared__ float2 tw[NH];
@@ -125,7 +125,16 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav,
   for (int m = t; m < nmel; m += 128) {
     const int2 r = melrange[m];
     float acc = 0.f;
-    for (int k = r.x; k < r.y; ++k) acc += mag[half][k] * melfb[k * nmel + m];
+    // the triangle's weights are one contiguous run of melw (api.cpp: [nmel][melw_ld], bin r.x first, zero-padded to a multiple of 4): four per
+    // load, every load of the run independent of the sum — the [bin][mel] table cost one dependent-latency global load per bin of the support
+    const float4* w4 = reinterpret_cast<const float4*>(melfb + (size_t)m * melw_ld);
+    for (int k = r.x, j = 0; k < r.y; k += 4, ++j) {
+      const float4 w = w4[j];
+      acc += mag[half][k] * w.x;
+      if (k + 1 < r.y) acc += mag[half][k + 1] * w.y;
+      if (k + 2 < r.y) acc += mag[half][k + 2] * w.z;
+      if (k + 3 < r.y) acc += mag[half][k + 3] * w.w;
+    }
     const float v = logf(fmaxf(acc, 1e-5f));
     if (frame_major) out[((int64_t)b * frames + f) * nmel + m] = v;
     else out[((int64_t)b * nmel + m) * frames + f] = v;
@@ -212,10 +221,10 @@ __global__ __launch_bounds__(256) void istft_fused_kernel(const float* __restric
 }  // namespace
 
 hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
-                      const float* melfb, const int* melrange, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s) {
-  if (nmel > 256 || nsamp < pad + 1 || frames <= 0 || !melrange) return hipErrorInvalidValue;
+                      const float* melfb, const int* melrange, int melw_ld, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s) {
+  if (nmel > 256 || nsamp < pad + 1 || frames <= 0 || !melrange || melw_ld <= 0 || (melw_ld & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(mel_kernel, dim3((frames + 1) / 2, B), dim3(256), 0, s, wav, nsamp, frames, reinterpret_cast<const float2*>(twiddle), window, melfb,
-                     reinterpret_cast<const int2*>(melrange), nmel, frame_major, pad, mag_eps, out);
+                     reinterpret_cast<const int2*>(melrange), melw_ld, nmel, frame_major, pad, mag_eps, out);
   return hipGetLastError();
 }
 // inverse STFT of B x T logits rows into B x 256 (T - 1) samples: workgroups of 13 hops (16 frames each) once they fill the chip twice,

@@ -136,26 +136,24 @@ __device__ __forceinline__ float apply_act(int act, float x) {
   }
 }
 
-// Two floats -> two halves as ONE packed conversion (v_cvt_pk_f16_f32) of two MATERIALISED fp32 values.  Why the inputs are made opaque
-// (round 6): where a value is a product x * r, hipcc is free (-ffp-contract=fast) to form a half as v_fma_mixlo_f16(x, r, 0) — the EXACT
-// product rounded once — in one place and as the conversion of the fp32-ROUNDED product in another: for the stored half and for the half a
-// remainder v - (float)hi is taken from, or in one unrolled copy of an epilogue and not in the next.  The two agree except where the product
-// sits within an fp32 ulp of a half-way point (tools/probes/cvt_pk_f16_probe.hip: 144 of 2 M products).  Seen on the GPU, never on the host
-// shim (one conversion): hi + lo off by one fp16 ulp in 0.007 % of the operand elements (the stored hi and the remainder's hi derived
-// apart), and identical utterances of one batch 6e-5 apart (rows in different 32-row tiles of a wave rounded by different instructions).
-// With the inputs pinned to fp32 registers every half is RNE16(fl32(value)) wherever and however often it is derived.
-__device__ __forceinline__ f16x2 pack_f16x2(float a, float b) {
+// Pin two values to fp32 registers before halves and remainders are taken off them.  Why (round 6): where a value is a product x * r, hipcc
+// is free (-ffp-contract=fast) to form a half as v_fma_mixlo_f16(x, r, 0) — the EXACT product rounded once — in one place and as the
+// conversion of the fp32-ROUNDED product in another: for the stored half and for the half a remainder v - (float)hi is taken from, or in one
+// unrolled copy of an epilogue and not in the next.  The two agree except where the product sits within an fp32 ulp of a half-way point
+// (tools/probes/cvt_pk_f16_probe.hip: 144 of 2 M products).  Seen on the GPU, never on the host shim (one conversion): hi + lo off by one
+// fp16 ulp in 0.007 % of the operand elements (the stored hi and the remainder's hi derived apart), and identical utterances of one batch
+// 6e-5 apart (rows in different 32-row tiles of a wave rounded by different instructions).  Behind the pin every half is RNE16(fl32(value))
+// wherever and however often it is derived, and two of them convert with one v_cvt_pk_f16_f32.
+__device__ __forceinline__ void pin_f32(float& a, float& b) {
 #ifndef F5_HIPEMU
   asm volatile("" : "+v"(a), "+v"(b));
 #endif
-  const f16x2 h = {(f16)a, (f16)b};
-  return h;
 }
 
 // fp16 hi/lo split: v ~= hi + lo with 22 significant bits
 __device__ __forceinline__ void split_f16(float v, f16& hi, f16& lo) {
 #ifndef F5_HIPEMU
-  asm volatile("" : "+v"(v));  // v as ONE fp32 value: the stored half and the half the remainder is taken from cannot be derived apart (pack_f16x2)
+  asm volatile("" : "+v"(v));  // v as ONE fp32 value: the stored half and the half the remainder is taken from cannot be derived apart (pin_f32)
 #endif
   hi = (f16)v;
   lo = (f16)(v - (float)hi);
@@ -207,10 +205,8 @@ __device__ __forceinline__ void mx_pack16(const float (&v)[16], uint32_t (&hi)[8
   f32x16 c, l;
 #pragma unroll
   for (int t = 0; t < 16; t += 2) {
-    float va = v[t], vb = v[t + 1];  // pinned to fp32 registers: halves, coarse values and remainders all come off the same two values
-#ifndef F5_HIPEMU
-    asm volatile("" : "+v"(va), "+v"(vb));
-#endif
+    float va = v[t], vb = v[t + 1];
+    pin_f32(va, vb);  // halves, coarse values and remainders all come off the same two fp32 values
     const f16x2 hp = {(f16)va, (f16)vb};  // one v_cvt_pk_f16_f32
     hi[t >> 1] = __builtin_bit_cast(uint32_t, hp);
     c[t] = va; c[t + 1] = vb;

@@ -201,12 +201,15 @@ struct f5hip_ctx {
   std::vector<TextBlockW> tblocks;
   std::vector<VocosLayerW> vlayers;
   DevBuf conv_w32[2], conv_whi[2], conv_wlo[2];
+  DevBuf conv_wmx[2];  // fp16m: the per-tap tiles as MX lines [G][K][co][2 x 128 B] (64 channels per group only; else empty)
   DevBuf wp_hi, wp_pk;                 // proj_out f16: plain rows, packed hi/lo rows
   DevBuf dwpack;                       // [7,C] depthwise weights (text + vocos)
   DevBuf freqs_cis;                    // [8192, text_dim]
   DevBuf inv_freq;                     // [dh/2]
   DevBuf vhead_w, vhead_b;             // padded vocos head [1028, C], [1028]
   DevBuf melrange, melrange_slaney;              // per mel channel: [first, one past last) bin of its filterbank triangle
+  DevBuf melw, melw_slaney;                      // ... and the weights of those bins as contiguous zero-padded runs [nmel][melw_ld]
+  int melw_ld = 0, melw_slaney_ld = 0;
   DevBuf twiddle, window, melfb, melfb_slaney;  // audio tables (HTK filterbank of the Vocos-type mel, slaney one of the BigVGAN type)
   const float *adaln_w = nullptr, *adaln_b = nullptr;  // [depth*6D, D], [depth*6D]
 

@@ -94,10 +94,8 @@ __device__ __forceinline__ uint32_t pack2(f16 a, f16 b) {
 __device__ __forceinline__ void split4(const float (&x)[4], uint32_t (&hi)[2], uint32_t (&lo)[2]) {
 #pragma unroll
   for (int e = 0; e < 4; e += 2) {
-    float xa = x[e], xb = x[e + 1];  // pinned to fp32 registers (common.h pack_f16x2): stored halves and remainders off the same values
-#ifndef F5_HIPEMU
-    asm volatile("" : "+v"(xa), "+v"(xb));
-#endif
+    float xa = x[e], xb = x[e + 1];
+    pin_f32(xa, xb);  // (common.h: stored halves and remainders off the same fp32 values)
     const f16x2 h = {(f16)xa, (f16)xb};
     const f16x2 l = {(f16)(xa - (float)h[0]), (f16)(xb - (float)h[1])};
     hi[e >> 1] = __builtin_bit_cast(uint32_t, h);

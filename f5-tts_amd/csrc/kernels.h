@@ -102,7 +102,8 @@ hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_m
 //   model/modules.py:187-201: input and conv output zero-filled outside the mask)
 hipError_t launch_convpos(int op, const float* x, const float* w32, const f16* whi, const f16* wlo, const float* bias,
                           const uint8_t* rowvalid, const float* residual, int S, int n, int D, int groups, int K, float* out,
-                          hipStream_t s, int out_n = 0, int out_off = 0);  // output row of (seq, m) = seq * out_n + m + out_off (out_n 0 = n)
+                          hipStream_t s, int out_n = 0, int out_off = 0,  // output row of (seq, m) = seq * out_n + m + out_off (out_n 0 = n)
+                          const f16* wmx = nullptr);  // MX lines of the per-tap tiles (64 channels per group, op OP_F16X3): the 1.5-MFMA form
 
 // ---- attention.hip ----------------------------------------------------------------------------
 // flash-style non-causal attention, fp32 softmax + accumulate.  nsplit 1: plain fp16 operands; 3: every operand hi/lo split; 2: q, k split;
@@ -130,9 +131,10 @@ struct AudioTables {
   const float* melfb;     // [513, 100] HTK triangles
   const float* env_inv;   // unused (envelope computed per call)
 };
-// melrange [nmel][2]: first bin and one past the last bin with a non-zero filterbank weight, per mel channel
+// melrange [nmel][2]: first bin and one past the last bin with a non-zero filterbank weight, per mel channel; melw [nmel][melw_ld]: the
+// weights of those bins, first bin first, zero-padded (melw_ld % 4 == 0)
 hipError_t launch_mel(const float* wav, int B, int64_t nsamp, int frames, const float* twiddle, const float* window,
-                      const float* melfb, const int* melrange, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s);
+                      const float* melw, const int* melrange, int melw_ld, int nmel, int frame_major, int pad, float mag_eps, float* out, hipStream_t s);
 // head logits [B*T, ld] (log-mag | phase) -> inverse real transform, window, overlap-add, envelope normalisation, centre trim ->
 // wav [B, 256*(T-1)]: one kernel, no intermediate in HBM
 hipError_t launch_istft(const float* logits, int64_t ld, int B, int T, const float* twiddle, const float* window, float* wav, hipStream_t s);

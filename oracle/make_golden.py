@@ -85,6 +85,9 @@ CASES = {
     # 48 channels per conv-position group (dim 768 / 16 groups in the Small models)
     "tiny48_ragged_b2": dict(preset="tiny48", wseed=7, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
                              pad_from=30, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
+    # 64 channels per conv-position group (dim 1024 / 16 groups: the Base models' width at depth 2): the MX form of the conv-position kernel (fp16m)
+    "tiny1024_ragged_b2": dict(preset="tiny1024", wseed=7, nw=256 * 60, wavseed=3, batch=2, nt=40, tseed=2, duration=[200, 170], lens=[61, 50],
+                               pad_from=30, kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=7)),
     # attention inner width != model width (heads * dim_head = 512, dim = 256)
     "tiny_inner512": dict(preset="tiny_inner512", wseed=8, nw=256 * 30, wavseed=9, batch=1, nt=20, tseed=6, duration=100, lens=None,
                           kw=dict(steps=4, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=3)),

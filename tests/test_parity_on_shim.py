@@ -73,7 +73,7 @@ def shim_engines(engine_emu_lib):  # noqa: F811
                          [(n, "fp16x3", G.X3TOL) for n in (CASES if ALL_CASES else ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2"))] +
                          # fp16m: MX lines in the DiT block GEMMs (LayerNorm / flash / GELU producers, the MX k-loop); the other backbones run it as fp16x3
                          [(n, "fp16m", G.MXTOL) for n in (CASES if ALL_CASES else ("tiny_v1_ragged_b2", "tiny_mask_ragged_b3", "tiny48_ragged_b2", "tiny_inner512", "tiny_unett_noskip", "tiny_v1_trained_like", "tiny_unett_trained_like",
-                                                                                "tiny_qknorm_trained_like", "tiny_mmdit_trained_like"))])
+                                                                                "tiny_qknorm_trained_like", "tiny_mmdit_trained_like", "tiny1024_ragged_b2"))])
 def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
     G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
 

@@ -27,7 +27,7 @@ def klass(name):
         return "flash_attn"
     if "layernorm" in name:
         return "layernorm"
-    if "convpos_kernel" in name:
+    if "convpos_kernel" in name or "convpos_mx_kernel" in name:
         return "convpos"
     # the memory-bound kernels north_star names (ConvNeXt text blocks, Vocos blocks, mel front-end, iSTFT) and the per-step update
     for key in ("dwconv7_ln_kernel", "grn_finish_kernel", "grn_sumsq_kernel", "grn_apply_kernel", "text_embed_kernel", "mel_kernel",
