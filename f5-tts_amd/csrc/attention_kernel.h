@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
   constexpr int NPL = NSPLIT >= 2 ? 2 : 1;    // planes of q and k
   constexpr int NPV = PVSPLIT >= 2 ? 2 : 1;   // planes of v
   constexpr int NPP = PVSPLIT == 3 ? 2 : 1;   // planes of P
+  constexpr bool VADAPT = PVSPLIT == 2 && LAZY;  // V_lo . P tile by tile, where the row's weights are concentrated (below)
   constexpr bool MXQK = NSPLIT == 2;          // plane 1 = P words
   constexpr int STAGE = NPL * K_PLANE + NPV * V_PLANE;
   F5_DYN_LDS(char, smem);
@@ -291,11 +292,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     float alpha = 1.0f, rs = 0.f;
+    float raised = 0.f;  // (VADAPT) what this tile's reference raise took off the scores
     if constexpr (LAZY) {
       // s holds score - reference (base-2 units).  Raise the reference where a row went more than LAZY_TAU above it (and fix it on the first tile)
       if (f5_wave_any(first || mx > LAZY_TAU)) {
         const float mxr = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the row's maximum over both half-waves' keys
         const float delta = first ? mxr : (mxr > LAZY_TAU ? mxr : 0.f);
+        raised = delta;
         if (!first) {
           alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -334,6 +337,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
     }
 
     // ---- O^T += V^T . P^T ----------------------------------------------------------------------------
+    // VADAPT (PVSPLIT 2 in the lazy forms): the V_lo . P product only for tiles that can matter.  The rounding of V shows in the output
+    // where a FEW keys carry a row (under a near one-hot row the output is one V row; over many comparable keys the 2^-12 errors average
+    // away), so a tile whose largest weight is below 1 / 16 of the mass the row has gathered so far — for every row of the wave — skips
+    // its eight V_lo MFMAs and fragment reads: every tile of a flat row after the first, none that holds a dominant key (the first tile,
+    // l = 0, always runs; a late dominant key makes its tile's weight large against the mass before it).  One exponential, one compare and
+    // one ballot per tile.
+    bool vlo = true;
+    // (l_run: with the row sums on the matrix pipe it is the mass BEFORE this tile, not yet rescaled by a raise; on the VALU this lane's half of
+    // the row including this tile — smaller than the row's, so the test only errs towards running the product)
+    if constexpr (VADAPT) vlo = f5_wave_any(__builtin_amdgcn_exp2f(mx - raised) * 16.0f > (MSUM ? l_run * alpha : l_run));
     f32x16 rsum;
 #pragma unroll
     for (int r = 0; r < 16; ++r) rsum[r] = 0.f;
@@ -353,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
         Frag fv[NPV];
 #pragma unroll
         for (int p = 0; p < NPV; ++p) {
+          if (VADAPT && p == 1 && !vlo) continue;  // (wave-uniform)
           const char* src = sV + p * V_PLANE + db * 32 * V_ROWB + g * 32;
           const uint2 v0 = *reinterpret_cast<const uint2*>(src);       // keys 16g + 4hi + 0..3
           const uint2 v1 = *reinterpret_cast<const uint2*>(src + 16);  // keys 16g + 8 + 4hi + 0..3
@@ -360,7 +374,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void flash_attn_kernel(Fl
         }
         Mma32<f16>::mma(o[db], fv[0], fp[0]);
         if constexpr (NPP == 2) Mma32<f16>::mma(o[db], fv[0], fp[1]);  // V_hi . P_lo
-        if constexpr (NPV == 2) Mma32<f16>::mma(o[db], fv[1], fp[0]);  // V_lo . P_hi
+        if constexpr (NPV == 2) {
+          if (!VADAPT || vlo) Mma32<f16>::mma(o[db], fv[1], fp[0]);     // V_lo . P_hi
+        }
       }
     }
     if constexpr (MSUM) l_run = l_run * alpha + rsum[0];  // the whole row: both half-waves' keys

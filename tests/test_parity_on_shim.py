@@ -69,11 +69,16 @@ def shim_engines(engine_emu_lib):  # noqa: F811
     mp.undo()
 
 
+# 80-100 s each on the shim (dim 48 with ragged rows through the generic tiles; dim 1024 / 16 heads through the tiles of the real model): part of
+# the GPU suite, on the shim only with F5HIP_SHIM_FULL=1 — the CPU suite keeps to a few minutes
+HEAVY_MX_CASES = ("tiny48_ragged_b2", "tiny1024_ragged_b2") if os.environ.get("F5HIP_SHIM_FULL") == "1" else ()
+
+
 @pytest.mark.parametrize("name,prec,tol", [(n, "fp32", G.TIGHT) for n in CASES] +
                          [(n, "fp16x3", G.X3TOL) for n in (CASES if ALL_CASES else ("tiny_qknorm", "tiny_unett_add_ragged_b2", "tiny_mmdit_mask_ragged_b2"))] +
                          # fp16m: MX lines in the DiT block GEMMs (LayerNorm / flash / GELU producers, the MX k-loop); the other backbones run it as fp16x3
-                         [(n, "fp16m", G.MXTOL) for n in (CASES if ALL_CASES else ("tiny_v1_ragged_b2", "tiny_mask_ragged_b3", "tiny48_ragged_b2", "tiny_inner512", "tiny_unett_noskip", "tiny_v1_trained_like", "tiny_unett_trained_like",
-                                                                                "tiny_qknorm_trained_like", "tiny_mmdit_trained_like", "tiny1024_ragged_b2"))])
+                         [(n, "fp16m", G.MXTOL) for n in (CASES if ALL_CASES else ("tiny_v1_ragged_b2", "tiny_mask_ragged_b3", "tiny_inner512", "tiny_unett_noskip", "tiny_v1_trained_like", "tiny_unett_trained_like",
+                                                                                "tiny_qknorm_trained_like", "tiny_mmdit_trained_like") + HEAVY_MX_CASES)])
 def test_reference_golden_on_the_shim(shim_engines, name, prec, tol):
     G.test_sample_matches_reference_golden(shim_engines, name, prec, tol)
 
@@ -101,7 +106,7 @@ def test_gpu_suite_function_on_the_shim(shim_engines, fn):
 
 def test_packed_rows_on_the_shim(shim_engines):
     # two CFG chains (the row tables are shared by both); one chain and the fp16 mode as well on the GPU
-    G.test_packed_rows_equal_the_padded_layout_on_the_valid_rows(shim_engines, 1, precisions=("fp16x3", "fp16m"))
+    G.test_packed_rows_equal_the_padded_layout_on_the_valid_rows(shim_engines, 1, precisions=("fp16x3", "fp16m") if os.environ.get("F5HIP_SHIM_FULL") == "1" else ("fp16m",))
 
 
 @pytest.mark.parametrize("nw", [513, 256 * 20 + 255])
