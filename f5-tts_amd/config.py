@@ -168,4 +168,8 @@ PRESETS = {
     "tiny_mmdit": MMDIT_TINY,
     "tiny_mmdit_mask": replace(MMDIT_TINY, attn_mask_enabled=True, qk_norm="rms_norm"),
     "tiny_mmdit_nopad": replace(MMDIT_TINY, text_mask_padding=False),
+    # full-width variants of the optional paths, for cost measurements only (what the attention default costs where the q|k|v
+    # launch cannot pack the score corrections): the v1 Base DiT with qk RMSNorm; an MMDiT at the Base width (no yaml of it ships)
+    "F5TTS_v1_Base_qknorm": replace(F5TTS_V1_BASE, qk_norm="rms_norm"),
+    "MMDiT_1024": DiTConfig(dim=1024, depth=22, heads=16, dim_head=64, ff_mult=2, text_dim=1024, conv_layers=0, text_num_embeds=2545, backbone="MMDiT"),
 }
