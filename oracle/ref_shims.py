@@ -213,10 +213,13 @@ def install():
 
         lf = mod("librosa.filters", mel=_slaney_mel)
         lb.filters = lf
-    if "rjieba" not in sys.modules:
-        mod("rjieba", cut=lambda s: [s])
+    g2p_stubs = []  # import-time only: taken out of sys.modules again below, so that nothing else in the process mistakes them for the packages
+    if "rjieba" not in sys.modules:  # (f5_tts_amd.infer.convert_char_to_pinyin uses rjieba when it is importable: with the stub left behind,
+        mod("rjieba", cut=lambda s: [s])  # tests/test_infer_host.py failed whenever an oracle test had run earlier in the same process)
+        g2p_stubs.append("rjieba")
     if "pypinyin" not in sys.modules:
         mod("pypinyin", Style=types.SimpleNamespace(TONE3=0), lazy_pinyin=lambda s, **k: list(s))
+        g2p_stubs.append("pypinyin")
 
     base = os.path.join(REFERENCE_SRC, "f5_tts")
     for name, path in (("f5_tts", base), ("f5_tts.model", os.path.join(base, "model")),
@@ -228,6 +231,8 @@ def install():
     for sub in ("f5_tts.model.utils", "f5_tts.model.modules", "f5_tts.model.backbones.dit",
                 "f5_tts.model.backbones.unett", "f5_tts.model.backbones.mmdit", "f5_tts.model.cfm"):
         importlib.import_module(sub)
+    for name in g2p_stubs:  # the reference's modules keep their own bindings
+        sys.modules.pop(name, None)
 
 
 def reference_classes():
