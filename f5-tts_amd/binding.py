@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("F5HIP_LIB") or os.path.join(_HERE, "csrc", "libf5hip.so")
 BENCH_LIB_PATH = os.environ.get("F5HIP_BENCH_LIB") or os.path.join(_HERE, "csrc", "libf5hip_bench.so")
 
-ABI_VERSION = 9  # F5HIP_ABI_VERSION in include/f5hip.h
+ABI_VERSION = 10  # F5HIP_ABI_VERSION in include/f5hip.h
 PREC_FP32, PREC_FP16X3, PREC_FP16, PREC_FP16M = 0, 1, 2, 3
 PRECISIONS = {"fp32": PREC_FP32, "fp16x3": PREC_FP16X3, "fp16": PREC_FP16, "fp16m": PREC_FP16M}
 
@@ -66,6 +66,7 @@ SYMBOLS = {
     "f5hip_kernel_stat": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "f5hip_reset_kernel_stats": (C.c_int, [_P]),
+    "f5hip_attention_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
     "f5hip_bigvgan_create": (C.c_int, [C.POINTER(BigVGANConfigC), C.c_int, C.POINTER(_P)]),
     "f5hip_bigvgan_destroy": (C.c_int, [_P]),
     "f5hip_bigvgan_last_error": (C.c_char_p, [_P]),

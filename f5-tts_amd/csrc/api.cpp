@@ -959,7 +959,8 @@ int run_attention(f5hip_ctx* ctx, int S, int s0, int n, int op, bool exact_attn,
         EpiStore e = epi_store(sc, np, nullptr);
         e.zdiv = 1; e.so1 = (int64_t)n * np; e.so2 = 0;
         HIPCHK(launch_gemm_store(OP_F32, g, e, S * H, st));
-        HIPCHK(launch_softmax_rows(sc, (int64_t)S * H * n, np, n, H, kvlen, n, st, kvlen2, seg2_off));
+        HIPCHK(launch_softmax_rows(sc, (int64_t)S * H * n, np, n, H, kvlen, n, st, kvlen2, seg2_off,
+                                   ctx->attn_stats ? ctx->attn_stats_buf.as<double>() : nullptr));
         g = core(sc, np, vt, np, n, dh, np);
         g.strideA = (int64_t)n * np; g.strideW = (int64_t)dh * np;
         EpiStore e2 = epi_store(o32, inner, nullptr);
@@ -1722,7 +1723,7 @@ int f5hip_destroy(f5hip_ctx* ctx) {
                     &ctx->ta, &ctx->th, &ctx->tg, &ctx->sumsq, &ctx->step_cond, &ctx->cconst, &ctx->y, &ctx->h, &ctx->c1, &ctx->x, &ctx->a32,
                     &ctx->a_hi, &ctx->o32, &ctx->o_hi, &ctx->f32, &ctx->f_hi, &ctx->q32, &ctx->k32,
                     &ctx->vt32, &ctx->scores, &ctx->q16, &ctx->k16, &ctx->vt16, &ctx->q16_lo, &ctx->k16_lo, &ctx->vt16_lo, &ctx->vel, &ctx->rope, &ctx->dbg_vel, &ctx->vcol, &ctx->vx,
-                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->attn_part};
+                    &ctx->va, &ctx->vh, &ctx->vlogits, &ctx->attn_part, &ctx->attn_stats_buf};
   for (DevBuf* b : bufs) b->release();
   ctx->stage.release();
   if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
@@ -1818,12 +1819,33 @@ int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value) {
   else if (k == "mx_weights") {  // read by the NEXT f5hip_finalize_weights (the copies are carved from the pool it sizes)
     ctx->mx_weights_opt = value ? 1 : 0;
   }
+  else if (k == "attn_stats") {  // 0 off (default) / 1: the materialised-score attention (precision FP32, or attn_impl 1) accumulates how sharp
+    // its softmax rows are — f5hip_attention_stats reads the figures; the flash kernels do not (they never see a whole row's sum at a point
+    // where it is cheap to publish), so the option only has an effect on that path
+    if (value) {
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(ctx->attn_stats_buf.ensure(4 * sizeof(double), nullptr, true));  // (zeroed when first allocated)
+    }
+    ctx->attn_stats = value ? 1 : 0;
+    ctx->ws_epoch++;  // (a captured graph holds the launch's pointer argument)
+  }
   else if (k == "attn_kv_split") {  // 1 = off (default); 2..8 = flash attention with every query block cut into that many key ranges
     if (value < 1 || value > 8) FAIL(F5HIP_ERR_INVALID, "attn_kv_split must be in [1, 8]");
     ctx->attn_kv_split = (int)value;
     ctx->ws_epoch++;
   }
   else FAIL(F5HIP_ERR_INVALID, "unknown option '%s'", key);
+  return F5HIP_OK;
+}
+
+int f5hip_attention_stats(f5hip_ctx* ctx, double* out4, int reset) {
+  if (!ctx || !out4) return F5HIP_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!ctx->attn_stats_buf.p) FAIL(F5HIP_ERR_INVALID, "attention statistics were never switched on (option attn_stats)");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());  // a diagnostic call: whatever stream the samples ran on has finished
+  HIPCHK(hipMemcpy(out4, ctx->attn_stats_buf.p, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(ctx->attn_stats_buf.p, 0, 4 * sizeof(double)));
   return F5HIP_OK;
 }
 

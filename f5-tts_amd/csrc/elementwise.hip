@@ -561,9 +561,12 @@ __global__ void dw_pack_kernel(const float* w, int C, float* w7) {
   w7[i] = w[c * 7 + t];
 }
 
-// exact attention: softmax over the first kv columns of each score row, zero the rest (incl. padding to ld)
+// exact attention: softmax over the first kv columns of each score row, zero the rest (incl. padding to ld).
+// stats (engine option "attn_stats", f5hip_attention_stats): the row's LARGEST probability is 1 / sum here (exp(max - max) = 1) — how sharp a
+// checkpoint's attention is, which is what decides the half-precision attention form it needs (sharpness sweep);
+// stats = {max over rows, sum over rows, rows, rows above 1/2} as doubles, accumulated with atomics (a diagnostic pass, not a hot path)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, int64_t rows, int ld, int nseq, int heads,
-                                                            const int32_t* kvlen, int kv_default, const int32_t* kvlen2, int seg2_off) {
+                                                            const int32_t* kvlen, int kv_default, const int32_t* kvlen2, int seg2_off, double* stats) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -588,6 +591,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* S, int64_t row
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
   for (int c = lane; c < ld; c += 64) p[c] = c < kv ? p[c] * inv : 0.f;
+  if (stats && lane == 0 && kv > 0) {
+    const double pm = (double)inv;
+    unsigned long long bits;
+    memcpy(&bits, &pm, 8);  // (positive doubles order like their bit patterns)
+    atomicMax(reinterpret_cast<unsigned long long*>(stats), bits);
+    atomicAdd(stats + 1, pm);
+    atomicAdd(stats + 2, 1.0);
+    if (inv > 0.5f) atomicAdd(stats + 3, 1.0);
+  }
 }
 
 // mel [B, T, Cin] (or [B, Cin, T]) -> col [B*T, ldc], k = ci*7 + tap (matches weight [Cout, Cin, 7] flattened)
@@ -788,9 +800,9 @@ hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
-                               hipStream_t s, const int32_t* kvlen2, int seg2_off) {
+                               hipStream_t s, const int32_t* kvlen2, int seg2_off, double* stats) {
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, rows, ld, nseq, heads, kvlen_per_batch,
-                     kv_default, kvlen2, seg2_off);
+                     kv_default, kvlen2, seg2_off, stats);
   return hipGetLastError();
 }
 hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s) {

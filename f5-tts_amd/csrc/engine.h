@@ -275,6 +275,8 @@ struct f5hip_ctx {
   bool mx_call = false;        // f5hip_sample: this call's block GEMMs read MX lines (precision FP16M and every condition holds)
   int attn_kv_split = 1;       // option "attn_kv_split": key ranges per query block in the flash kernel (1 = off); attn_part = its scratch
   DevBuf attn_part;
+  int attn_stats = 0;          // option "attn_stats": the materialised-score attention accumulates the rows' largest probabilities in
+  DevBuf attn_stats_buf;       // attn_stats_buf (4 doubles, f5hip_attention_stats)
   // host inputs of queued copies (the entry points never wait for the stream) and the ordering of calls that arrive on different streams:
   // the workspace is one per context, so a call on a new stream first waits (on the GPU, not the host) for the previous call's work
   HostStage stage;

@@ -92,7 +92,8 @@ hipError_t launch_convpos_pack(const float* w, int D, int cpg, int K, float* w32
 hipError_t launch_dw_pack(const float* w, int C, float* w7, hipStream_t s);
 // row softmax for the exact (materialised-score) attention: S [rows, ld], cols >= kvlen(row) get 0
 hipError_t launch_softmax_rows(float* S, int64_t rows, int ld, int nseq, int heads, const int32_t* kvlen_per_batch, int kv_default,
-                               hipStream_t s, const int32_t* kvlen2 = nullptr, int seg2_off = 0);  // second key run: see launch_flash_attn
+                               hipStream_t s, const int32_t* kvlen2 = nullptr, int seg2_off = 0,  // second key run: see launch_flash_attn
+                               double* stats = nullptr);  // {max, sum, rows, rows > 1/2} of the rows' largest probabilities, accumulated (or null)
 // im2col for the Vocos embed conv (k=7, pad 3): mel [B, T, Cin] (frame-major) -> col [B*T, 7*Cin] with k index = ci*7 + tap
 hipError_t launch_im2col7(const float* mel, int B, int T, int Cin, int channel_major, float* col, int64_t ldc, hipStream_t s);
 

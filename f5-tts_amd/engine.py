@@ -183,6 +183,14 @@ class F5HipEngine:
     def reset_kernel_stats(self):
         self._chk(self.lib.f5hip_reset_kernel_stats(self._ctx))
 
+    def attention_stats(self, reset: bool = True) -> Dict[str, float]:
+        """How sharp the softmax rows of the materialised-score attention were since ``set_option("attn_stats", 1)`` (include/f5hip.h
+        f5hip_attention_stats): the mean / largest of the rows' largest probabilities and the share of rows above 1/2."""
+        out = (C.c_double * 4)()
+        self._chk(self.lib.f5hip_attention_stats(self._ctx, out, int(reset)))
+        rows = out[2]
+        return dict(rows=int(rows), mean_max_prob=(out[1] / rows if rows else 0.0), max_prob=out[0], frac_rows_above_half=(out[3] / rows if rows else 0.0))
+
     # -- compute -------------------------------------------------------------------------------
     def mel(self, wav: torch.Tensor, frame_major: bool = False, mel_spec_type: str = "vocos") -> torch.Tensor:
         if mel_spec_type not in ("vocos", "bigvgan"):

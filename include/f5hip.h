@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define F5HIP_ABI_VERSION 9  /* v9: option "mx_weights"; precision value 4 (a microbenchmark-only operand form of v8) removed */
+#define F5HIP_ABI_VERSION 10 /* v10: option "attn_stats" + f5hip_attention_stats; v9: option "mx_weights"; precision value 4 (a
+                                microbenchmark-only operand form of v8) removed */
 
 /* status codes */
 enum {
@@ -261,8 +262,17 @@ int f5hip_bigvgan_reset_kernel_stats(f5hip_bigvgan* v);
  * shorter workgroups for small batches, csrc/attention_kernel.h),
  * "mx_weights" (1 (default) / 0; read by the next f5hip_finalize_weights: whether the MX-line copies of the block weights that
  * F5HIP_PREC_FP16M multiplies are built — 2 more halves per block-weight element on top of the fp32 blob and the plain / hi|lo half copies,
- * +1.3 GB for F5-TTS Base; with 0 an FP16M call runs as FP16X3, for users of the other precisions who want the memory back). */
+ * +1.3 GB for F5-TTS Base; with 0 an FP16M call runs as FP16X3, for users of the other precisions who want the memory back),
+ * "attn_stats" (0 (default) / 1: the materialised-score attention — precision FP32, or "attn_impl" 1 — accumulates how sharp its softmax
+ * rows are; read with f5hip_attention_stats). */
 int f5hip_set_option(f5hip_ctx* ctx, const char* key, int64_t value);
+/* How sharp is this checkpoint's attention?  No counterpart in the reference (F.scaled_dot_product_attention, model/modules.py:511-520,
+ * is exact in fp32 whatever the logits); here the half-precision attention forms hold the 1e-3 tolerance up to a sharpness that DESIGN.md
+ * section 2 ("sharpness sweep") measures, and this call measures a checkpoint against it: with option "attn_stats" = 1, every softmax row
+ * of the materialised-score path contributes its LARGEST probability.  out4 = { largest over all rows, sum over rows, rows, rows whose
+ * largest probability exceeds 1/2 } since the option was set or the figures were last reset (reset != 0 zeroes them after reading).
+ * Synchronises the device.  INTEGRATION.md, "Which attention form does my checkpoint need?", has the thresholds. */
+int f5hip_attention_stats(f5hip_ctx* ctx, double* out4, int reset);
 /* Per-kernel-class statistics accumulated while "profile" is on: calls, total milliseconds, algorithmic
  * FLOPs and algorithmic bytes.  index in [0, f5hip_num_kernel_stats). */
 int f5hip_num_kernel_stats(const f5hip_ctx* ctx);

@@ -163,6 +163,13 @@ FULL_CASES = {
     "small_mask_ragged_b3_trained_like_sharp1p4": dict(preset="F5TTS_v1_Small_mask", wseed=2, trained=True, sharp=math.sqrt(2.0), nw=256 * 190, wavseed=4, batch=3,
                                                        nt=70, tseed=6, duration=[460, 380, 250], lens=[181, 150, 101], pad_from=50,
                                                        kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    # logits x 1.41 (to_q, to_k x 2^0.25): the point between "inside" (x 1) and "outside" (x 2) of the default attention's tolerance — the
+    # calibration of f5hip_attention_stats' thresholds ("Which attention form does my checkpoint need?")
+    "base_v1_trained_like_sharp1p2": dict(preset="F5TTS_v1_Base", wseed=0, trained=True, sharp=2.0 ** 0.25, nw=120000, wavseed=0, batch=1, nt=220, tseed=0,
+                                          duration=1406, lens=None, kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
+    "small_mask_ragged_b3_trained_like_sharp1p2": dict(preset="F5TTS_v1_Small_mask", wseed=2, trained=True, sharp=2.0 ** 0.25, nw=256 * 190, wavseed=4, batch=3,
+                                                       nt=70, tseed=6, duration=[460, 380, 250], lens=[181, 150, 101], pad_from=50,
+                                                       kw=dict(steps=8, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     "base_v1_trained_like_sharp1p7": dict(preset="F5TTS_v1_Base", wseed=0, trained=True, sharp=2.0 ** 0.75, nw=120000, wavseed=0, batch=1, nt=220, tseed=0,
                                           duration=1406, lens=None, kw=dict(steps=16, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0)),
     "small_mask_ragged_b3_trained_like_sharp1p7": dict(preset="F5TTS_v1_Small_mask", wseed=2, trained=True, sharp=2.0 ** 0.75, nw=256 * 190, wavseed=4, batch=3,

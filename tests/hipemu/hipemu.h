@@ -584,3 +584,20 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// the two global atomics the kernels use (softmax_rows_kernel's statistics): workgroups run on several host threads
+static inline double atomicAdd(double* p, double v) {
+  unsigned long long* u = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long old = __atomic_load_n(u, __ATOMIC_RELAXED), want;
+  double o;
+  do {
+    memcpy(&o, &old, 8);
+    const double n = o + v;
+    memcpy(&want, &n, 8);
+  } while (!__atomic_compare_exchange_n(u, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return o;
+}
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}

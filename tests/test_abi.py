@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = binding.load_library()
     for name in header_symbols():
         assert hasattr(lib, name)
-    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 9
+    assert lib.f5hip_abi_version() == binding.ABI_VERSION == 10
     out = subprocess.run(["nm", "-D", "--defined-only", binding.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (f5hip_[a-z_0-9]+)", out))
     assert set(header_symbols()) <= exported

@@ -256,6 +256,38 @@ def test_graph_replay_equals_eager(engines):
     assert torch.equal(eager, g1) and torch.equal(g1, g2)
 
 
+def test_attention_stats_follow_the_sharpness(engines):
+    """Option "attn_stats" / f5hip_attention_stats (include/f5hip.h): the materialised-score attention publishes every softmax row's largest
+    probability — the figure INTEGRATION.md uses to say which half-precision attention form a checkpoint needs.  Row count = cond + uncond
+    x heads x frames x blocks x steps; 1 / n <= mean <= max <= 1; weights with sharper attention (q, k projections x sqrt 2: logits x 2) read
+    sharper; the flash forms do not contribute; reading with reset zeroes."""
+    from f5_tts_amd.engine import F5HipCFM
+
+    cfg = config.DIT_TINY
+    wav = synth.synth_wave(256 * 45, seed=21)
+    text = synth.synth_text_ids(1, 50, cfg.text_num_embeds, seed=22)
+    n, steps = 120, 2
+    kw = dict(steps=steps, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=5)
+    got = {}
+    for sharp in (None, 2.0 ** 0.5):
+        eng = engines("tiny", 1, trained=True, sharp=sharp)
+        try:
+            eng.set_option("attn_stats", 1)
+            eng.attention_stats(reset=True)
+            F5HipCFM(eng, precision="fp32").sample(wav.cuda(), text, n, **kw)
+            st = eng.attention_stats()
+            F5HipCFM(eng, precision="fp16x3").sample(wav.cuda(), text, n, **kw)  # flash attention: nothing is published
+            assert eng.attention_stats()["rows"] == 0
+        finally:
+            eng.set_option("attn_stats", 0)
+        assert st["rows"] == 2 * cfg.heads * n * cfg.depth * steps, st
+        assert 1.0 / n <= st["mean_max_prob"] <= st["max_prob"] <= 1.0 + 1e-6, st
+        assert 0.0 <= st["frac_rows_above_half"] <= 1.0
+        got[sharp] = st
+    print(got)
+    assert got[2.0 ** 0.5]["mean_max_prob"] > 1.05 * got[None]["mean_max_prob"], got
+
+
 def test_flash_attention_equals_materialised_attention(engines):
     """The flash kernel (attention.hip) against the materialised-score fp32 attention (three GEMM/softmax launches)
     inside the same fp16x3 pipeline, at a frame count that is neither a multiple of the 64-key tile nor of the
@@ -989,11 +1021,12 @@ def test_ragged_masked_batch_on_trained_like_weights():
 
 @pytest.mark.parametrize("family,tols", [
     # golden -> bounds of (fp16m default, fp16m attn_impl 6, fp16m attn_impl 7, fp16x3 attn_impl 2, fp32); measured (profiles/r06g_sharpness_sweep.md)
-    ("base_v1_trained_like", {"": (7e-4, 6e-4, 6e-4, 1.5e-4, 1e-4), "_sharp1p4": (2.2e-3, 1.6e-3, 7e-4, 2e-4, 1.5e-4), "_sharp1p7": (6e-3, 4e-3, 1.5e-3, 4e-4, 3.5e-4)}),
-    ("small_mask_ragged_b3_trained_like", {"": (7e-4, 6e-4, 5e-4, 1e-4, 1e-4), "_sharp1p4": (3e-3, 1.6e-3, 6e-4, 1e-4, 1e-4), "_sharp1p7": (5e-3, 4e-3, 1.3e-3, 1.5e-4, 1.5e-4)}),
+    ("base_v1_trained_like", {"": (7e-4, 6e-4, 6e-4, 1.5e-4, 1e-4), "_sharp1p2": (1e-3, 8e-4, 5.5e-4, 1.5e-4, 1e-4), "_sharp1p4": (2.2e-3, 1.6e-3, 7e-4, 2e-4, 1.5e-4), "_sharp1p7": (6e-3, 4e-3, 1.5e-3, 4e-4, 3.5e-4)}),
+    ("small_mask_ragged_b3_trained_like", {"": (7e-4, 6e-4, 5e-4, 1e-4, 1e-4), "_sharp1p2": (1e-3, 7e-4, 5e-4, 1e-4, 1e-4), "_sharp1p4": (3e-3, 1.6e-3, 6e-4, 1e-4, 1e-4), "_sharp1p7": (5e-3, 4e-3, 1.3e-3, 1.5e-4, 1.5e-4)}),
 ])
 def test_sharpness_sweep_full_size(family, tols):
-    """VERDICT r05 item 3, measured instead of argued: the trained-like goldens with every attention logit x 2 and x 2.8 (to_q, to_k x sqrt 2,
+    """VERDICT r05 item 3, measured instead of argued: the trained-like goldens with every attention logit x 1.41, x 2 and x 2.8 (to_q, to_k
+    x 2^0.25 — inside the 1e-3 tolerance in the default mode: 7.0e-4 / 7.9e-4, the point f5hip_attention_stats' thresholds are calibrated on —, x sqrt 2,
     x 2^0.75; minted by the reference's own CFM.sample; at x 4 the reference's fp32 result is itself only reproducible to 1.3e-3 and at x 16
     not at all, tests/golden/pins.json).  What the sweep showed: the error of the DEFAULT half-precision attention —
     MX-corrected scores, plain fp16 P and V — GROWS with the logits (4.9e-4 -> 1.4e-3 -> 4e-3): it leaves the 1e-3 tolerance between x 1.4

@@ -92,7 +92,8 @@ ENGINE_TESTS = ["test_bigvgan_mel_matches_reference_golden", "test_mel_too_short
                 "test_edit_mask_and_no_ref_audio", "test_vocos_decode_matches_oracle_golden", "test_vocos_batch_and_min_frames",
                 "test_flash_attention_equals_materialised_attention", "test_invalid_arguments_raise", "test_speech_edit_matches_oracle",
                 "test_all_padding_text_and_single_frame_prompt", "test_weight_blob_receiver_equals_the_rank_that_loaded",
-                "test_fp16m_runs_as_fp16x3_where_the_mx_tiles_do_not_apply", "test_hip_istft_against_the_reference_conv_istft_fixture"]
+                "test_fp16m_runs_as_fp16x3_where_the_mx_tiles_do_not_apply", "test_hip_istft_against_the_reference_conv_istft_fixture",
+                "test_attention_stats_follow_the_sharpness"]
 if os.environ.get("F5HIP_SHIM_FULL") == "1":  # 15-80 s each on the shim; pass as well (the CPU suite keeps to a few minutes without them)
     # test_graph_replay_equals_eager: stream capture is emulated by recording closures (tests/hipemu/hipemu.h GraphRec); the default suite
     # covers the captured path through tests/test_bench_on_shim.py

@@ -177,6 +177,11 @@ evidence)
   tag=${1:?tag}; out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
   timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $out/gpu_tests.log; cat $out/gpu_tests.log
   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/smoke.log
+  # the counter passes first, installed as profiles/<tag>_pmc_*.json in this copy of the tree: the bench lines of the SAME call then quote them as
+  # roofline.traffic (bench.py takes a committed PMC json only if its kernel_source_hash is that of the sources it runs)
+  pmc $out fp16m_b1 --batch 1 --nfe 16 --no-other-configs
+  pmc $out fp16m_b32 --batch 32 --nfe 2 --no-other-configs
+  for f in $out/pmc_*.json; do cp $f profiles/${tag}_$(basename $f); done
   # the headline line exactly as the driver runs it (default precision fp16m; carries cpu_baseline and other_configs = configs[2], configs[4])
   timeout 1500 python bench.py --steps 10 --warmup 3 > $out/bench_b1.json 2> $out/bench_b1.err
   Q="--no-cpu-baseline --no-other-configs"
@@ -193,8 +198,6 @@ evidence)
   for f in $out/bench_*.json; do line $f $(basename $f .json); done
   trace $out b1 --steps 3 --warmup 1 --no-other-configs
   trace $out b32_nfe32 --steps 1 --warmup 1 --batch 32 --nfe 32 --no-other-configs
-  pmc $out fp16m_b1 --batch 1 --nfe 16 --no-other-configs
-  pmc $out fp16m_b32 --batch 32 --nfe 2 --no-other-configs
   B1="2812,3072,1024;2812,1024,1024;2812,2048,1024;2812,1024,2048"
   MID="11248,2048,1024;22496,1024,2048;89984,2048,1024;89984,1024,2048"
   { for epi in 1 2; do
