@@ -107,6 +107,21 @@ int main(void) {
     if (e == 0.0) { fprintf(stderr, "silent wave\n"); return 1; }
     free(w);
   }
+  /* how sharp are this model's softmax rows (ABI v10)?  one fp32 call with the option on: rows were counted, the figures are probabilities */
+  {
+    double st[4];
+    if (f5hip_attention_stats(ctx, st, 0) == 0) { fprintf(stderr, "attention statistics readable before the option was ever set\n"); return 1; }
+    CHECK(f5hip_set_option(ctx, "attn_stats", 1));
+    CHECK(f5hip_sample(ctx, 1, N, cond_d, cond_mask, text, NTXT, duration, 0, y0_d, t, STEPS, 0, 2.0f, F5HIP_PREC_FP32, out2_d, NULL, NULL));
+    CHECK(f5hip_attention_stats(ctx, st, 1));
+    CHECK(f5hip_set_option(ctx, "attn_stats", 0));
+    if (!(st[2] > 0.0 && st[1] / st[2] >= 1.0 / N && st[1] / st[2] <= st[0] && st[0] <= 1.0 + 1e-6 && st[3] <= st[2])) {
+      fprintf(stderr, "attention statistics out of range: max %g sum %g rows %g above-half %g\n", st[0], st[1], st[2], st[3]);
+      return 1;
+    }
+    CHECK(f5hip_attention_stats(ctx, st, 0));
+    if (st[2] != 0.0) { fprintf(stderr, "attention statistics not reset\n"); return 1; }
+  }
   /* argument errors come back as status codes with a message, never as crashes */
   if (f5hip_sample(ctx, 1, N, cond_d, cond_mask, text, NTXT, duration, 0, y0_d, t, STEPS, 7, 2.0f, 0, out_d, NULL, NULL) == 0 ||
       strlen(f5hip_last_error(ctx)) == 0) { fprintf(stderr, "bad ode_method accepted\n"); return 1; }
