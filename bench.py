@@ -235,6 +235,7 @@ def main():
     from f5_tts_amd.engine import F5HipCFM, F5HipEngine, F5HipVocos
 
     rank, local, world = fdist.init_distributed()
+    grouped = torch.distributed.is_initialized()  # world > 1 — or a one-rank group forced with F5HIP_DIST_FORCE=1 (tests/test_gpu_rccl.py: the whole rank protocol over RCCL on a one-GPU box)
     if world != max(a.gpus, 1):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to print a line for the wrong job size")
 
@@ -258,8 +259,8 @@ def main():
     why = fdist.check_census(census, world)
     if why is not None:
         raise SystemExit(f"bench.py: --gpus {a.gpus}: {why}; refusing to print a line for a job that is not {world} GPUs")
-    weights_via = "rccl broadcast of the packed blob from rank 0" if world > 1 else "local (single rank)"
-    if world > 1:
+    weights_via = "rccl broadcast of the packed blob from rank 0" if grouped else "local (single rank)"
+    if grouped:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     tb0 = time.perf_counter()
@@ -304,7 +305,7 @@ def main():
     one_pass()  # set-up, like loading the weights: workspace allocation and graph capture happen here, whatever --warmup says
     for _ in range(a.warmup):
         one_pass()
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -312,13 +313,13 @@ def main():
         wave = one_pass()
     torch.cuda.synchronize(dev)
     my_s = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
     dt = fdist.barrier_max_seconds(time.perf_counter() - t0, dev)
     assert wave.shape == (B, HOP * (t_gen if big else t_gen - 1)) and bool(torch.isfinite(wave).all())
     per_rank_ms = [1e3 * my_s / a.steps]
     seen = fdist.ranks_seen(dev)  # an all-reduce of ones over RCCL: the ranks that really took part (outside the timed region)
-    if world > 1:
+    if grouped:
         box = [None] * world
         torch.distributed.all_gather_object(box, (per_rank_ms[0], numa))
         per_rank_ms, numa_all = [b[0] for b in box], [b[1] for b in box]
@@ -363,8 +364,8 @@ def main():
                                (f" (BASELINE.json configs[{which}])" if which is not None else ""),
                    "batch_per_gpu": B, "global_batch": B * world, "frames": duration, "nfe": a.nfe, "graph": not a.no_graph,
                    "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast, no in-step collective", "weights": weights_via,
-                   "rccl_ranks": world if world > 1 else 0, "rccl_ranks_seen": seen if world > 1 else 0,
-                   "rccl_devices": [f"rank {d['rank']}: {d['host']} cuda:{d['device_index']} pci {d['pci_bus_id']}" for d in census] if world > 1 else [],
+                   "rccl_ranks": world if grouped else 0, "rccl_ranks_seen": seen if grouped else 0,
+                   "rccl_devices": [f"rank {d['rank']}: {d['host']} cuda:{d['device_index']} pci {d['pci_bus_id']}" for d in census] if grouped else [],
                    "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms],
                    "host_numa_pinning": [{k: v for k, v in n.items() if v is not None} for n in numa_all],
                    "weight_broadcast_plus_finalize_s": round(bcast_s, 4),
@@ -430,7 +431,7 @@ def main():
         torch.cuda.empty_cache()
         res["other_configs"] = other_configs(a)
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -22,7 +22,8 @@ def init_distributed(backend: str | None = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # F5HIP_DIST_FORCE=1: a process group even for ONE rank — every collective of the job then really runs (RCCL on a one-GPU box, gloo on the shim)
+    if (world > 1 or os.environ.get("F5HIP_DIST_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -59,7 +60,7 @@ def shard_balanced(costs: Sequence[float], world: int) -> List[List[int]]:
 def broadcast_blob(blob: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20) -> None:
     """Broadcast the packed weight blob in <=256 MiB chunks (few, large collectives; xGMI links are
     point-to-point so a ring/tree broadcast is per-link bound — ~1.4 GB fp32 takes ~10 ms)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():  # (a one-rank group still goes through the collective: tests/test_gpu_rccl.py runs RCCL itself that way)
         return
     flat = blob.view(-1)
     for s in range(0, flat.numel(), chunk_elems):
@@ -68,7 +69,7 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0, chunk_elems: int = 64 << 20
 
 def broadcast_engine_weights(engine, src: int = 0) -> None:
     """Rank `src` has loaded the state dict; everyone else receives the blob and finalises."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         blob = engine.weight_blob()  # an alias of the context's device memory (engine._as_tensor refuses to hand out a copy)
         broadcast_blob(blob, src=src)
         # which entries the sender actually read (a checkpoint's optional buffers travel in the blob; the mask says to use them)
@@ -81,7 +82,7 @@ def broadcast_engine_weights(engine, src: int = 0) -> None:
 
 def barrier_max_seconds(seconds: float, device: torch.device | None = None) -> float:
     """MAX over ranks of a per-rank wall time (the bench contract)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -142,7 +143,7 @@ def device_identity(local_rank: int, device_type: str = "cuda") -> dict:
 
 def device_census(ident: dict) -> List[dict]:
     """All-gather of every rank's ``device_identity`` over the job's process group (the group the weight broadcast used), in rank order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return [ident]
     box: List[dict | None] = [None] * dist.get_world_size()
     dist.all_gather_object(box, ident)

@@ -43,6 +43,18 @@ def test_single_rank(engine_emu_lib):  # noqa: F811
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
+def test_single_rank_with_a_forced_group(engine_emu_lib):  # noqa: F811
+    """F5HIP_DIST_FORCE=1: a ONE-rank process group (gloo here; RCCL in tests/test_gpu_rccl.py) — census, broadcast, barriers and reductions all
+    run, and the line names the group."""
+    import socket
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    d = run([sys.executable, HARNESS, "--tiny", "--nfe", "1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], engine_emu_lib,
+            F5HIP_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["rccl_ranks"] == 1 and c["rccl_ranks_seen"] == 1 and len(c["rccl_devices"]) == 1 and "rccl broadcast" in c["weights"], c
+
+
 def test_plain_gpus_2_command_launches_its_own_two_ranks(engine_emu_lib):  # noqa: F811
     """`python bench.py --gpus 2 ...` with no launcher around it (what a user types; the driver wraps it in torch.distributed.run itself)."""
     d = run([sys.executable, HARNESS, "--gpus", "2", "--tiny", "--nfe", "1", "--steps", "2", "--warmup", "1"], engine_emu_lib, timeout=1200)
